@@ -37,6 +37,7 @@ def test_each_phase_on_random_state(pkg, which):
         getattr(b, phase)()
         for n in outs:
             assert rel_err(a.get(n), b.get(n)) < 1e-12, (phase, n)
+            a.put(n, b.get(n))  # re-sync so that every phase is checked in isolation
     a.set_iter(3)
     b.set_iter(3)
     assert a.termination_condition() == b.termination_condition()
