@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/s of the batched quadrotor solve (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`;
+     run directly with --gpus N > 1 it re-launches itself that way before touching the GPU.)
+
+One "step" = one cold-started batched solve on every rank: reset the persistent ADMM state, then ONE
+launch of k_admm_solve running 200 forced ADMM iterations (tolerances 0, check_termination 1, so the
+residual reductions are always paid) for `--batch-per-gpu` quadrotor instances (nx=12, nu=4, N=50, box
+constraints on states and inputs, rho=5) whose x0 are already resident in HBM. Weak scaling: the per-GPU
+shard is fixed (8,192 instances), so 8 GPUs reproduce BASELINE config 5 exactly (65,536 instances);
+instances are independent, so there is no data-path collective -- only a summary all-reduce after the
+timed region.
+
+Prints ONE JSON line on rank 0 (see the keys below). `value` is the whole-job aggregate
+instance-iterations per second; `roofline` prices the solve kernel's ALGORITHMIC bytes
+(8*(11U+9X) per instance-iteration) against the 8 TB/s HBM peak using the kernel duration
+measured live with HIP events on the kernel's stream; `cpu_baseline` times the reference's own compiled
+core (oracle/_ref, kind "reference") -- or this repo's C restatement (kind "port") where that binary is
+absent -- on the host cores, on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+PEAK_FP64_TFLOPS = 78.6    # MI355X FP64 vector peak (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--iters", type=int, default=200, help="forced ADMM iterations per solve")
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args) -> int:
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(P, prob, iters: int, seconds: float) -> dict:
+    """Reference core (or the C port) on all host cores: each thread owns one solver object and runs
+    cold-started 200-iteration solves of seeded quadrotor instances until the time budget is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O  # checker / baseline only
+
+    settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1)
+    cls = O.OracleRef if O.ref_available() else O.OraclePort
+    cores = os.cpu_count() or 1
+    per_call = 16
+    x0s = P.quadrotor_batch_x0(per_call * cores)
+    solvers = [cls(prob).load_problem(prob, settings) for _ in range(cores)]
+    counts = [0] * cores
+    deadline = time.perf_counter() + seconds
+
+    def work(t):
+        mine = x0s[:, t * per_call:(t + 1) * per_call]
+        while time.perf_counter() < deadline:
+            counts[t] += solvers[t].bench_solves(mine, 1)  # ctypes releases the GIL during the call
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    total = sum(counts)
+    # single-thread figure from a short separate run (for the per-core anchor of SURVEY.md section 6)
+    t1 = time.perf_counter()
+    one = solvers[0].bench_solves(x0s[:, :per_call], 2)
+    dt1 = time.perf_counter() - t1
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": total / dt, "unit": "ADMM iters/s", "cores": cores, "kind": cls.kind,
+            "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={prob.N} solves over {cores} threads in {dt:.1f} s "
+                      f"(seeded x0, same settings as the GPU run)",
+            "single_thread_iters_per_s": one / dt1, "us_per_iter_single_thread": 1e6 * dt1 / one, "cpu_model": cpu_model}
+
+
+def main() -> int:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return relaunch_under_torchrun(args)  # nothing has touched the GPU yet
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    P = pkg.problems
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    prob = P.quadrotor(args.horizon)
+    B = args.batch_per_gpu
+    first, count = pkg.batch.shard_range(B * world, rank, world)
+    x0_host = P.quadrotor_batch_x0(count, offset=first)              # (12, count), seeded per global instance index
+    x0_dev = torch.from_numpy(np.ascontiguousarray(x0_host.T)).to(dev)  # [count][nx] == nx x count column-major
+
+    solver = pkg.TinyMPC()
+    solver.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=count, device=local_rank, rho=prob.rho,
+                 abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
+    solver.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    solver.set_x0_batch(x0_dev)  # device-to-device: inputs are HBM-resident before the timed region
+    solver.synchronize()
+
+    def step() -> float:
+        solver.reset_workspace()      # cold start: every step does identical work
+        return solver.solve_timed()   # one launch of k_admm_solve; ms from HIP events on its stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_avg = float(t[0]), float(t[1])
+
+    # after the timed region: the one collective of the batched mode (summary statistics)
+    st = solver.get_stats_batch()
+    summary = pkg.batch.allreduce_summary(pkg.batch.local_summary(st["iter"], st["status"], st["residuals"]), device=dev)
+
+    total_instances = B * world
+    inst_iters_per_step = total_instances * args.iters
+    value = inst_iters_per_step * args.steps / elapsed
+    bytes_iter = prob.bytes_per_iteration()
+    flops_iter = prob.flops_per_iteration()
+    kernel_s = kernel_ms_avg * 1e-3
+    alg_bytes_per_launch = count * args.iters * bytes_iter
+    achieved_gbs = alg_bytes_per_launch / kernel_s / 1e9
+
+    out = None
+    if rank == 0:
+        info = solver.launch_info()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("batch_per_gpu") == B and tj.get("iters") == args.iters and tj.get("horizon") == args.horizon:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "ADMM iterations/s, batched quadrotor nx=12 nu=4 N=%d (instance-iterations/s, whole job)" % prob.N,
+            "value": value, "unit": "ADMM iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "quadrotor hover nx=12 nu=4 N=%d, box x in [-5,5] u in [-0.5,0.5], rho=5, cold start, "
+                                   "%d forced ADMM iterations per solve (tol 0, check_termination 1), %d instances per GPU "
+                                   "(BASELINE config 5 = 65,536 instances at 8 GPUs)" % (prob.N, args.iters, B),
+                       "batch_per_gpu": B, "global_batch": total_instances, "iters_per_solve": args.iters,
+                       "parallelism": "independent instances sharded x%d, no data-path collective" % world},
+            "solves_per_s": value / args.iters,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                         "kernel": "k_admm_solve<16,16>", "kernel_ms_avg": kernel_ms_avg,
+                         "algorithmic_bytes_per_instance_iteration": bytes_iter,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "note": "ADMM state is LDS-resident for the whole solve, so measured HBM traffic is far below the "
+                                 "algorithmic (streaming) bytes and frac may exceed 1; the kernel is FP64-issue bound",
+                         "fp64_tflops": count * args.iters * flops_iter / kernel_s / 1e12,
+                         "fp64_frac_of_vector_peak": count * args.iters * flops_iter / kernel_s / 1e12 / PEAK_FP64_TFLOPS},
+            "launch": info,
+            "summary": summary,
+        }
+        if not args.no_single:
+            one = pkg.TinyMPC()
+            one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho,
+                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
+            one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            one.set_x0(prob.x0)
+            ms = []
+            for k in range(13):
+                one.reset_workspace()
+                ms.append(one.solve_timed())
+            ms = sorted(ms[3:])
+            med = ms[len(ms) // 2]
+            out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
+                                      "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            one.reset()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, prob, args.iters, args.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    solver.reset()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

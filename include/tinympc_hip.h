@@ -1,0 +1,199 @@
+/* tinympc_hip.h -- C ABI of libtinympc_hip.so: the MI355X (gfx950) implementation of TinyMPC's
+ * ADMM hot path behind the reference's MEX verb surface.
+ *
+ * The reference exposes ONE MEX function, tinympc_matlab('<verb>', args...), dispatching 17 string
+ * verbs onto a process-global solver (/root/reference/src/bindings.cpp:17, 641-692). This header
+ * declares one extern "C" function per verb, taking an explicit handle instead of the global, raw
+ * column-major `const double*` buffers with explicit sizes instead of mxArrays, and returning an
+ * int status instead of long-jumping out through mexErrMsgIdAndTxt. A MEX shim that forwards the
+ * 17 verbs to these functions is in tinympc-matlab_amd/matlab/tinympc_matlab_mex.cpp; INTEGRATION.md
+ * shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - All matrices are FP64, column-major, column = knot point (reference types.hpp:15-17,
+ *    bindings.cpp:40-41). Inputs are copied during the call (the caller keeps ownership);
+ *    outputs are written into caller-allocated buffers.
+ *  - Every function returns TINYMPC_OK (0) or a negative TINYMPC_ERR_* code; the message is
+ *    available from tinympc_last_error() (thread-local). Nothing throws or long-jumps.
+ *  - A handle is externally synchronised (one caller at a time), owns one HIP stream and all its
+ *    device buffers, and is bound to one GPU. tinympc_solve is synchronous.
+ *  - There is NO CPU fallback: without a GPU / without the gfx950 code object every compute verb
+ *    fails with TINYMPC_ERR_NO_DEVICE or TINYMPC_ERR_HIP.
+ */
+#ifndef TINYMPC_HIP_H
+#define TINYMPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TINYMPC_ABI_VERSION 1
+
+#define TINYMPC_OK 0
+#define TINYMPC_ERR_INVALID_INPUT (-1)   /* MEX id TinyMPC:InvalidInput   (bindings.cpp:22,50,...) */
+#define TINYMPC_ERR_NOT_INITIALIZED (-2) /* MEX id TinyMPC:NotInitialized (bindings.cpp:113,...)   */
+#define TINYMPC_ERR_HIP (-3)             /* a HIP runtime call failed (message has the hipError)   */
+#define TINYMPC_ERR_UNSUPPORTED (-4)     /* problem shape outside what the kernels support         */
+#define TINYMPC_ERR_NOT_IMPLEMENTED (-5) /* verb exported for ABI completeness, out of scope       */
+#define TINYMPC_ERR_NO_DEVICE (-6)       /* no HIP device visible                                  */
+#define TINYMPC_ERR_ALLOC (-7)
+
+/* solver status values, as the reference core reports them (admm.cpp:114, 183) */
+#define TINYMPC_STATUS_SOLVED 1
+#define TINYMPC_STATUS_UNSOLVED 11
+
+typedef struct tinympc_solver tinympc_solver; /* opaque */
+
+const char *tinympc_last_error(void);
+int tinympc_abi_version(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int tinympc_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * The 17 MEX verbs (bindings.cpp:641-692). `verbose` is the trailing scalar every verb takes.
+ * ------------------------------------------------------------------------------------------- */
+
+/* verb 'setup'  (bindings.cpp:47-104 -> tiny_setup, tiny_api.cpp:21-122).
+ * A nx*nx, B nx*nu, fdyn nx (may be NULL = zeros), Q nx*nx, R nu*nu (only the diagonals of Q and R
+ * are used, tiny_api.cpp:90-91). Allocates the handle, uploads the problem, runs the LQR-cache
+ * precompute kernel (tiny_precompute_and_set_cache, tiny_api.cpp:124-190) on the device and installs
+ * the core's default settings (tiny_api.cpp:213-231). Equivalent to
+ * tinympc_setup_batch(out, ..., batch=1, device=-1). */
+int tinympc_setup(tinympc_solver **out, const double *A, const double *B, const double *fdyn,
+                  const double *Q, const double *R, double rho, int nx, int nu, int N, int verbose);
+
+/* verb 'set_x0' (bindings.cpp:107-131 -> tiny_set_x0, tiny_api.cpp:233-243). len must be nx.
+ * In a batched handle this sets instance 0. */
+int tinympc_set_x0(tinympc_solver *s, const double *x0, int len, int verbose);
+
+/* verb 'set_x_ref' (bindings.cpp:134-158 -> tiny_api.cpp:245-255). Xref is nx x N. */
+int tinympc_set_x_ref(tinympc_solver *s, const double *Xref, int rows, int cols, int verbose);
+
+/* verb 'set_u_ref' (bindings.cpp:161-185 -> tiny_api.cpp:257-267). Uref is nu x (N-1). */
+int tinympc_set_u_ref(tinympc_solver *s, const double *Uref, int rows, int cols, int verbose);
+
+/* verb 'set_bound_constraints' (bindings.cpp:188-209). x_min/x_max nx x N, u_min/u_max nu x (N-1),
+ * already expanded by the caller (TinyMPC.m:256-264). Enables both bound flags (bindings.cpp:206-207). */
+int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const double *x_max,
+                                  const double *u_min, const double *u_max, int verbose);
+
+/* verb 'solve' (bindings.cpp:212-232 -> tiny_solve -> solve(), admm.cpp:109-207). One kernel launch
+ * runs the whole ADMM loop, in-kernel termination included, for every instance of the handle.
+ * Returns TINYMPC_OK whether or not the solver converged (the MEX verb swallows the core status,
+ * bindings.cpp:224-231); the core status is reported by tinympc_get_stats. */
+int tinympc_solve(tinympc_solver *s, int verbose);
+
+/* verb 'get_solution' (bindings.cpp:235-261): x_out nx*N, u_out nu*(N-1) = the projected slack
+ * variables vnew/znew (admm.cpp:187-188, 204-205). Instance 0 of a batched handle. */
+int tinympc_get_solution(tinympc_solver *s, double *x_out, double *u_out, int verbose);
+
+/* verb 'get_stats' (bindings.cpp:264-285): iter, status, primal_residual_state, primal_residual_input. */
+int tinympc_get_stats(tinympc_solver *s, int *iter, int *status, double *pri_res_state,
+                      double *pri_res_input, int verbose);
+
+/* verb 'codegen' (bindings.cpp:288-316): embedded-C++ emitter, OUT OF SCOPE for this build
+ * (SURVEY.md section 2 #7). Always TINYMPC_ERR_NOT_IMPLEMENTED. */
+int tinympc_codegen(tinympc_solver *s, const char *output_dir, int verbose);
+
+/* verb 'set_sensitivity_matrices' (bindings.cpp:319-361): the reference stores nothing (prints norms
+ * when verbose); validated and accepted as a no-op here too. */
+int tinympc_set_sensitivity_matrices(tinympc_solver *s, const double *dK, const double *dP,
+                                     const double *dC1, const double *dC2, int verbose);
+
+/* verb 'set_cache_terms' (bindings.cpp:364-405): overwrite Kinf (nu x nx), Pinf (nx x nx),
+ * Quu_inv (nu x nu), AmBKt (nx x nx); C1/C2 alias the last two. */
+int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf,
+                            const double *Quu_inv, const double *AmBKt, int verbose);
+
+/* verb 'set_linear_constraints' (bindings.cpp:408-431): rows of Alin_x (nlx x nx) * x <= blin_x and
+ * Alin_u (nlu x nu) * u <= blin_u at every knot; a non-empty side is auto-enabled (:422-429).
+ * PARITY UNPINNED (no core source in the reference tree). */
+int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, const double *blin_x,
+                                   int nlx, const double *Alin_u, const double *blin_u, int nlu);
+
+/* verb 'set_cone_constraints' (bindings.cpp:433-478): per cone (start row Ac, 0-based; dimension qc;
+ * slope c), constraint ||s[Ac : Ac+qc-1)||_2 <= c * s[Ac+qc-1] at every knot. State cones first,
+ * then input cones (the MATLAB-side order). PARITY UNPINNED. */
+int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *qcx, const double *cx,
+                                 int ncx, const int *Acu, const int *qcu, const double *cu, int ncu);
+
+/* verb 'codegen_with_sensitivity' (bindings.cpp:481-529): OUT OF SCOPE, TINYMPC_ERR_NOT_IMPLEMENTED. */
+int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *output_dir, const double *dK,
+                                     const double *dP, const double *dC1, const double *dC2,
+                                     int verbose);
+
+/* verb 'reset' (bindings.cpp:532-545): destroy the handle and free every host and device buffer.
+ * *s is set to NULL. Passing NULL / a NULL handle is a no-op, as in the reference. */
+int tinympc_reset(tinympc_solver **s, int verbose);
+
+/* verb 'update_settings' (bindings.cpp:548-603), same argument order as the MEX verb. adaptive_rho
+ * must be 0: the adaptive-rho side-car is out of scope and enabling it fails
+ * loudly with TINYMPC_ERR_NOT_IMPLEMENTED rather than silently solving something else. */
+int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                            int check_termination, int en_state_bound, int en_input_bound,
+                            int en_state_soc, int en_input_soc, int en_state_linear,
+                            int en_input_linear, int adaptive_rho, double adaptive_rho_min,
+                            double adaptive_rho_max, int adaptive_rho_enable_clipping, int verbose);
+
+/* verb 'print_problem_data' (bindings.cpp:606-638): prints the same scalars to stdout. */
+int tinympc_print_problem_data(tinympc_solver *s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Extensions (not in the reference): cache read-back, batched mode, timing.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Read back what the precompute kernel produced (any pointer may be NULL). riccati_iters = number
+ * of fixed-point steps taken before max|dK| < 1e-5 (tiny_api.cpp:157). */
+int tinympc_get_cache(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt,
+                      int *riccati_iters);
+
+/* All four residuals of instance 0: primal state, dual state, primal input, dual input
+ * (admm.cpp:93-96). */
+int tinympc_get_residuals(tinympc_solver *s, double residuals[4]);
+
+/* Batched setup: `batch` independent MPC instances sharing (A,B,fdyn,Q,R,rho,bounds,refs,settings),
+ * each with its own x0 and its own persistent ADMM state. device < 0 keeps the current HIP device. */
+int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, const double *fdyn,
+                        const double *Q, const double *R, double rho, int nx, int nu, int N,
+                        int batch, int device, int verbose);
+
+/* x0s is nx x count (column b = instance first+b), host memory. */
+int tinympc_set_x0_batch(tinympc_solver *s, const double *x0s, int first, int count);
+/* Same, from device memory on the handle's GPU (e.g. a torch tensor's data_ptr); asynchronous on
+ * the handle's stream. */
+int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int first, int count);
+
+/* Zero the persistent ADMM state (cold start) of every instance; x0 is kept. */
+int tinympc_reset_workspace(tinympc_solver *s);
+
+/* Solutions of instances [first, first+count): x_out nx*N*count, u_out nu*(N-1)*count. */
+int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count);
+/* First control of each instance, nu x count: what a closed-loop caller applies. */
+int tinympc_get_first_controls_batch(tinympc_solver *s, double *u0_out, int first, int count);
+/* iters[count], status[count], residuals 4 x count (any may be NULL). */
+int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *residuals, int first,
+                            int count);
+/* Device pointers of the solution buffers (nx*N*batch and nu*(N-1)*batch doubles), valid until
+ * tinympc_reset; lets a caller consume results without a D2H copy. */
+int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u);
+
+/* Launch the solve without waiting (same kernel as tinympc_solve); pair with tinympc_synchronize. */
+int tinympc_solve_async(tinympc_solver *s);
+int tinympc_synchronize(tinympc_solver *s);
+/* Synchronous solve that also reports the kernel's duration measured with HIP events recorded on
+ * the handle's stream immediately around the launch. */
+int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
+
+/* Launch geometry of the solve kernel, for reports: lanes per instance, instances per wavefront,
+ * workgroups in the grid, dynamic LDS bytes per workgroup, and whether the per-knot bound/reference
+ * tables are LDS-resident. Any pointer may be NULL. */
+int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave,
+                            int *workgroups, int *lds_bytes, int *tables_in_lds);
+
+/* The HIP stream of the handle as an opaque pointer (hipStream_t). */
+void *tinympc_get_stream(tinympc_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYMPC_HIP_H */

@@ -17,6 +17,7 @@
 // prebuilt binary only.
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
 
@@ -31,14 +32,26 @@ tinyMatrix to_mat(const double *p, int rows, int cols) {
 
 // The reference core chats on std::cout (tiny_api.cpp:138-179, admm.cpp:190); silence it
 // unless the caller asked for verbose output.
+// Process-wide and reference-counted, so that bench.py's baseline threads (one solver object each)
+// can overlap: the first one in swaps the buffer, the last one out restores it.
 struct CoutSilencer {
-    std::streambuf *old;
-    std::ostringstream sink;
-    explicit CoutSilencer(bool quiet) : old(nullptr) {
-        if (quiet) old = std::cout.rdbuf(sink.rdbuf());
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static int &depth() { static int d = 0; return d; }
+    static std::streambuf *&saved() { static std::streambuf *p = nullptr; return p; }
+    static std::ostringstream &sink() { static std::ostringstream s; return s; }
+    bool on;
+    explicit CoutSilencer(bool quiet) : on(quiet) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(mu());
+        if (depth()++ == 0) saved() = std::cout.rdbuf(sink().rdbuf());
     }
     ~CoutSilencer() {
-        if (old) std::cout.rdbuf(old);
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(mu());
+        if (--depth() == 0) {
+            std::cout.rdbuf(saved());
+            sink().str(std::string());
+        }
     }
 };
 

@@ -1,0 +1,127 @@
+"""ctypes binding of libtinympc_hip.so (include/tinympc_hip.h). No torch, no numpy math: plumbing only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinympc_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+Handle = C.c_void_p
+
+OK = 0
+ERR_INVALID_INPUT = -1
+ERR_NOT_INITIALIZED = -2
+ERR_HIP = -3
+ERR_UNSUPPORTED = -4
+ERR_NOT_IMPLEMENTED = -5
+ERR_NO_DEVICE = -6
+ERR_ALLOC = -7
+
+# MEX error identifiers the reference raises for the same conditions (bindings.cpp)
+MEX_ERROR_IDS = {
+    ERR_INVALID_INPUT: "TinyMPC:InvalidInput",
+    ERR_NOT_INITIALIZED: "TinyMPC:NotInitialized",
+    ERR_HIP: "TinyMPC:Exception",
+    ERR_UNSUPPORTED: "TinyMPC:SetupFailed",
+    ERR_NOT_IMPLEMENTED: "TinyMPC:InvalidFunction",
+    ERR_NO_DEVICE: "TinyMPC:SetupFailed",
+    ERR_ALLOC: "TinyMPC:SetupFailed",
+}
+
+# name -> (restype, argtypes); mirrors include/tinympc_hip.h one to one
+SIGNATURES = {
+    "tinympc_last_error": (C.c_char_p, []),
+    "tinympc_abi_version": (C.c_int, []),
+    "tinympc_device_count": (C.c_int, []),
+    "tinympc_setup": (C.c_int, [C.POINTER(Handle), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tinympc_set_x0": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
+    "tinympc_set_x_ref": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int, C.c_int]),
+    "tinympc_set_u_ref": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int, C.c_int]),
+    "tinympc_set_bound_constraints": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    "tinympc_solve": (C.c_int, [Handle, C.c_int]),
+    "tinympc_get_solution": (C.c_int, [Handle, c_double_p, c_double_p, C.c_int]),
+    "tinympc_get_stats": (C.c_int, [Handle, c_int_p, c_int_p, c_double_p, c_double_p, C.c_int]),
+    "tinympc_codegen": (C.c_int, [Handle, C.c_char_p, C.c_int]),
+    "tinympc_set_sensitivity_matrices": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    "tinympc_set_cache_terms": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    "tinympc_set_linear_constraints": (C.c_int, [Handle, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, C.c_int]),
+    "tinympc_set_cone_constraints": (C.c_int, [Handle, c_int_p, c_int_p, c_double_p, C.c_int,
+                                               c_int_p, c_int_p, c_double_p, C.c_int]),
+    "tinympc_codegen_with_sensitivity": (C.c_int, [Handle, C.c_char_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    "tinympc_reset": (C.c_int, [C.POINTER(Handle), C.c_int]),
+    "tinympc_update_settings": (C.c_int, [Handle, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "tinympc_print_problem_data": (C.c_int, [Handle]),
+    "tinympc_get_cache": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "tinympc_get_residuals": (C.c_int, [Handle, c_double_p]),
+    "tinympc_setup_batch": (C.c_int, [C.POINTER(Handle), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                      C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tinympc_set_x0_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
+    "tinympc_set_x0_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_int, C.c_int]),
+    "tinympc_reset_workspace": (C.c_int, [Handle]),
+    "tinympc_get_solution_batch": (C.c_int, [Handle, c_double_p, c_double_p, C.c_int, C.c_int]),
+    "tinympc_get_first_controls_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
+    "tinympc_get_stats_batch": (C.c_int, [Handle, c_int_p, c_int_p, c_double_p, C.c_int, C.c_int]),
+    "tinympc_get_solution_device_ptrs": (C.c_int, [Handle, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "tinympc_solve_async": (C.c_int, [Handle]),
+    "tinympc_synchronize": (C.c_int, [Handle]),
+    "tinympc_solve_timed": (C.c_int, [Handle, C.POINTER(C.c_float)]),
+    "tinympc_get_launch_info": (C.c_int, [Handle, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "tinympc_get_stream": (C.c_void_p, [Handle]),
+}
+
+_lib = None
+
+
+class TinyMPCError(RuntimeError):
+    """Raised for any non-zero status of the C ABI; `.identifier` is the MEX error id the reference
+    would have raised (bindings.cpp), `.code` the TINYMPC_ERR_* value."""
+
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.identifier = MEX_ERROR_IDS.get(code, "TinyMPC:Exception")
+        super().__init__(f"{self.identifier}: {message}")
+
+
+def load_library() -> C.CDLL:
+    """dlopen libtinympc_hip.so and type every exported entry point. Fails loudly when the library
+    (the HIP extension) is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "The HIP library is the only implementation; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export: {missing}")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load_library().tinympc_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise TinyMPCError(code, last_error())
+
+
+def abi_version() -> int:
+    return int(load_library().tinympc_abi_version())
+
+
+def device_count() -> int:
+    return int(load_library().tinympc_device_count())

@@ -1,0 +1,674 @@
+// tinympc_capi.hip -- the extern "C" boundary declared in include/tinympc_hip.h.
+//
+// Host-side bookkeeping only: argument validation with the reference's error behaviour, device
+// buffer ownership, lazy rebuild of the fused operators / per-knot tables when their inputs change,
+// and kernel launches. Every number the solver produces is computed by the kernels in
+// tinympc_kernels.hip; there is no CPU fallback anywhere in this file.
+#include "tinympc_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tinympc_device.h"
+
+using namespace tinympc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(TINYMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings.cpp:583-586)
+    double abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination;
+    int en_state_bound, en_input_bound;
+    int en_state_soc, en_input_soc, en_state_linear, en_input_linear;
+    int adaptive_rho;
+    double adaptive_rho_min, adaptive_rho_max;
+    int adaptive_rho_enable_clipping;
+};
+
+constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
+
+}  // namespace
+
+struct tinympc_solver {
+    int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
+    int W = 0, KT = 0, IPW = 0, groups = 0;
+    double rho = 0.0;
+    Settings st{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // problem + cache
+    double *dA = nullptr, *dB = nullptr, *dfdyn = nullptr, *dQd = nullptr, *dRd = nullptr;
+    double *dKinf = nullptr, *dPinf = nullptr, *dQuu = nullptr, *dAmBKt = nullptr, *dAPf = nullptr, *dBPf = nullptr;
+    double *dscratch = nullptr;
+    int *dinfo = nullptr;
+    // user-layout bounds / refs
+    double *dxmin = nullptr, *dxmax = nullptr, *dumin = nullptr, *dumax = nullptr, *dXref = nullptr, *dUref = nullptr;
+    // derived
+    double *dops = nullptr, *dtables = nullptr;
+    bool ops_dirty = true, tables_dirty = true;
+    // per-instance state
+    double *dx0 = nullptr, *dG = nullptr, *dV = nullptr, *dD = nullptr, *dsolx = nullptr, *dsolu = nullptr;
+    int *distats = nullptr;
+    double *ddstats = nullptr;
+    size_t lds_bytes = 0;
+    bool tables_in_lds = false;
+    int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
+    std::vector<void *> allocs;
+
+    size_t X() const { return (size_t)nx * N; }
+    size_t U() const { return (size_t)nu * (N - 1); }
+    size_t state_doubles() const { return (size_t)groups * N * 64; }
+    size_t d_doubles() const { return (size_t)groups * (N - 1) * IPW * nu; }
+};
+
+namespace {
+
+template <typename T>
+int dalloc(tinympc_solver *s, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", sizeof(T) * count, hipGetErrorString(e));
+    s->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return TINYMPC_OK;
+}
+
+int bind_device(tinympc_solver *s) {
+    HIP_TRY(hipSetDevice(s->device));
+    return TINYMPC_OK;
+}
+
+int upload(tinympc_solver *s, double *dst, const double *src, size_t count) {
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // the caller keeps ownership of src: copy completes inside the call
+    return TINYMPC_OK;
+}
+
+int download(tinympc_solver *s, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
+int fill_host_upload(tinympc_solver *s, double *dst, size_t count, double value) {
+    std::vector<double> h(count, value);
+    return upload(s, dst, h.data(), count);
+}
+
+int check_handle(const tinympc_solver *s) {
+    if (!s) return fail(TINYMPC_ERR_NOT_INITIALIZED, "Solver not initialized");
+    return TINYMPC_OK;
+}
+
+int run_precompute(tinympc_solver *s) {
+    PrecomputeParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.rho = s->rho;
+    p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
+    p.Kinf = s->dKinf; p.Pinf = s->dPinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
+    p.info = s->dinfo; p.scratch = s->dscratch;
+    p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
+    HIP_TRY(launch_precompute(p, s->stream));
+    s->ops_dirty = true;
+    s->tables_dirty = true;
+    return TINYMPC_OK;
+}
+
+int refresh_derived(tinympc_solver *s) {
+    if (s->ops_dirty) {
+        OperatorParams p{};
+        p.nx = s->nx; p.nu = s->nu; p.W = s->W; p.KT = s->KT;
+        p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
+        p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
+        p.ops = s->dops;
+        HIP_TRY(launch_build_operators(p, s->stream));
+        s->ops_dirty = false;
+        s->tables_dirty = true;
+    }
+    if (s->tables_dirty) {
+        TableParams p{};
+        p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.W = s->W; p.KT = s->KT;
+        p.en_state_bound = s->st.en_state_bound; p.en_input_bound = s->st.en_input_bound;
+        p.x_min = s->dxmin; p.x_max = s->dxmax; p.u_min = s->dumin; p.u_max = s->dumax;
+        p.Xref = s->dXref; p.Uref = s->dUref; p.Pinf = s->dPinf; p.ops = s->dops; p.tables = s->dtables;
+        HIP_TRY(launch_build_tables(p, s->stream));
+        s->tables_dirty = false;
+    }
+    return TINYMPC_OK;
+}
+
+int launch(tinympc_solver *s, bool timed) {
+    if (s->st.adaptive_rho)
+        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6)");
+    if ((s->st.en_state_soc && s->n_cone_x) || (s->st.en_input_soc && s->n_cone_u) ||
+        (s->st.en_state_linear && s->n_lin_x) || (s->st.en_input_linear && s->n_lin_u))
+        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "cone / linear constraint families are not implemented in the HIP path yet");
+    int rc = refresh_derived(s);
+    if (rc) return rc;
+    SolveParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = s->batch;
+    p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
+    p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
+    p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0;
+    p.G = s->dG; p.V = s->dV; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
+    p.istats = s->distats; p.dstats = s->ddstats;
+    p.tables_in_lds = s->tables_in_lds ? 1 : 0;
+    if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    HIP_TRY(launch_solve(p, s->W, s->KT, s->lds_bytes, s->stream));
+    if (timed) HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    return TINYMPC_OK;
+}
+
+void destroy(tinympc_solver *s) {
+    if (!s) return;
+    // teardown is best effort: errors here have nowhere useful to go
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void *q : s->allocs) (void)hipFree(q);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tinympc_last_error(void) { return g_last_error.c_str(); }
+int tinympc_abi_version(void) { return TINYMPC_ABI_VERSION; }
+
+int tinympc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, const double *fdyn,
+                        const double *Q, const double *R, double rho, int nx, int nu, int N, int batch,
+                        int device, int verbose) {
+    if (!out) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: output handle pointer is NULL");
+    *out = nullptr;
+    if (!A || !B || !Q || !R) return fail(TINYMPC_ERR_INVALID_INPUT, "setup requires A, B, Q, R");
+    if (nx < 1 || nu < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: nx and nu must be >= 1 (got %d, %d)", nx, nu);
+    if (N < 2) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: N must be >= 2 (TinyMPC.m:52), got %d", N);
+    if (batch < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: batch must be >= 1, got %d", batch);
+    int W = 0, KT = 0;
+    if (!choose_geometry(nx, nu, &W, &KT))
+        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d exceeds the 64 lanes of a wavefront; not supported by this build", nx + nu);
+    int ndev = tinympc_device_count();
+    if (ndev < 1) return fail(TINYMPC_ERR_NO_DEVICE, "no HIP device visible: the HIP path has no CPU fallback");
+    if (device >= ndev) return fail(TINYMPC_ERR_INVALID_INPUT, "device %d out of range (have %d)", device, ndev);
+
+    tinympc_solver *s = new (std::nothrow) tinympc_solver();
+    if (!s) return fail(TINYMPC_ERR_ALLOC, "out of host memory");
+    if (device < 0) {
+        if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    } else {
+        s->device = device;
+    }
+    s->nx = nx; s->nu = nu; s->N = N; s->batch = batch; s->rho = rho;
+    s->W = W; s->KT = KT; s->IPW = 64 / W; s->groups = (batch + s->IPW - 1) / s->IPW;
+    // tiny_set_default_settings (tiny_api.cpp:213-231, tiny_api_constants.hpp:5-10)
+    s->st = Settings{1e-3, 1e-3, 1000, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, 100.0, 1};
+
+    int rc = TINYMPC_OK;
+#define TRY(x)            \
+    do {                  \
+        rc = (x);         \
+        if (rc) {         \
+            destroy(s);   \
+            return rc;    \
+        }                 \
+    } while (0)
+#define HIP_TRY_S(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            destroy(s);                                                                              \
+            return fail(TINYMPC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));            \
+        }                                                                                            \
+    } while (0)
+
+    HIP_TRY_S(hipSetDevice(s->device));
+    HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY_S(hipEventCreate(&s->ev0));
+    HIP_TRY_S(hipEventCreate(&s->ev1));
+
+    // LDS plan: ADMM state always; the per-knot tables too when the total fits the 160 KB of a CU.
+    const size_t with_tables = solve_lds_bytes(nx, nu, N, W, true);
+    const size_t without = solve_lds_bytes(nx, nu, N, W, false);
+    constexpr size_t kLdsMax = 160 * 1024;
+    if (without > kLdsMax) {
+        destroy(s);
+        return fail(TINYMPC_ERR_UNSUPPORTED, "horizon too long for the LDS-resident solve kernel: needs %zu bytes of LDS (max %zu)", without, kLdsMax);
+    }
+    // Two workgroups per CU need <= 80 KB each; prefer LDS tables whenever they do not cost a workgroup slot.
+    const size_t slots_without = kLdsMax / without, slots_with = kLdsMax / with_tables;
+    s->tables_in_lds = (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
+    s->lds_bytes = s->tables_in_lds ? with_tables : without;
+
+    const size_t X = s->X(), U = s->U();
+    TRY(dalloc(s, &s->dA, (size_t)nx * nx)); TRY(dalloc(s, &s->dB, (size_t)nx * nu)); TRY(dalloc(s, &s->dfdyn, nx));
+    TRY(dalloc(s, &s->dQd, nx)); TRY(dalloc(s, &s->dRd, nu));
+    TRY(dalloc(s, &s->dKinf, (size_t)nu * nx)); TRY(dalloc(s, &s->dPinf, (size_t)nx * nx));
+    TRY(dalloc(s, &s->dQuu, (size_t)nu * nu)); TRY(dalloc(s, &s->dAmBKt, (size_t)nx * nx));
+    TRY(dalloc(s, &s->dAPf, nx)); TRY(dalloc(s, &s->dBPf, nu)); TRY(dalloc(s, &s->dinfo, 4));
+    TRY(dalloc(s, &s->dscratch, precompute_scratch_doubles(nx, nu) + 8));
+    TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
+    TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));
+    TRY(dalloc(s, &s->dops, ops_doubles(W, KT))); TRY(dalloc(s, &s->dtables, tables_doubles(W, N)));
+    TRY(dalloc(s, &s->dx0, (size_t)batch * nx));
+    TRY(dalloc(s, &s->dG, s->state_doubles())); TRY(dalloc(s, &s->dV, s->state_doubles())); TRY(dalloc(s, &s->dD, s->d_doubles()));
+    TRY(dalloc(s, &s->dsolx, X * batch)); TRY(dalloc(s, &s->dsolu, U * batch));
+    TRY(dalloc(s, &s->distats, (size_t)batch * 2)); TRY(dalloc(s, &s->ddstats, (size_t)batch * 4));
+
+    // Problem data. Only the diagonals of Q and R are kept, each + rho (tiny_api.cpp:90-91).
+    std::vector<double> qd(nx), rd(nu), fz(nx, 0.0);
+    for (int i = 0; i < nx; ++i) qd[i] = Q[i + (size_t)i * nx] + rho;
+    for (int i = 0; i < nu; ++i) rd[i] = R[i + (size_t)i * nu] + rho;
+    TRY(upload(s, s->dA, A, (size_t)nx * nx)); TRY(upload(s, s->dB, B, (size_t)nx * nu));
+    TRY(upload(s, s->dfdyn, fdyn ? fdyn : fz.data(), nx));
+    TRY(upload(s, s->dQd, qd.data(), nx)); TRY(upload(s, s->dRd, rd.data(), nu));
+    TRY(fill_host_upload(s, s->dxmin, X, -kBoundInf)); TRY(fill_host_upload(s, s->dxmax, X, kBoundInf));
+    TRY(fill_host_upload(s, s->dumin, U, -kBoundInf)); TRY(fill_host_upload(s, s->dumax, U, kBoundInf));
+    // Everything tiny_setup zeroes (tiny_api.cpp:41-44, 73-88, 100-111)
+    HIP_TRY_S(hipMemsetAsync(s->dXref, 0, sizeof(double) * X, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dUref, 0, sizeof(double) * U, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dx0, 0, sizeof(double) * batch * nx, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dV, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dsolx, 0, sizeof(double) * X * batch, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dsolu, 0, sizeof(double) * U * batch, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->distats, 0, sizeof(int) * batch * 2, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->ddstats, 0, sizeof(double) * batch * 4, s->stream));
+
+    TRY(run_precompute(s));  // tiny_api.cpp:113
+    HIP_TRY_S(hipStreamSynchronize(s->stream));
+#undef TRY
+#undef HIP_TRY_S
+    if (verbose) {
+        int steps = 0;
+        download(s, &steps, s->dinfo, sizeof(int));
+        printf("TinyMPC-HIP setup: nx=%d nu=%d N=%d rho=%g batch=%d device=%d | lanes/instance=%d LDS=%zu B tables_in_lds=%d | Kinf converged after %d iterations\n",
+               nx, nu, N, rho, batch, s->device, s->W, s->lds_bytes, (int)s->tables_in_lds, steps);
+    }
+    *out = s;
+    return TINYMPC_OK;
+}
+
+int tinympc_setup(tinympc_solver **out, const double *A, const double *B, const double *fdyn,
+                  const double *Q, const double *R, double rho, int nx, int nu, int N, int verbose) {
+    return tinympc_setup_batch(out, A, B, fdyn, Q, R, rho, nx, nu, N, 1, -1, verbose);
+}
+
+int tinympc_set_x0(tinympc_solver *s, const double *x0, int len, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0) return fail(TINYMPC_ERR_INVALID_INPUT, "set_x0: x0 is NULL");
+    // The reference only perror()s on a wrong length and still assigns (tiny_api.cpp:238-241); an
+    // Eigen column assignment of the wrong length is undefined behaviour, so the C ABI rejects it.
+    if (len != s->nx) return fail(TINYMPC_ERR_INVALID_INPUT, "set_x0: x0 has %d entries, expected %d", len, s->nx);
+    if ((rc = bind_device(s))) return rc;
+    rc = upload(s, s->dx0, x0, s->nx);
+    if (!rc && verbose) printf("Initial state set\n");
+    return rc;
+}
+
+int tinympc_set_x_ref(tinympc_solver *s, const double *Xref, int rows, int cols, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!Xref) return fail(TINYMPC_ERR_INVALID_INPUT, "set_x_ref: Xref is NULL");
+    // The reference prints the mismatch and assigns anyway (tiny_api.cpp:250-254), which would change
+    // the workspace shape under the solver; rejected here.
+    if (rows != s->nx || cols != s->N)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "State reference trajectory (x_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nx, s->N);
+    if ((rc = bind_device(s))) return rc;
+    rc = upload(s, s->dXref, Xref, s->X());
+    s->tables_dirty = true;
+    if (!rc && verbose) printf("State reference set\n");
+    return rc;
+}
+
+int tinympc_set_u_ref(tinympc_solver *s, const double *Uref, int rows, int cols, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!Uref) return fail(TINYMPC_ERR_INVALID_INPUT, "set_u_ref: Uref is NULL");
+    if (rows != s->nu || cols != s->N - 1)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "Control/input reference trajectory (u_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nu, s->N - 1);
+    if ((rc = bind_device(s))) return rc;
+    rc = upload(s, s->dUref, Uref, s->U());
+    s->tables_dirty = true;
+    if (!rc && verbose) printf("Input reference set\n");
+    return rc;
+}
+
+int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const double *x_max,
+                                  const double *u_min, const double *u_max, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x_min || !x_max || !u_min || !u_max)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "set_bound_constraints requires x_min, x_max, u_min, u_max (expanded to nx x N / nu x (N-1))");
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = upload(s, s->dxmin, x_min, s->X()))) return rc;
+    if ((rc = upload(s, s->dxmax, x_max, s->X()))) return rc;
+    if ((rc = upload(s, s->dumin, u_min, s->U()))) return rc;
+    if ((rc = upload(s, s->dumax, u_max, s->U()))) return rc;
+    s->st.en_state_bound = 1;  // bindings.cpp:206-207
+    s->st.en_input_bound = 1;
+    s->tables_dirty = true;
+    if (verbose) printf("Bound constraints set\n");
+    return TINYMPC_OK;
+}
+
+int tinympc_solve_async(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    return launch(s, false);
+}
+
+int tinympc_synchronize(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
+int tinympc_solve(tinympc_solver *s, int verbose) {
+    int rc = tinympc_solve_async(s);
+    if (rc) return rc;
+    if ((rc = tinympc_synchronize(s))) return rc;
+    if (verbose) {
+        int is[2] = {0, 0};
+        if ((rc = download(s, is, s->distats, sizeof(is)))) return rc;
+        if (is[1] == TINYMPC_STATUS_SOLVED) printf("Solver converged in %d iterations\n", is[0]);  // admm.cpp:190
+        printf("Solve completed with status: %d\n", is[1] == TINYMPC_STATUS_SOLVED ? 0 : 1);
+    }
+    return TINYMPC_OK;
+}
+
+int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = refresh_derived(s))) return rc;  // keep table rebuilds out of the timed region
+    if ((rc = launch(s, true))) return rc;
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    return TINYMPC_OK;
+}
+
+int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    if (x_out && (rc = download(s, x_out, s->dsolx + (size_t)first * s->X(), sizeof(double) * s->X() * count))) return rc;
+    if (u_out && (rc = download(s, u_out, s->dsolu + (size_t)first * s->U(), sizeof(double) * s->U() * count))) return rc;
+    return TINYMPC_OK;
+}
+
+int tinympc_get_solution(tinympc_solver *s, double *x_out, double *u_out, int verbose) {
+    int rc = tinympc_get_solution_batch(s, x_out, u_out, 0, 1);
+    if (!rc && verbose) printf("Solution retrieved\n");
+    return rc;
+}
+
+int tinympc_get_first_controls_batch(tinympc_solver *s, double *u0_out, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "u0_out is NULL");
+    if (first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(u0_out, sizeof(double) * s->nu, s->dsolu + (size_t)first * s->U(), sizeof(double) * s->U(),
+                             sizeof(double) * s->nu, count, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
+int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *residuals, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    if (iters || status) {
+        std::vector<int> is((size_t)count * 2);
+        if ((rc = download(s, is.data(), s->distats + (size_t)first * 2, sizeof(int) * 2 * count))) return rc;
+        for (int b = 0; b < count; ++b) {
+            if (iters) iters[b] = is[2 * (size_t)b];
+            if (status) status[b] = is[2 * (size_t)b + 1];
+        }
+    }
+    if (residuals && (rc = download(s, residuals, s->ddstats + (size_t)first * 4, sizeof(double) * 4 * count))) return rc;
+    return TINYMPC_OK;
+}
+
+int tinympc_get_stats(tinympc_solver *s, int *iter, int *status, double *pri_res_state, double *pri_res_input, int verbose) {
+    double res[4];
+    int it = 0, st = 0;
+    int rc = tinympc_get_stats_batch(s, &it, &st, res, 0, 1);
+    if (rc) return rc;
+    if (iter) *iter = it;
+    if (status) *status = st;
+    if (pri_res_state) *pri_res_state = res[0];
+    if (pri_res_input) *pri_res_input = res[2];
+    if (verbose) printf("Statistics retrieved: iter=%d, status=%d\n", it, st);
+    return TINYMPC_OK;
+}
+
+int tinympc_get_residuals(tinympc_solver *s, double residuals[4]) {
+    return tinympc_get_stats_batch(s, nullptr, nullptr, residuals, 0, 1);
+}
+
+int tinympc_codegen(tinympc_solver *s, const char *, int) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "codegen is out of scope for the MI355X build (embedded C++ emitter, SURVEY.md section 2 #7)");
+}
+
+int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *, const double *, const double *, const double *, const double *, int) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "codegen_with_sensitivity is out of scope for the MI355X build (SURVEY.md section 2 #7)");
+}
+
+int tinympc_set_sensitivity_matrices(tinympc_solver *s, const double *dK, const double *dP, const double *dC1, const double *dC2, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!dK || !dP || !dC1 || !dC2) return fail(TINYMPC_ERR_INVALID_INPUT, "set_sensitivity_matrices requires 4 matrices");
+    // The reference stores nothing here either (bindings.cpp:338-352): the matrices only feed codegen.
+    if (verbose) printf("Sensitivity matrices accepted (unused: adaptive rho / codegen are out of scope)\n");
+    return TINYMPC_OK;
+}
+
+int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf, const double *Quu_inv, const double *AmBKt, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!Kinf || !Pinf || !Quu_inv || !AmBKt) return fail(TINYMPC_ERR_INVALID_INPUT, "set_cache_terms requires Kinf, Pinf, Quu_inv, AmBKt");
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = upload(s, s->dKinf, Kinf, (size_t)s->nu * s->nx))) return rc;
+    if ((rc = upload(s, s->dPinf, Pinf, (size_t)s->nx * s->nx))) return rc;
+    if ((rc = upload(s, s->dQuu, Quu_inv, (size_t)s->nu * s->nu))) return rc;
+    if ((rc = upload(s, s->dAmBKt, AmBKt, (size_t)s->nx * s->nx))) return rc;
+    s->ops_dirty = true;
+    s->tables_dirty = true;
+    if (verbose) printf("Cache terms set\n");
+    return TINYMPC_OK;
+}
+
+int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, const double *blin_x, int nlx,
+                                   const double *Alin_u, const double *blin_u, int nlu) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (nlx < 0 || nlu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative constraint count");
+    if ((nlx > 0 && (!Alin_x || !blin_x)) || (nlu > 0 && (!Alin_u || !blin_u)))
+        return fail(TINYMPC_ERR_INVALID_INPUT, "set_linear_constraints: NULL matrix for a non-empty side");
+    s->n_lin_x = nlx;
+    s->n_lin_u = nlu;
+    if (nlx > 0) s->st.en_state_linear = 1;  // bindings.cpp:422-429
+    if (nlu > 0) s->st.en_input_linear = 1;
+    if (nlx > 0 || nlu > 0)
+        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "linear-inequality slack family is not implemented in the HIP path yet; solve will refuse to run while it is enabled");
+    return TINYMPC_OK;
+}
+
+int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *qcx, const double *cx, int ncx,
+                                 const int *Acu, const int *qcu, const double *cu, int ncu) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (ncx < 0 || ncu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative cone count");
+    if ((ncx > 0 && (!Acx || !qcx || !cx)) || (ncu > 0 && (!Acu || !qcu || !cu)))
+        return fail(TINYMPC_ERR_INVALID_INPUT, "set_cone_constraints: NULL array for a non-empty side");
+    s->n_cone_x = ncx;
+    s->n_cone_u = ncu;
+    if (ncx > 0) s->st.en_state_soc = 1;  // bindings.cpp:468-476
+    if (ncu > 0) s->st.en_input_soc = 1;
+    if (ncx > 0 || ncu > 0)
+        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "second-order-cone slack family is not implemented in the HIP path yet; solve will refuse to run while it is enabled");
+    return TINYMPC_OK;
+}
+
+int tinympc_reset(tinympc_solver **s, int verbose) {
+    if (!s || !*s) return TINYMPC_OK;  // bindings.cpp:539: silently nothing to do
+    destroy(*s);
+    *s = nullptr;
+    if (verbose) printf("Solver reset\n");
+    return TINYMPC_OK;
+}
+
+int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                            int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
+                            int en_state_linear, int en_input_linear, int adaptive_rho, double adaptive_rho_min,
+                            double adaptive_rho_max, int adaptive_rho_enable_clipping, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (max_iter < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "max_iter must be >= 0");
+    const bool bounds_changed = (s->st.en_state_bound != en_state_bound) || (s->st.en_input_bound != en_input_bound);
+    s->st.abs_pri_tol = abs_pri_tol; s->st.abs_dua_tol = abs_dua_tol;
+    s->st.max_iter = max_iter; s->st.check_termination = check_termination;
+    s->st.en_state_bound = en_state_bound; s->st.en_input_bound = en_input_bound;
+    s->st.en_state_soc = en_state_soc; s->st.en_input_soc = en_input_soc;
+    s->st.en_state_linear = en_state_linear; s->st.en_input_linear = en_input_linear;
+    s->st.adaptive_rho = adaptive_rho; s->st.adaptive_rho_min = adaptive_rho_min;
+    s->st.adaptive_rho_max = adaptive_rho_max; s->st.adaptive_rho_enable_clipping = adaptive_rho_enable_clipping;
+    if (bounds_changed) s->tables_dirty = true;
+    if (adaptive_rho)
+        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6); solve will refuse to run while it is enabled");
+    if (verbose) printf("Settings updated successfully\n");
+    return TINYMPC_OK;
+}
+
+int tinympc_print_problem_data(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    int is[2] = {0, 0};
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = download(s, is, s->distats, sizeof(is)))) return rc;
+    printf("solution iter: %d\nsolution solved: %d\n", is[0], is[1] == TINYMPC_STATUS_SOLVED);
+    printf("\n\ncache rho: %f\n", s->rho);
+    printf("\n\nabs_pri_tol: %f\nabs_dua_tol: %f\nmax_iter: %d\ncheck_termination: %d\nen_state_bound: %d\nen_input_bound: %d\n",
+           s->st.abs_pri_tol, s->st.abs_dua_tol, s->st.max_iter, s->st.check_termination, s->st.en_state_bound, s->st.en_input_bound);
+    printf("\n\nnx: %d\nnu: %d\niter: %d\nstatus: %d\n", s->nx, s->nu, is[0], is[1]);
+    return TINYMPC_OK;
+}
+
+int tinympc_get_cache(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt, int *riccati_iters) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if (Kinf && (rc = download(s, Kinf, s->dKinf, sizeof(double) * s->nu * s->nx))) return rc;
+    if (Pinf && (rc = download(s, Pinf, s->dPinf, sizeof(double) * s->nx * s->nx))) return rc;
+    if (Quu_inv && (rc = download(s, Quu_inv, s->dQuu, sizeof(double) * s->nu * s->nu))) return rc;
+    if (AmBKt && (rc = download(s, AmBKt, s->dAmBKt, sizeof(double) * s->nx * s->nx))) return rc;
+    if (riccati_iters && (rc = download(s, riccati_iters, s->dinfo, sizeof(int)))) return rc;
+    return TINYMPC_OK;
+}
+
+int tinympc_set_x0_batch(tinympc_solver *s, const double *x0s, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0s) return fail(TINYMPC_ERR_INVALID_INPUT, "x0s is NULL");
+    if (first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    return upload(s, s->dx0 + (size_t)first * s->nx, x0s, (size_t)count * s->nx);
+}
+
+int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!d_x0s) return fail(TINYMPC_ERR_INVALID_INPUT, "d_x0s is NULL");
+    if (first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->dx0 + (size_t)first * s->nx, d_x0s, sizeof(double) * count * s->nx, hipMemcpyDeviceToDevice, s->stream));
+    return TINYMPC_OK;
+}
+
+int tinympc_reset_workspace(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    HIP_TRY(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
+    HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
+    HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));
+    HIP_TRY(hipMemsetAsync(s->ddstats, 0, sizeof(double) * s->batch * 4, s->stream));
+    return TINYMPC_OK;
+}
+
+int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (d_x) *d_x = s->dsolx;
+    if (d_u) *d_u = s->dsolu;
+    return TINYMPC_OK;
+}
+
+int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave, int *workgroups,
+                            int *lds_bytes, int *tables_in_lds) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (lanes_per_instance) *lanes_per_instance = s->W;
+    if (instances_per_wave) *instances_per_wave = s->IPW;
+    if (workgroups) *workgroups = s->groups;
+    if (lds_bytes) *lds_bytes = (int)s->lds_bytes;
+    if (tables_in_lds) *tables_in_lds = s->tables_in_lds ? 1 : 0;
+    return TINYMPC_OK;
+}
+
+void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// tinympc_device.h -- parameter blocks and launcher declarations shared by the kernels
+// (tinympc_kernels.hip) and the C-ABI layer (tinympc_capi.hip).
+//
+// Lane layout of the solve kernel ("row-per-lane"): a wavefront of 64 lanes is cut into 64/W groups
+// of W lanes (W = 16, 32 or 64, the smallest with nx+nu <= W); one group = one MPC instance; inside
+// a group lane r < nx owns state row r and lane nx+j owns input row j. Every trajectory array of the
+// reference (TinyWorkspace, types.hpp:79-136) that is indexed [row, knot] therefore becomes
+// [knot][lane]: one 512-byte line per knot per wavefront, in LDS and in HBM alike.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tinympc {
+
+// Fixed-size operators and per-lane constants built by k_build_operators (doubles):
+//   Mf[W*KT]   forward sweep rows    [ A-B*Kinf | -B ]  (state rows),  [ -Kinf | -I ]        (input rows)
+//   Mb[W*KT]   backward sweep rows   [ AmBKt | -Kinf' ] (state rows),  [ Quu_inv*B' | Quu_inv ] (input rows)
+//   cf[W]      forward constants     fdyn (state rows), 0 (input rows)
+//   cb[W]      backward constants    APf (state rows), Quu_inv*BPf (input rows)
+//   dg[W]      diagonal of Q+rho*I (state rows) / R+rho*I (input rows)   (tiny_api.cpp:90-91)
+__host__ __device__ inline size_t ops_doubles(int W, int KT) { return (size_t)2 * W * KT + 3 * W; }
+
+// Per-knot tables built by k_build_tables (doubles), all [N][W]:
+//   lo, hi     clamp bounds (-inf/+inf where the bound flag is off)              (admm.cpp:49-58)
+//   linref     -(Xref .* Q) / -(Uref .* R)                                       (admm.cpp:77, 79)
+// followed by pNref[W] = -(Xref[:,N-1]' * Pinf)'                                  (admm.cpp:81)
+__host__ __device__ inline size_t tables_doubles(int W, int N) { return (size_t)3 * N * W + W; }
+
+struct PrecomputeParams {
+    int nx, nu;
+    double rho;
+    const double *A, *B, *fdyn, *Qd, *Rd;  // Qd/Rd: diagonals already + rho (tiny_api.cpp:90-91)
+    double *Kinf, *Pinf, *Quu_inv, *AmBKt, *APf, *BPf;
+    int *info;        // info[0] = Riccati steps taken
+    double *scratch;  // global scratch, used when the working set does not fit in LDS
+    int use_lds;
+};
+
+struct OperatorParams {
+    int nx, nu, W, KT;
+    const double *A, *B, *fdyn, *Qd, *Rd, *Kinf, *Quu_inv, *AmBKt, *APf, *BPf;
+    double *ops;
+};
+
+struct TableParams {
+    int nx, nu, N, W;
+    int en_state_bound, en_input_bound;
+    const double *x_min, *x_max, *u_min, *u_max, *Xref, *Uref, *Pinf;
+    const double *ops;  // for dg[]
+    int KT;
+    double *tables;
+};
+
+struct SolveParams {
+    int nx, nu, N, batch;
+    int max_iter, check_termination;
+    double rho, abs_pri_tol, abs_dua_tol;
+    const double *ops;
+    const double *tables;
+    const double *x0;  // [batch][nx]
+    double *G, *V;     // [groups][N][64]     duals (g|y) and slack (v|z), persistent across solves
+    double *D;         // [groups][N-1][IPW*nu]  feed-forward term d, persistent across solves
+    double *sol_x;     // [batch][N][nx]      == nx x N x batch column-major
+    double *sol_u;     // [batch][N-1][nu]
+    int *istats;       // [batch][2]  iter, status
+    double *dstats;    // [batch][4]  pri_x, dua_x, pri_u, dua_u
+    int tables_in_lds;
+};
+
+// Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
+hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
+hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream);
+hipError_t launch_build_tables(const TableParams &p, hipStream_t stream);
+// Chooses the <W,KT> instantiation; returns hipErrorInvalidValue when none fits.
+hipError_t launch_solve(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+// Geometry helpers shared with the host layer.
+bool choose_geometry(int nx, int nu, int *W, int *KT);
+size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds);
+size_t precompute_scratch_doubles(int nx, int nu);
+
+}  // namespace tinympc
