@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinympc_hip.so")
+# TINYMPC_HIP_LIBRARY lets a developer point at an alternative build of the SAME library (kernel A/B runs).
+LIB_PATH = os.environ.get("TINYMPC_HIP_LIBRARY") or os.path.join(_HERE, "libtinympc_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

@@ -81,7 +81,7 @@ struct tinympc_solver {
 
     size_t X() const { return (size_t)nx * N; }
     size_t U() const { return (size_t)nu * (N - 1); }
-    size_t state_doubles() const { return (size_t)groups * N * 64; }
+    size_t state_doubles() const { return (size_t)groups * (N + 1) * 64; }  // row N: per-lane dummy slot
     size_t d_doubles() const { return (size_t)groups * (N - 1) * IPW * nu; }
 };
 

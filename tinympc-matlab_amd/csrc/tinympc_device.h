@@ -19,11 +19,13 @@ namespace tinympc {
 //   dg[W]      diagonal of Q+rho*I (state rows) / R+rho*I (input rows)   (tiny_api.cpp:90-91)
 __host__ __device__ inline size_t ops_doubles(int W, int KT) { return (size_t)2 * W * KT + 3 * W; }
 
-// Per-knot tables built by k_build_tables (doubles), all [N][W]:
+// Per-knot tables built by k_build_tables (doubles), all [N+2][W] (row k+1 = knot k; rows 0 and N+1
+// are padding for the solve kernel's one-step-ahead prefetch):
 //   lo, hi     clamp bounds (-inf/+inf where the bound flag is off)              (admm.cpp:49-58)
 //   linref     -(Xref .* Q) / -(Uref .* R)                                       (admm.cpp:77, 79)
 // followed by pNref[W] = -(Xref[:,N-1]' * Pinf)'                                  (admm.cpp:81)
-__host__ __device__ inline size_t tables_doubles(int W, int N) { return (size_t)3 * N * W + W; }
+__host__ __device__ inline size_t table_rows(int N) { return (size_t)N + 2; }
+__host__ __device__ inline size_t tables_doubles(int W, int N) { return 3 * table_rows(N) * W + W; }
 
 struct PrecomputeParams {
     int nx, nu;

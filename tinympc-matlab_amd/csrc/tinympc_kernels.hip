@@ -1,23 +1,10 @@
-// tinympc_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4), FP64.
+// tinympc_kernels.hip -- setup-time HIP kernels for gfx950 (MI355X, CDNA4), FP64.
 //
 //   k_precompute        P1  tiny_precompute_and_set_cache         (reference tiny_api.cpp:124-190)
-//   k_build_operators       fuses the cache into the two 1-step sweep operators used below
+//   k_build_operators       fuses the cache into the two 1-step sweep operators used by the solve
 //   k_build_tables          per-knot clamp bounds / linear-cost reference terms
-//   k_admm_solve        M1  the whole solve(): F1 forward_pass, S1 update_slack, D1 update_dual,
-//                           L1 update_linear_cost, R1 termination_condition, C1 v/z copies,
-//                           B1 backward_pass_grad                  (reference admm.cpp:13-207)
 //
-// Design of k_admm_solve (see DESIGN.md for the full rationale):
-//   * one wavefront = 64/W MPC instances, W lanes per instance, one lane per state/input row;
-//   * the ADMM state that survives an iteration (duals g|y, slack v|z, feed-forward d) lives in LDS
-//     for the whole solve: HBM is touched once at entry and once at exit;
-//   * each sweep step is ONE (nx+nu)x(nx+nu) mat-vec per instance: the operand vector is spread
-//     over the W lanes of the instance and broadcast with DPP row_newbcast (W=16), so a step is
-//     KT DPP-broadcasts + KT FP64 FMAs per lane and no LDS round trip sits on the dependency chain;
-//   * slack projection, dual ascent, linear-cost refresh and the four inf-norm residuals are
-//     row-local, so they are fused into the forward sweep, lane by lane, right after the lane's
-//     row of x_{i+1} / u_i has been produced;
-//   * inf-norm residuals: per-lane running max, then a W-lane butterfly once per iteration.
+// The solve kernel itself (M1: F1, S1, D1, L1, R1, C1, B1) is in tinympc_solve.hip.
 #include "tinympc_device.h"
 
 namespace tinympc {
@@ -277,15 +264,20 @@ hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream) {
 // Per-knot tables in the solve kernel's [knot][row-lane] layout. A disabled bound family becomes
 // (-inf, +inf): min(hi, max(lo, s)) is then the identity, which is what the reference does when
 // en_state_bound / en_input_bound are off (admm.cpp:49, 55).
+// Each table has N+2 rows: row k+1 is knot k; rows 0 and N+1 are padding that the solve kernel's
+// one-step-ahead operand prefetch may touch at either end of a sweep (values never used).
 __global__ void __launch_bounds__(256) k_build_tables(const TableParams p) {
     const int nx = p.nx, nu = p.nu, N = p.N, W = p.W, nxu = nx + nu;
-    double *lo = p.tables, *hi = lo + (size_t)N * W, *lr = hi + (size_t)N * W, *pn = lr + (size_t)N * W;
+    const size_t TR = (size_t)(N + 2) * W;
+    double *lo = p.tables, *hi = lo + TR, *lr = hi + TR, *pn = lr + TR;
     const double *dg = p.ops + (size_t)2 * W * p.KT + 2 * W;
     const double inf = __longlong_as_double(0x7FF0000000000000LL);
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * W; idx += gridDim.x * 256) {
-        const int kn = idx / W, r = idx % W;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < (N + 2) * W; idx += gridDim.x * 256) {
+        const int kn = idx / W - 1, r = idx % W;
         double l = -inf, h = inf, ref = 0.0;
-        if (r < nx) {
+        if (kn < 0 || kn >= N) {
+            // padding row
+        } else if (r < nx) {
             if (p.en_state_bound) {
                 l = p.x_min[r + (size_t)kn * nx];
                 h = p.x_max[r + (size_t)kn * nx];
@@ -316,283 +308,10 @@ __global__ void __launch_bounds__(256) k_build_tables(const TableParams p) {
 }
 
 hipError_t launch_build_tables(const TableParams &p, hipStream_t stream) {
-    const int blocks = (p.N * p.W + 255) / 256;
+    const int blocks = ((p.N + 2) * p.W + 255) / 256;
     hipLaunchKernelGGL(k_build_tables, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
-// =====================================================================================
-// M1: the ADMM solve
-// =====================================================================================
-
-// Broadcast lane K of every W-lane group to all lanes of that group.
-template <int W, int K>
-__device__ __forceinline__ double group_bcast(double w) {
-    if constexpr (W == 16) {
-        // DPP row_newbcast:K -- a "row" is 16 lanes, exactly one instance; lowers to one v_mov_b64_dpp.
-        // bound_ctrl + full row/bank masks make `old` dead, so no zero-initialising move is emitted.
-        return __builtin_amdgcn_update_dpp(w, w, 0x150 + K, 0xf, 0xf, true);
-    } else if constexpr (W == 64) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(w), K);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(w), K);
-        return __hiloint2double(hi, lo);
-    } else {
-        return __shfl(w, K, W);
-    }
-}
-
-template <int W, int KT, int K = 0>
-__device__ __forceinline__ void matvec_accumulate(const double (&m)[KT], double w, double (&acc)[4]) {
-    if constexpr (K < KT) {
-        acc[K & 3] = fma(m[K], group_bcast<W, K>(w), acc[K & 3]);
-        matvec_accumulate<W, KT, K + 1>(m, w, acc);
-    }
-}
-
-// out = sum_k m[k] * w_k + c, with w_k the operand held by lane k of the group; four partial sums
-// to keep the FP64 FMA pipe busy (a single chain would be latency-bound).
-template <int W, int KT>
-__device__ __forceinline__ double group_matvec(const double (&m)[KT], double w, double c) {
-    double acc[4] = {c, 0.0, 0.0, 0.0};
-    matvec_accumulate<W, KT>(m, w, acc);
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
-}
-
-template <int W>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int m = 1; m < W; m <<= 1) v = fmax(v, __shfl_xor(v, m, W));
-    return v;
-}
-
-size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds) {
-    const int ipw = 64 / W;
-    size_t d = (size_t)2 * N * 64 + (size_t)(N - 1) * ipw * nu;
-    d = (d + 1) & ~(size_t)1;
-    if (tables_in_lds) d += tables_doubles(W, N);
-    (void)nx;
-    return d * sizeof(double);
-}
-
-bool choose_geometry(int nx, int nu, int *W, int *KT) {
-    const int nxu = nx + nu;
-    if (nx < 1 || nu < 1 || nxu > 64) return false;
-    if (nxu <= 8) { *W = 16; *KT = 8; }
-    else if (nxu <= 12) { *W = 16; *KT = 12; }
-    else if (nxu <= 16) { *W = 16; *KT = 16; }
-    else if (nxu <= 32) { *W = 32; *KT = 32; }
-    else { *W = 64; *KT = 64; }
-    return true;
-}
-
-template <int W, int KT, bool TLDS>
-__global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int IPW = 64 / W;
-    const int lane = threadIdx.x;
-    const int j = lane / W, r = lane % W;
-    const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu;
-    const long grp = blockIdx.x;
-    const long inst = grp * IPW + j;
-    const bool is_x = r < nx;
-    const bool is_u = (r >= nx) && (r < nxu);
-    const bool inst_ok = inst < p.batch;
-    const bool row_ok = inst_ok && (r < nxu);
-    const int dstride = IPW * nu;
-    const int dsize = (N - 1) * dstride;
-
-    // ---- LDS carve: duals G, slack V ([knot][lane]), feed-forward D ([knot][instance][input row])
-    double *sG = smem;
-    double *sV = sG + (size_t)N * 64;
-    double *sD = sV + (size_t)N * 64;
-    double *sT = sD + ((dsize + 1) & ~1);
-    const double *tab = TLDS ? sT : p.tables;
-    const double *t_lo = tab, *t_hi = tab + (size_t)N * W, *t_lr = tab + (size_t)2 * N * W;
-
-    double *gG = p.G + (size_t)grp * N * 64;
-    double *gV = p.V + (size_t)grp * N * 64;
-    double *gD = p.D + (size_t)grp * dsize;
-
-    // ---- one coalesced pass HBM -> LDS (512-byte lines)
-    for (int kn = 0; kn < N; ++kn) {
-        sG[kn * 64 + lane] = gG[kn * 64 + lane];
-        sV[kn * 64 + lane] = gV[kn * 64 + lane];
-    }
-    for (int i = lane; i < dsize; i += 64) sD[i] = gD[i];
-    if (TLDS) {
-        const int tn = (int)tables_doubles(W, N);
-        for (int i = lane; i < tn; i += 64) sT[i] = p.tables[i];
-    }
-
-    // ---- per-lane operator rows and constants (registers for the whole solve)
-    double mf[KT], mb[KT];
-    {
-        const double *Mf = p.ops + (size_t)r * KT, *Mb = p.ops + (size_t)W * KT + (size_t)r * KT;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            mf[k] = Mf[k];
-            mb[k] = Mb[k];
-        }
-    }
-    const double cf = p.ops[(size_t)2 * W * KT + r];
-    const double cb = p.ops[(size_t)2 * W * KT + W + r];
-    const double pnref = p.tables[(size_t)3 * N * W + r];
-    const double rho = p.rho;
-    const double x0v = (inst_ok && is_x) ? p.x0[inst * nx + r] : 0.0;
-    const int dIdx = is_u ? (j * nu + (r - nx)) : 0;
-    const int ct = p.check_termination;
-    __syncthreads();
-
-    bool active = inst_ok;
-    int it_done = 0;
-    int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
-    bool res_valid = false;
-    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
-
-    for (int it = 0; it < p.max_iter; ++it) {  // admm.cpp:129
-        if (__ballot(active) == 0ull) break;
-        const bool check = (ct > 0) && (((it + 1) % ct) == 0);  // admm.cpp:91 (iter already incremented, :143)
-        const bool st = active && row_ok;
-        double pri, dua;
-
-        // ---------------- forward sweep (F1) with the row-local phases S1+D1+R1 fused in.
-        // For one (row, knot) element with rollout value `val` (admm.cpp:45-58, 67-68, 93-96):
-        //   s = val + G ; snew = min(hi, max(lo, s)) ; G <- s - snew ; V <- snew ; running max of
-        //   |val - snew| (primal) and |Vold - snew| (dual).
-        // The row-local operands of step i+1 are fetched while step i's mat-vec runs, so no LDS
-        // latency sits on the serial x_i -> x_{i+1} chain.
-        {   // knot 0, state lanes only: x_0 is given (tiny_set_x0), no mat-vec
-            const double g = sG[lane], vold = sV[lane];
-            const double s = x0v + g;
-            const double snew = fmin(t_hi[r], fmax(t_lo[r], s));
-            pri = is_x ? fabs(x0v - snew) : 0.0;
-            dua = is_x ? fabs(vold - snew) : 0.0;
-            if (st && is_x) {
-                if (check) gV[lane] = vold;
-                sG[lane] = s - snew;
-                sV[lane] = snew;
-            }
-        }
-        const int koff = is_x ? 1 : 0;  // at step i a state lane finishes knot i+1, an input lane knot i
-        double xcur = x0v;
-        double dv = sD[dIdx];
-        double g = sG[koff * 64 + lane], vold = sV[koff * 64 + lane];
-        double lo = t_lo[koff * W + r], hi = t_hi[koff * W + r];
-        for (int i = 0; i < N - 1; ++i) {
-            const double w = is_x ? xcur : dv;
-            const int in = (i + 1 < N - 1) ? (i + 1) : i;  // prefetch for the next step (clamped on the last)
-            const double dv_n = sD[in * dstride + dIdx];
-            const int en = (in + koff) * 64 + lane, ten = (in + koff) * W + r;
-            const double g_n = sG[en], vold_n = sV[en], lo_n = t_lo[ten], hi_n = t_hi[ten];
-
-            const double out = group_matvec<W, KT>(mf, w, cf);  // state lanes: x_{i+1}; input lanes: u_i
-
-            const int e = (i + koff) * 64 + lane;
-            const double s = out + g;
-            const double snew = fmin(hi, fmax(lo, s));
-            pri = fmax(pri, fabs(out - snew));
-            dua = fmax(dua, fabs(vold - snew));
-            if (st) {
-                // The reference returns from a converged solve BEFORE v <- vnew (admm.cpp:181-197), so its
-                // workspace keeps the previous iteration's v/z. Stream that value out while it is still in a
-                // register; on convergence the HBM copy is then exactly the reference's v/z.
-                if (check) gV[e] = vold;
-                sG[e] = s - snew;
-                sV[e] = snew;
-            }
-            xcur = out;
-            dv = dv_n; g = g_n; vold = vold_n; lo = lo_n; hi = hi_n;
-        }
-        if (active) it_done = it + 1;  // admm.cpp:143
-
-        // ---------------- R1: inf-norm residuals (admm.cpp:93-101), one butterfly per iteration
-        if (check) {
-            const double px = group_max<W>(is_x ? pri : 0.0);
-            const double pu = group_max<W>(is_u ? pri : 0.0);
-            const double dx = group_max<W>(is_x ? dua : 0.0) * rho;
-            const double du = group_max<W>(is_u ? dua : 0.0) * rho;
-            if (active) {
-                res_px = px; res_dx = dx; res_pu = pu; res_du = du;
-                res_valid = true;
-                if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
-                    status = 1;  // TINY_SOLVED: stop this instance before the backward pass (admm.cpp:181-192)
-                    active = false;
-                }
-            }
-        }
-
-        // ---------------- backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V,G
-        const bool stb = active && row_ok;
-        {
-            const int eN = (N - 1) * 64 + lane;
-            double pcur = pnref - rho * (sV[eN] - sG[eN]);  // p_{N-1}, admm.cpp:81-82 (state lanes)
-            int e0 = (N - 2) * 64 + lane;
-            double bv = sV[e0], bg = sG[e0], blr = t_lr[(N - 2) * W + r];
-            for (int i = N - 2; i >= 0; --i) {
-                const double lin = blr - rho * (bv - bg);  // q_i (state lanes) / r_i (input lanes), admm.cpp:77-80
-                const double w = is_x ? pcur : lin;
-                const int ip = (i > 0) ? (i - 1) : 0;  // prefetch for the next step
-                const int ep = ip * 64 + lane;
-                const double bv_n = sV[ep], bg_n = sG[ep], blr_n = t_lr[ip * W + r];
-                const double out = group_matvec<W, KT>(mb, w, cb);
-                if (stb && is_u) sD[i * dstride + dIdx] = out;  // d_i
-                pcur = lin + out;                                // p_i (state lanes)
-                bv = bv_n; bg = bg_n; blr = blr_n;
-            }
-        }
-    }
-
-    // ---- write-back: state for the next (warm-started) solve, solution, stats
-    if (p.max_iter > 0 && inst_ok) {
-        for (int kn = 0; kn < N; ++kn) {
-            const int e = kn * 64 + lane;
-            gG[e] = sG[e];
-            if (status != 1) gV[e] = sV[e];  // converged: HBM already holds the reference's stale v/z
-            const double sol = sV[e];         // solution = vnew / znew (admm.cpp:187-188, 204-205)
-            if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = sol;
-            if (is_u && kn < N - 1) p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = sol;
-        }
-        if (is_u)
-            for (int i = 0; i < N - 1; ++i) gD[i * dstride + dIdx] = sD[i * dstride + dIdx];
-    }
-    if (inst_ok && r == 0) {
-        p.istats[inst * 2 + 0] = it_done;
-        p.istats[inst * 2 + 1] = status;
-        if (res_valid) {
-            p.dstats[inst * 4 + 0] = res_px;
-            p.dstats[inst * 4 + 1] = res_dx;
-            p.dstats[inst * 4 + 2] = res_pu;
-            p.dstats[inst * 4 + 3] = res_du;
-        }
-    }
-}
-
-template <int W, int KT>
-static hipError_t launch_solve_t(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
-    constexpr int IPW = 64 / W;
-    const int groups = (p.batch + IPW - 1) / IPW;
-    hipError_t e;
-    if (p.tables_in_lds) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_admm_solve<W, KT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_admm_solve<W, KT, true>), dim3(groups), dim3(64), lds_bytes, stream, p);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_admm_solve<W, KT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_admm_solve<W, KT, false>), dim3(groups), dim3(64), lds_bytes, stream, p);
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_solve(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream) {
-    if (W == 16 && KT == 8) return launch_solve_t<16, 8>(p, lds_bytes, stream);
-    if (W == 16 && KT == 12) return launch_solve_t<16, 12>(p, lds_bytes, stream);
-    if (W == 16 && KT == 16) return launch_solve_t<16, 16>(p, lds_bytes, stream);
-    if (W == 32 && KT == 32) return launch_solve_t<32, 32>(p, lds_bytes, stream);
-    if (W == 64 && KT == 64) return launch_solve_t<64, 64>(p, lds_bytes, stream);
-    return hipErrorInvalidValue;
-}
 
 }  // namespace tinympc
