@@ -27,7 +27,6 @@ import json
 import os
 import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,9 +42,11 @@ def parse_args():
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
     ap.add_argument("--iters", type=int, default=200, help="forced ADMM iterations per solve")
     ap.add_argument("--horizon", type=int, default=50)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker-index", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -56,38 +57,52 @@ def relaunch_under_torchrun(args) -> int:
     return subprocess.call(cmd)
 
 
-def cpu_baseline(P, prob, iters: int, seconds: float) -> dict:
-    """Reference core (or the C port) on all host cores: each thread owns one solver object and runs
-    cold-started 200-iteration solves of seeded quadrotor instances until the time budget is spent."""
+def cpu_worker(seconds: float, iters: int, horizon: int, index: int) -> int:
+    """One baseline process: cold-started `iters`-iteration quadrotor solves on ONE core until the time
+    budget is spent. Prints 'kind total_iterations elapsed_seconds'. Never touches the GPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, ROOT)
     import pyoracle as O  # checker / baseline only
+    import __graft_entry__ as ge
 
+    P = ge.load_package().problems
+    prob = P.quadrotor(horizon)
     settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1)
     cls = O.OracleRef if O.ref_available() else O.OraclePort
-    cores = os.cpu_count() or 1
-    per_call = 16
-    x0s = P.quadrotor_batch_x0(per_call * cores)
-    solvers = [cls(prob).load_problem(prob, settings) for _ in range(cores)]
-    counts = [0] * cores
-    deadline = time.perf_counter() + seconds
-
-    def work(t):
-        mine = x0s[:, t * per_call:(t + 1) * per_call]
-        while time.perf_counter() < deadline:
-            counts[t] += solvers[t].bench_solves(mine, 1)  # ctypes releases the GIL during the call
-
+    solver = cls(prob).load_problem(prob, settings)
+    x0s = P.quadrotor_batch_x0(16, offset=16 * index)
+    total = 0
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.perf_counter() - t0
-    total = sum(counts)
-    # single-thread figure from a short separate run (for the per-core anchor of SURVEY.md section 6)
-    t1 = time.perf_counter()
-    one = solvers[0].bench_solves(x0s[:, :per_call], 2)
-    dt1 = time.perf_counter() - t1
+    while time.perf_counter() - t0 < seconds:
+        total += solver.bench_solves(x0s, 1)
+    print(cls.kind, total, time.perf_counter() - t0, flush=True)
+    return 0
+
+
+def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
+    """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host
+    cores: one PROCESS per logical CPU (Eigen's per-operation malloc makes threads of one process contend),
+    each running seeded cold-started solves for `seconds`. Runs before this process initialises the GPU."""
+    cores = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-seconds", str(seconds),
+           "--iters", str(iters), "--horizon", str(horizon)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + ["--worker-index", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(cores)]
+    total, kind, rates = 0, "port", []
+    for pr in procs:
+        out, _ = pr.communicate()
+        try:
+            k, n, dt = out.split()[-3:]
+            kind, total = k, total + int(n)
+            rates.append(int(n) / float(dt))
+        except (ValueError, IndexError):
+            pass
+    wall = time.perf_counter() - t0
+    # one process alone, for the per-core anchor (SURVEY.md section 6)
+    one = subprocess.run(cmd + ["--worker-index", "0", "--cpu-seconds", "2"], stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, text=True).stdout.split()
+    single = int(one[-2]) / float(one[-1]) if len(one) >= 3 else float("nan")
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -97,19 +112,28 @@ def cpu_baseline(P, prob, iters: int, seconds: float) -> dict:
                     break
     except OSError:
         pass
-    return {"value": total / dt, "unit": "ADMM iters/s", "cores": cores, "kind": cls.kind,
-            "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={prob.N} solves over {cores} threads in {dt:.1f} s "
-                      f"(seeded x0, same settings as the GPU run)",
-            "single_thread_iters_per_s": one / dt1, "us_per_iter_single_thread": 1e6 * dt1 / one, "cpu_model": cpu_model}
+    value = sum(rates)
+    return {"value": value, "unit": "ADMM iters/s", "cores": len(rates), "kind": kind,
+            "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={horizon} solves, {len(rates)} single-threaded "
+                      f"processes x {seconds:.0f} s each ({wall:.1f} s wall; seeded x0, same settings as the GPU run)",
+            "single_process_iters_per_s": single, "us_per_iter_single_process": 1e6 / single if single == single else None,
+            "cpu_model": cpu_model}
 
 
 def main() -> int:
     args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_seconds, args.iters, args.horizon, args.worker_index)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         return relaunch_under_torchrun(args)  # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # CPU baseline first (rank 0, single-GPU runs only): child processes, started before this process
+    # has initialised the GPU, so the host cores are not shared with the timed GPU region either.
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.iters, args.horizon, args.cpu_seconds)
 
     import numpy as np
     import torch
@@ -228,9 +252,9 @@ def main() -> int:
             out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
                                       "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS}
             one.reset()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, prob, args.iters, args.cpu_seconds)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
     solver.reset()
     if world > 1:

@@ -1,0 +1,143 @@
+"""The MEX shim (tinympc-matlab_amd/matlab/tinympc_matlab_mex.cpp) driven verb by verb through a mock of
+the MEX C API (tests/mock_mex): the string-verb dispatcher, argument counts and error identifiers of the
+reference's MEX function (bindings.cpp:641-692), without MATLAB. CPU tests cover dispatch and errors;
+the gpu-marked test runs the reference's one-solve script flow end to end against the golden fixture."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from conftest import ROOT, golden, rel_err
+
+MOCK = os.path.join(ROOT, "tests", "mock_mex", "libtinympc_matlab_mock.so")
+
+
+class Mex:
+    def __init__(self):
+        if not os.path.exists(MOCK):
+            pytest.fail("tests/mock_mex/libtinympc_matlab_mock.so missing: run `python __graft_entry__.py`")
+        L = C.CDLL(MOCK)
+        self.L = L
+        L.mxCreateDoubleMatrix.restype = C.c_void_p
+        L.mxCreateDoubleMatrix.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+        L.mxCreateInt32Matrix.restype = C.c_void_p
+        L.mxCreateInt32Matrix.argtypes = [C.c_size_t, C.c_size_t]
+        L.mxCreateString.restype = C.c_void_p
+        L.mxCreateString.argtypes = [C.c_char_p]
+        L.mxGetPr.restype = C.POINTER(C.c_double)
+        L.mxGetPr.argtypes = [C.c_void_p]
+        L.mxGetData.restype = C.c_void_p
+        L.mxGetData.argtypes = [C.c_void_p]
+        L.mxGetM.restype = C.c_size_t
+        L.mxGetM.argtypes = [C.c_void_p]
+        L.mxGetN.restype = C.c_size_t
+        L.mxGetN.argtypes = [C.c_void_p]
+        L.mxDestroyArray.argtypes = [C.c_void_p]
+        L.mock_mex_call.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        L.mock_mex_last_id.restype = C.c_char_p
+        L.mock_mex_last_msg.restype = C.c_char_p
+
+    def to_mx(self, v):
+        if isinstance(v, str):
+            return self.L.mxCreateString(v.encode())
+        a = np.asarray(v)
+        if a.dtype == np.int32:
+            a = np.atleast_1d(a)
+            h = self.L.mxCreateInt32Matrix(a.size, 1)
+            C.memmove(self.L.mxGetData(h), a.ctypes.data, a.nbytes)
+            return h
+        a = np.asfortranarray(np.atleast_2d(np.asarray(v, dtype=np.float64)))
+        if np.ndim(v) == 1:
+            a = np.asfortranarray(a.reshape(-1, 1))
+        m, n = (a.shape if a.size else (0, 0))
+        h = self.L.mxCreateDoubleMatrix(m, n, 0)
+        if a.size:
+            C.memmove(self.L.mxGetPr(h), a.ctypes.data, a.nbytes)
+        return h
+
+    def call(self, verb, *args, nlhs=0):
+        """tinympc_matlab(verb, args...) -> (error_id or None, [outputs as numpy])"""
+        ins = [self.to_mx(verb)] + [self.to_mx(a) for a in args]
+        prhs = (C.c_void_p * len(ins))(*ins)
+        plhs = (C.c_void_p * max(nlhs, 4))()
+        rc = self.L.mock_mex_call(nlhs, plhs, len(ins), prhs)
+        outs = []
+        if rc == 0:
+            for k in range(nlhs):
+                h = plhs[k]
+                m, n = self.L.mxGetM(h), self.L.mxGetN(h)
+                outs.append(np.ctypeslib.as_array(self.L.mxGetPr(h), shape=(n, m)).T.copy())
+        for h in ins:
+            self.L.mxDestroyArray(h)
+        return (self.L.mock_mex_last_id().decode() if rc else None), outs
+
+
+@pytest.fixture(scope="module")
+def mex():
+    return Mex()
+
+
+def test_unknown_verb_and_missing_verb(mex):
+    err, _ = mex.call("frobnicate")
+    assert err == "TinyMPC:InvalidFunction"  # bindings.cpp:685
+    prhs = (C.c_void_p * 1)()
+    plhs = (C.c_void_p * 1)()
+    assert mex.L.mock_mex_call(0, plhs, 0, prhs) == 1
+    assert mex.L.mock_mex_last_id() == b"TinyMPC:InvalidInput"  # bindings.cpp:642-644
+
+
+def test_verbs_before_setup_are_not_initialized(mex):
+    mex.call("reset", 0.0)
+    for verb, args in (("set_x0", (np.zeros(4), 0.0)), ("solve", (0.0,)), ("get_solution", (0.0,)), ("get_stats", (0.0,)),
+                       ("set_x_ref", (np.zeros((4, 20)), 0.0)), ("update_settings", tuple([0.0] * 15))):
+        err, _ = mex.call(verb, *args)
+        assert err == "TinyMPC:NotInitialized", verb  # bindings.cpp:112-114 etc.
+
+
+def test_argument_count_errors(mex):
+    assert mex.call("setup", np.eye(2))[0] == "TinyMPC:InvalidInput"          # bindings.cpp:49-51
+    assert mex.call("set_x0", np.zeros(4))[0] == "TinyMPC:InvalidInput"       # :108-110
+    assert mex.call("solve")[0] == "TinyMPC:InvalidInput"                     # :213-215
+    assert mex.call("update_settings", 1.0, 2.0)[0] == "TinyMPC:InvalidInput"  # :549-551
+    assert mex.call("reset", 0.0)[0] is None                                  # resetting nothing is fine (:539)
+
+
+def test_setup_without_gpu_raises_setup_failed(mex, pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    p = pkg.problems.cartpole()
+    err, _ = mex.call("setup", p.A, p.B, np.zeros((4, 1)), p.Q, p.R, 1.0, 4.0, 1.0, 20.0, 0.0, nlhs=1)
+    assert err == "TinyMPC:SetupFailed"  # no device: fail loudly, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_one_solve_script_through_the_mex_verbs(mex, pkg):
+    """examples/cartpole_example_one_solve.m + bounds, expressed as the MEX calls TinyMPC.m makes."""
+    g = golden("cartpole_box_tol")
+    nx, nu, N = 4, 1, 20
+    err, out = mex.call("setup", g["A"], g["B"], np.zeros((nx, 1)), g["Q"], g["R"], float(g["rho"]), float(nx), float(nu),
+                        float(N), 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] == 0
+    settings = [1e-4, 1e-4, 100.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 10.0, 1.0, 0.0]
+    assert mex.call("update_settings", *settings)[0] is None
+    assert mex.call("set_bound_constraints", g["x_min"], g["x_max"], g["u_min"], g["u_max"], 0.0)[0] is None
+    settings[4] = settings[5] = 1.0
+    assert mex.call("update_settings", *settings)[0] is None
+    assert mex.call("set_x0", g["x0"], 0.0)[0] is None
+    err, out = mex.call("solve", 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] == 0
+    err, (x, u) = mex.call("get_solution", 0.0, nlhs=2)
+    assert err is None and x.shape == (nx, N) and u.shape == (nu, N - 1)
+    assert rel_err(x, g["sol_x"]) < 1e-9 and rel_err(u, g["sol_u"]) < 1e-9
+    err, (it, status, pri_x, pri_u) = mex.call("get_stats", 0.0, nlhs=4)
+    assert int(it[0, 0]) == int(g["iter"]) and int(status[0, 0]) == 1
+    np.testing.assert_allclose([pri_x[0, 0], pri_u[0, 0]], g["residuals"][[0, 2]], rtol=1e-5, atol=1e-12)
+    # wrong-shaped bounds and references are rejected with the reference's identifiers
+    assert mex.call("set_bound_constraints", g["x_min"][:, :5], g["x_max"], g["u_min"], g["u_max"], 0.0)[0] == "TinyMPC:SetBoundConstraintsFailed"
+    assert mex.call("set_x_ref", np.zeros((3, N)), 0.0)[0] == "TinyMPC:SetXRefFailed"
+    err, out = mex.call("codegen", "/tmp/out", 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] != 0  # status != 0 -> TinyMPC.m raises TinyMPC:CodegenFailed
+    assert mex.call("reset", 0.0)[0] is None
+    assert mex.call("solve", 0.0)[0] == "TinyMPC:NotInitialized"
