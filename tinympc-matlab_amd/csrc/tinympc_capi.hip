@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -76,12 +77,15 @@ struct tinympc_solver {
     double *ddstats = nullptr;
     size_t lds_bytes = 0;
     bool tables_in_lds = false;
+    bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
+    double *dV2 = nullptr;
     int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
     std::vector<void *> allocs;
 
     size_t X() const { return (size_t)nx * N; }
     size_t U() const { return (size_t)nu * (N - 1); }
-    size_t state_doubles() const { return (size_t)groups * (N + 1) * 64; }  // row N: per-lane dummy slot
+    size_t state_doubles() const { return (size_t)groups * (N + 1) * 64; }  // G; row N: per-lane dummy slot
+    size_t v_doubles() const { return (size_t)groups * v_rows(N) * 64; }     // V (and V2)
     size_t d_doubles() const { return (size_t)groups * (N - 1) * IPW * nu; }
 };
 
@@ -173,11 +177,15 @@ int launch(tinympc_solver *s, bool timed) {
     p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
     p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
     p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0;
-    p.G = s->dG; p.V = s->dV; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
+    p.groups = s->groups;
+    p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
     p.istats = s->distats; p.dstats = s->ddstats;
     p.tables_in_lds = s->tables_in_lds ? 1 : 0;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-    HIP_TRY(launch_solve(p, s->W, s->KT, s->lds_bytes, s->stream));
+    if (s->layout_b)
+        HIP_TRY(launch_solve_b(p, s->W, s->KT, s->lds_bytes, s->stream));
+    else
+        HIP_TRY(launch_solve(p, s->W, s->KT, s->lds_bytes, s->stream));
     if (timed) HIP_TRY(hipEventRecord(s->ev1, s->stream));
     return TINYMPC_OK;
 }
@@ -270,6 +278,25 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     const size_t slots_without = kLdsMax / without, slots_with = kLdsMax / with_tables;
     s->tables_in_lds = (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
     s->lds_bytes = s->tables_in_lds ? with_tables : without;
+    // Layout A keeps all ADMM state in LDS (2 wavefronts per CU at quadrotor size, lowest latency);
+    // layout B trades LDS for L2-resident V traffic to fit 4 wavefronts per CU. B pays off once the
+    // grid has more wavefronts than layout A can keep resident (2 per CU x 256 CUs).
+    // TINYMPC_LAYOUT=A|B overrides the choice (kernel A/B experiments).
+    {
+        const size_t b_bytes = solve_b_lds_bytes(nx, nu, N, W);
+        const bool b_possible = (W == 16) && (N >= 8) && (b_bytes <= kLdsMax);
+        const size_t a_resident = (kLdsMax / s->lds_bytes) * 256;
+        bool want_b = b_possible && ((size_t)s->groups > a_resident) && (kLdsMax / s->lds_bytes) < (size_t)WAVES_PER_GROUP_B;
+        if (const char *env = getenv("TINYMPC_LAYOUT")) {
+            if (env[0] == 'A' || env[0] == 'a') want_b = false;
+            if ((env[0] == 'B' || env[0] == 'b') && b_possible) want_b = true;
+        }
+        if (want_b) {
+            s->layout_b = true;
+            s->tables_in_lds = true;
+            s->lds_bytes = b_bytes;
+        }
+    }
 
     const size_t X = s->X(), U = s->U();
     TRY(dalloc(s, &s->dA, (size_t)nx * nx)); TRY(dalloc(s, &s->dB, (size_t)nx * nu)); TRY(dalloc(s, &s->dfdyn, nx));
@@ -282,7 +309,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));
     TRY(dalloc(s, &s->dops, ops_doubles(W, KT))); TRY(dalloc(s, &s->dtables, tables_doubles(W, N)));
     TRY(dalloc(s, &s->dx0, (size_t)batch * nx));
-    TRY(dalloc(s, &s->dG, s->state_doubles())); TRY(dalloc(s, &s->dV, s->state_doubles())); TRY(dalloc(s, &s->dD, s->d_doubles()));
+    TRY(dalloc(s, &s->dG, s->state_doubles())); TRY(dalloc(s, &s->dV, s->v_doubles())); TRY(dalloc(s, &s->dV2, s->v_doubles())); TRY(dalloc(s, &s->dD, s->d_doubles()));
     TRY(dalloc(s, &s->dsolx, X * batch)); TRY(dalloc(s, &s->dsolu, U * batch));
     TRY(dalloc(s, &s->distats, (size_t)batch * 2)); TRY(dalloc(s, &s->ddstats, (size_t)batch * 4));
 
@@ -300,7 +327,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     HIP_TRY_S(hipMemsetAsync(s->dUref, 0, sizeof(double) * U, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dx0, 0, sizeof(double) * batch * nx, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
-    HIP_TRY_S(hipMemsetAsync(s->dV, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dV, 0, sizeof(double) * s->v_doubles(), s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->dV2, 0, sizeof(double) * s->v_doubles(), s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dsolx, 0, sizeof(double) * X * batch, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dsolu, 0, sizeof(double) * U * batch, s->stream));
@@ -640,7 +668,8 @@ int tinympc_reset_workspace(tinympc_solver *s) {
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
     HIP_TRY(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
-    HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->v_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dV2, 0, sizeof(double) * s->v_doubles(), s->stream));
     HIP_TRY(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
     HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
@@ -663,7 +692,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->groups;
+    if (workgroups) *workgroups = s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)s->lds_bytes;
     if (tables_in_lds) *tables_in_lds = s->tables_in_lds ? 1 : 0;
     return TINYMPC_OK;

@@ -25,6 +25,12 @@ __host__ __device__ inline size_t ops_doubles(int W, int KT) { return (size_t)2 
 //   linref     -(Xref .* Q) / -(Uref .* R)                                       (admm.cpp:77, 79)
 // followed by pNref[W] = -(Xref[:,N-1]' * Pinf)'                                  (admm.cpp:81)
 __host__ __device__ inline size_t table_rows(int N) { return (size_t)N + 2; }
+
+// HBM layout of the slack array V (v|z): [groups][N + 1 + 2*V_PAD][64]. Knot k is row k + V_PAD, row
+// N + V_PAD holds the per-lane dummy slots, and V_PAD untouched rows at either end absorb the
+// 4-steps-ahead prefetch of the layout-B kernel. Layout B uses two such buffers as a ping-pong pair.
+constexpr int V_PAD = 4;
+__host__ __device__ inline size_t v_rows(int N) { return (size_t)N + 1 + 2 * V_PAD; }
 __host__ __device__ inline size_t tables_doubles(int W, int N) { return 3 * table_rows(N) * W + W; }
 
 struct PrecomputeParams {
@@ -59,7 +65,10 @@ struct SolveParams {
     const double *ops;
     const double *tables;
     const double *x0;  // [batch][nx]
-    double *G, *V;     // [groups][N][64]     duals (g|y) and slack (v|z), persistent across solves
+    int groups;        // ceil(batch / (64/W))
+    double *G;         // [groups][N+1][64]          duals (g|y), persistent across solves (row N: dummy slots)
+    double *V, *V2;    // [groups][v_rows(N)][64]    slack (v|z); V is the canonical copy between solves,
+                       //                            V2 the second half of layout B's ping-pong pair
     double *D;         // [groups][N-1][IPW*nu]  feed-forward term d, persistent across solves
     double *sol_x;     // [batch][N][nx]      == nx x N x batch column-major
     double *sol_u;     // [batch][N-1][nu]
@@ -72,8 +81,14 @@ struct SolveParams {
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream);
 hipError_t launch_build_tables(const TableParams &p, hipStream_t stream);
+// Layout A: one wavefront per workgroup, all ADMM state in LDS (lowest latency, 2 waves per CU).
 // Chooses the <W,KT> instantiation; returns hipErrorInvalidValue when none fits.
 hipError_t launch_solve(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+// Layout B: four wavefronts per workgroup sharing the tables in LDS, G and D in LDS, V as an
+// L2-resident ping-pong pair in HBM (4 waves per CU). Only W = 16, N >= 8.
+hipError_t launch_solve_b(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
+constexpr int WAVES_PER_GROUP_B = 4;
 // Geometry helpers shared with the host layer.
 bool choose_geometry(int nx, int nu, int *W, int *KT);
 size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds);
