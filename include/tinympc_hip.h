@@ -190,6 +190,10 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
 int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave,
                             int *workgroups, int *lds_bytes, int *tables_in_lds);
 
+/* Which solve kernel the handle uses: 'A' (all ADMM state in LDS, one wavefront per workgroup) or 'B'
+ * (V as an L2-resident HBM ping-pong pair, four wavefronts per workgroup). 0 for a NULL handle. */
+int tinympc_get_layout(tinympc_solver *s);
+
 /* The HIP stream of the handle as an opaque pointer (hipStream_t). */
 void *tinympc_get_stream(tinympc_solver *s);
 

@@ -20,6 +20,15 @@ assert TOL < TOL_BAR
 SINGLE = ["cartpole_unconstrained", "cartpole_box_tol", "cartpole_box_200", "quadrotor_box_200", "quadrotor_box_tol"]
 
 
+@pytest.fixture(autouse=True, params=["A", "B"])
+def kernel_layout(request, monkeypatch):
+    """Every test runs against both solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip)
+    and layout B (V as an HBM ping-pong pair, 4-wave workgroups, tinympc_solve_b.hip). The layout is
+    chosen at setup time; where B does not apply (W > 16 or N < 8) the library falls back to A."""
+    monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
+    return request.param
+
+
 def make_solver(pkg, prob, settings, batch=1):
     s = pkg.TinyMPC()
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho,
@@ -43,6 +52,21 @@ def test_native_library_is_loaded(pkg):
     assert pkg.device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libtinympc_hip.so" in f.read()
+
+
+def test_layout_selection(pkg, kernel_layout, monkeypatch):
+    P = pkg.problems
+    s = make_solver(pkg, P.quadrotor(50), {})
+    assert s.launch_info()["layout"] == kernel_layout  # the env override is honoured where B applies
+    s.reset()
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    s = make_solver(pkg, P.quadrotor(50), {}, batch=8)
+    info = s.launch_info()
+    assert info["layout"] == "B" and info["workgroups"] == 1 and info["lds_bytes"] <= 160 * 1024  # default: B where it fits
+    s.reset()
+    s = make_solver(pkg, P.cartpole(5, True), {})
+    assert s.launch_info()["layout"] == "A"  # N < 8: layout B's 4-deep prefetch ring does not apply
+    s.reset()
 
 
 @pytest.mark.parametrize("name", SINGLE)

@@ -318,7 +318,7 @@ class TinyMPC:
         v = [C.c_int() for _ in range(5)]
         _lib.check(self._L.tinympc_get_launch_info(self._h, *[C.byref(x) for x in v]))
         return dict(lanes_per_instance=v[0].value, instances_per_wave=v[1].value, workgroups=v[2].value,
-                    lds_bytes=v[3].value, tables_in_lds=bool(v[4].value))
+                    lds_bytes=v[3].value, tables_in_lds=bool(v[4].value), layout=chr(self._L.tinympc_get_layout(self._h)))
 
     # ------------------------------------------------------------------ private helpers
     def _check_setup(self):
