@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -80,6 +81,18 @@ struct tinympc_solver {
     bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
     double *dV2 = nullptr;
     int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
+    // cone / linear families (host copies of what the verbs received; k_admm_solve_fam consumes `dfam`)
+    std::vector<int> Acx, qcx, Acu, qcu;
+    std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
+    double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
+    bool fam_dirty = true;
+    size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
+    bool tables_in_lds_a = false;
+
+    bool families_active() const {
+        return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
+               (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
+    }
     std::vector<void *> allocs;
 
     size_t X() const { return (size_t)nx * N; }
@@ -164,14 +177,76 @@ int refresh_derived(tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+// Per-lane description of the cone / linear families for k_admm_solve_fam (layout: fam_doubles()).
+// Masks and user coefficients only -- no solver arithmetic happens here.
+int refresh_families(tinympc_solver *s) {
+    const int W = s->W, KT = s->KT, nx = s->nx, nu = s->nu, nxu = nx + nu;
+    if (!s->dfam) {
+        int rc;
+        if ((rc = dalloc(s, &s->dfam, fam_doubles(W, KT)))) return rc;
+        if ((rc = dalloc(s, &s->dGC, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dGL, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dLX, s->v_doubles()))) return rc;
+        HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
+        s->fam_dirty = true;
+    }
+    if (!s->fam_dirty) return TINYMPC_OK;
+    std::vector<double> f(fam_doubles(W, KT), 0.0);
+    double *role = f.data(), *mu = role + W, *famc = mu + W, *faml = famc + W;
+    double *Cn = faml + W, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT, *lin = Ty + (size_t)W * KT;
+    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
+    const bool lin_x = s->st.en_state_linear && s->n_lin_x > 0, lin_u = s->st.en_input_linear && s->n_lin_u > 0;
+    for (int r = 0; r < nxu; ++r) {
+        const bool is_x = r < nx;
+        famc[r] = (is_x ? cone_x : cone_u) ? 1.0 : 0.0;
+        faml[r] = (is_x ? lin_x : lin_u) ? 1.0 : 0.0;
+        for (int k = 0; k < nxu; ++k)
+            if ((k < nx) == is_x) Ty[(size_t)r * KT + k] = 1.0;
+    }
+    auto add_cones = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
+        if (!on) return;
+        for (size_t ci = 0; ci < Ac.size(); ++ci) {
+            const int first = base + Ac[ci], last = first + qc[ci] - 1;
+            for (int r = first; r <= last; ++r) {
+                role[r] = (r == last) ? 2.0 : 1.0;
+                mu[r] = c[ci];
+                for (int k = first; k < last; ++k) Cn[(size_t)r * KT + k] = 1.0;
+                Ct[(size_t)r * KT + last] = 1.0;
+            }
+        }
+    };
+    add_cones(cone_x, s->Acx, s->qcx, s->cx, 0);
+    add_cones(cone_u, s->Acu, s->qcu, s->cu, nx);
+    const int nlx = lin_x ? s->n_lin_x : 0, nlu = lin_u ? s->n_lin_u : 0;
+    const int nl = nlx > nlu ? nlx : nlu;
+    lin[0] = (double)nl;
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+        double *ak = lin + 1 + (size_t)(3 * k + 0) * W, *bk = ak + W, *nk = bk + W;
+        double nrm_x = 0.0, nrm_u = 0.0;
+        if (k < nlx) for (int c = 0; c < nx; ++c) { const double a = s->Alin_x[k + (size_t)c * s->n_lin_x]; nrm_x += a * a; }
+        if (k < nlu) for (int c = 0; c < nu; ++c) { const double a = s->Alin_u[k + (size_t)c * s->n_lin_u]; nrm_u += a * a; }
+        for (int r = 0; r < W; ++r) {
+            ak[r] = 0.0; bk[r] = inf; nk[r] = 1.0;
+            if (r < nx && k < nlx) { ak[r] = s->Alin_x[k + (size_t)r * s->n_lin_x]; bk[r] = s->blin_x[k]; nk[r] = nrm_x; }
+            if (r >= nx && r < nxu && k < nlu) { ak[r] = s->Alin_u[k + (size_t)(r - nx) * s->n_lin_u]; bk[r] = s->blin_u[k]; nk[r] = nrm_u; }
+        }
+    }
+    int rc = upload(s, s->dfam, f.data(), f.size());
+    if (rc) return rc;
+    s->fam_dirty = false;
+    return TINYMPC_OK;
+}
+
 int launch(tinympc_solver *s, bool timed) {
     if (s->st.adaptive_rho)
         return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6)");
-    if ((s->st.en_state_soc && s->n_cone_x) || (s->st.en_input_soc && s->n_cone_u) ||
-        (s->st.en_state_linear && s->n_lin_x) || (s->st.en_input_linear && s->n_lin_u))
-        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "cone / linear constraint families are not implemented in the HIP path yet");
     int rc = refresh_derived(s);
     if (rc) return rc;
+    const bool fam = s->families_active();
+    if (fam && (rc = refresh_families(s))) return rc;
     SolveParams p{};
     p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = s->batch;
     p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
@@ -181,11 +256,18 @@ int launch(tinympc_solver *s, bool timed) {
     p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
     p.istats = s->distats; p.dstats = s->ddstats;
     p.tables_in_lds = s->tables_in_lds ? 1 : 0;
+    p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-    if (s->layout_b)
+    if (fam) {
+        // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
+        // handle can switch between them from one solve to the next.
+        p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
+        HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (s->layout_b) {
         HIP_TRY(launch_solve_b(p, s->W, s->KT, s->lds_bytes, s->stream));
-    else
+    } else {
         HIP_TRY(launch_solve(p, s->W, s->KT, s->lds_bytes, s->stream));
+    }
     if (timed) HIP_TRY(hipEventRecord(s->ev1, s->stream));
     return TINYMPC_OK;
 }
@@ -278,6 +360,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     const size_t slots_without = kLdsMax / without, slots_with = kLdsMax / with_tables;
     s->tables_in_lds = (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
     s->lds_bytes = s->tables_in_lds ? with_tables : without;
+    s->lds_bytes_a = s->lds_bytes;
+    s->tables_in_lds_a = s->tables_in_lds;
     // Layout A keeps all ADMM state in LDS (2 wavefronts per CU at quadrotor size); layout B keeps V as an
     // L2-resident ping-pong pair in HBM and fits 4 wavefronts per CU. Measured on MI355X (quadrotor N=50):
     // B is 1.72x faster on a GPU-filling batch (5.56 vs 9.57 ms per 8192 x 200 iterations) and also
@@ -561,12 +645,27 @@ int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, cons
     if (nlx < 0 || nlu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative constraint count");
     if ((nlx > 0 && (!Alin_x || !blin_x)) || (nlu > 0 && (!Alin_u || !blin_u)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_linear_constraints: NULL matrix for a non-empty side");
+    if (nlx > MAX_LIN_ROWS || nlu > MAX_LIN_ROWS)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d linear rows per side are supported by the HIP kernel (got %d state, %d input)",
+                    MAX_LIN_ROWS, nlx, nlu);
+    auto zero_row = [](const double *A, int rows, int cols, int k) {
+        for (int c = 0; c < cols; ++c)
+            if (A[k + (size_t)c * rows] != 0.0) return false;
+        return true;
+    };
+    for (int k = 0; k < nlx; ++k)
+        if (zero_row(Alin_x, nlx, s->nx, k)) return fail(TINYMPC_ERR_INVALID_INPUT, "Alin_x row %d is all zero", k);
+    for (int k = 0; k < nlu; ++k)
+        if (zero_row(Alin_u, nlu, s->nu, k)) return fail(TINYMPC_ERR_INVALID_INPUT, "Alin_u row %d is all zero", k);
     s->n_lin_x = nlx;
     s->n_lin_u = nlu;
+    s->Alin_x.assign(Alin_x, Alin_x + (size_t)nlx * s->nx);
+    s->blin_x.assign(blin_x, blin_x + nlx);
+    s->Alin_u.assign(Alin_u, Alin_u + (size_t)nlu * s->nu);
+    s->blin_u.assign(blin_u, blin_u + nlu);
     if (nlx > 0) s->st.en_state_linear = 1;  // bindings.cpp:422-429
     if (nlu > 0) s->st.en_input_linear = 1;
-    if (nlx > 0 || nlu > 0)
-        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "linear-inequality slack family is not implemented in the HIP path yet; solve will refuse to run while it is enabled");
+    s->fam_dirty = true;
     return TINYMPC_OK;
 }
 
@@ -577,12 +676,31 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
     if (ncx < 0 || ncu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative cone count");
     if ((ncx > 0 && (!Acx || !qcx || !cx)) || (ncu > 0 && (!Acu || !qcu || !cu)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_cone_constraints: NULL array for a non-empty side");
+    // Each cone must lie inside its vector and cones of one side must not share rows: the kernel projects
+    // all cones of a knot at once (upstream applies them one after another, which only differs if they overlap).
+    auto check_side = [&](const int *Ac, const int *qc, const double *c, int n, int dim, const char *side) -> int {
+        std::vector<int> owner(dim, -1);
+        for (int k = 0; k < n; ++k) {
+            if (qc[k] < 1 || Ac[k] < 0 || Ac[k] + qc[k] > dim)
+                return fail(TINYMPC_ERR_INVALID_INPUT, "%s cone %d (start %d, dimension %d) does not fit a vector of %d rows", side, k, Ac[k], qc[k], dim);
+            if (!(c[k] > 0.0)) return fail(TINYMPC_ERR_INVALID_INPUT, "%s cone %d has non-positive slope %g", side, k, c[k]);
+            for (int r = Ac[k]; r < Ac[k] + qc[k]; ++r) {
+                if (owner[r] >= 0)
+                    return fail(TINYMPC_ERR_UNSUPPORTED, "%s cones %d and %d overlap at row %d: overlapping cones are not supported by the HIP kernel", side, owner[r], k, r);
+                owner[r] = k;
+            }
+        }
+        return TINYMPC_OK;
+    };
+    if ((rc = check_side(Acx, qcx, cx, ncx, s->nx, "state"))) return rc;
+    if ((rc = check_side(Acu, qcu, cu, ncu, s->nu, "input"))) return rc;
     s->n_cone_x = ncx;
     s->n_cone_u = ncu;
+    s->Acx.assign(Acx, Acx + ncx); s->qcx.assign(qcx, qcx + ncx); s->cx.assign(cx, cx + ncx);
+    s->Acu.assign(Acu, Acu + ncu); s->qcu.assign(qcu, qcu + ncu); s->cu.assign(cu, cu + ncu);
     if (ncx > 0) s->st.en_state_soc = 1;  // bindings.cpp:468-476
     if (ncu > 0) s->st.en_input_soc = 1;
-    if (ncx > 0 || ncu > 0)
-        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "second-order-cone slack family is not implemented in the HIP path yet; solve will refuse to run while it is enabled");
+    s->fam_dirty = true;
     return TINYMPC_OK;
 }
 
@@ -610,6 +728,7 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
     s->st.adaptive_rho = adaptive_rho; s->st.adaptive_rho_min = adaptive_rho_min;
     s->st.adaptive_rho_max = adaptive_rho_max; s->st.adaptive_rho_enable_clipping = adaptive_rho_enable_clipping;
     if (bounds_changed) s->tables_dirty = true;
+    s->fam_dirty = true;  // the family enable flags are folded into the per-lane family description
     if (adaptive_rho)
         return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6); solve will refuse to run while it is enabled");
     if (verbose) printf("Settings updated successfully\n");
@@ -671,6 +790,11 @@ int tinympc_reset_workspace(tinympc_solver *s) {
     HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->v_doubles(), s->stream));
     HIP_TRY(hipMemsetAsync(s->dV2, 0, sizeof(double) * s->v_doubles(), s->stream));
     HIP_TRY(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
+    if (s->dGC) {
+        HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
+    }
     HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));

@@ -75,7 +75,24 @@ struct SolveParams {
     int *istats;       // [batch][2]  iter, status
     double *dstats;    // [batch][4]  pri_x, dua_x, pri_u, dua_u
     int tables_in_lds;
+    // Cone / linear-inequality slack families (k_admm_solve_fam only; PARITY UNPINNED upstream semantics)
+    const double *fam;  // per-lane family description, see fam_doubles()
+    double *GC, *GL;    // [groups][v_rows(N)][64]  duals gc|yc and gl|yl, persistent across solves
+    double *LX;         // [groups][v_rows(N)][64]  -rho*(vcnew-gc) - rho*(vlnew-gl), forward -> backward
 };
+
+// Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
+//   role[W]   0 = row in no cone, 1 = norm member, 2 = the cone's last ("t") row
+//   mu[W]     slope of the row's cone
+//   famc[W]   1 if the cone family is enabled for this row's side (state / input), else 0
+//   faml[W]   same for the linear family
+//   Cn[W][KT] 0/1: columns = norm-member rows of the row's cone      (a^2 = Cn * s.^2)
+//   Ct[W][KT] 0/1: column  = the t row of the row's cone             (t   = Ct * s)
+//   Ty[W][KT] 0/1: columns = rows of the same side                   (dot = Ty * (a_k .* s))
+//   nl        number of linear rows in use (max over the two sides), then for k < MAX_LIN_ROWS:
+//   ak[W], bk[W], nk[W]   coefficient of the row in constraint k, its bound (+inf if absent), ||a_k||^2
+constexpr int MAX_LIN_ROWS = 8;
+__host__ __device__ inline size_t fam_doubles(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
 
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
@@ -89,6 +106,8 @@ hipError_t launch_solve(const SolveParams &p, int W, int KT, size_t lds_bytes, h
 hipError_t launch_solve_b(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
 constexpr int WAVES_PER_GROUP_B = 4;
+// Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
+hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 // Geometry helpers shared with the host layer.
 bool choose_geometry(int nx, int nu, int *W, int *KT);
 size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds);
