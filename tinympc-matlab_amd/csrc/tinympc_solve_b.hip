@@ -18,6 +18,8 @@
 // both ends so the prefetch never needs clamping. The values a sweep needs right at its start are
 // never waited for: the backward sweep takes the last forward steps' vnew straight from registers, and
 // the operands of the next forward sweep's first steps are requested at the start of the backward sweep.
+#include <type_traits>
+
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
 
@@ -33,6 +35,24 @@ static __host__ __device__ inline size_t b_wave_doubles(int nu, int N, int W) {
 size_t solve_b_lds_bytes(int nx, int nu, int N, int W) {
     (void)nx;
     return (b_tables_doubles(W, N) + WPG * b_wave_doubles(nu, N, W)) * sizeof(double);
+}
+
+#ifndef TINY_B_INPLACE
+#define TINY_B_INPLACE 1  // 1: V updated in place + conditional stale copy; 0: unconditional ping-pong pair
+#endif
+
+// `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the
+// lanes that belong to a still-active instance. True if some live instance has no bad lane.
+template <int W>
+__device__ __forceinline__ bool wave_may_converge(unsigned long long bad, unsigned long long live) {
+    constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 64 / W; ++j) {
+        const unsigned long long b = (bad >> (j * W)) & ones, l = (live >> (j * W)) & ones;
+        any = any || (l != 0ull && b == 0ull);
+    }
+    return any;
 }
 
 struct FwdLds { double g, lo, hi, dv; };
@@ -128,8 +148,12 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
         if (__ballot(active) == 0ull) break;
         const bool check = (ct > 0) && (((it + 1) % ct) == 0);  // admm.cpp:91 (iter already incremented, :143)
         const bool st = active && row_ok;
+#if TINY_B_INPLACE
+        double *const Vr = gV0, *const Vw = gV0;  // V is updated in place; gV1 receives the stale copy (below)
+#else
         double *const Vr = (it & 1) ? gV1 : gV0;  // sweep k = it+1 reads V[(k-1)&1] ...
         double *const Vw = (it & 1) ? gV0 : gV1;  // ... and writes V[k&1]
+#endif
         double pri, dua;
         double w0, w1, w2, w3;  // vnew of the last four forward steps (w3 = last), consumed by the backward sweep
 
@@ -142,9 +166,24 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             pri = is_x ? fabs(x0v - snew) : 0.0;
             dua = is_x ? fabs(vk0 - snew) : 0.0;
             sG[on ? 64 + lane : ldummy] = s - snew;
+#if TINY_B_INPLACE
+            if (check) gV1[on ? lane : vdummy] = vk0;
+#endif
             Vw[on ? lane : vdummy] = snew;
         }
         {
+#if TINY_B_INPLACE
+            // Stale copy (the reference's v/z after a converged solve = the PREVIOUS iterate): needed only
+            // if this very sweep ends converged, i.e. only while some instance of the wave still has all
+            // its rows' running residual maxima below the tolerances (maxima only grow, so the test is exact).
+            // In iterations that cannot converge the copy stops after the first group of four steps. The
+            // decision is taken once per group of four steps and selects one of two copies of the group
+            // body, so the common no-copy path carries no per-step overhead.
+            const long sdelta = gV1 - gV0;  // wave-uniform distance (in doubles) from V to its stale copy
+            bool may = check;
+#else
+            constexpr bool may = false;
+#endif
             const double *pg = sG + (1 + koff) * 64 + lane;
             const double *pt = t_lo + (1 + koff) * W + r;
             const double *pd = sD + dIdx;
@@ -154,7 +193,7 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             const int inc = st ? 64 : 0;
             double xcur = x0v;
             FwdLds A, B;
-            auto fstep = [&](const FwdLds &cur, FwdLds &nxt, double &vslot, double &wslot) {
+            auto fstep = [&](auto stale, const FwdLds &cur, FwdLds &nxt, double &vslot, double &wslot) {
                 const double w = is_x ? xcur : cur.dv;
                 pg += 64;
                 pt += W;
@@ -168,21 +207,47 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
                 project_element(out, cur.g, cur.lo, cur.hi, vold, gnew, wslot, pri, dua);
                 ps[0] = gnew;
                 *pvw = wslot;
+#if TINY_B_INPLACE
+                if constexpr (decltype(stale)::value) pvw[sdelta] = vold;
+#endif
                 ps += inc;
                 pvw += inc;
                 xcur = out;
             };
+            constexpr std::true_type with_copy{};
+            constexpr std::false_type no_copy{};
             // Head: the R4 odd steps, on the ring slots that make the sweep end on slot 3.
             A.g = pg[0]; A.lo = pt[0]; A.hi = pt[TOFF]; A.dv = pd[0];
             if constexpr (R4 & 1) B = A;  // an odd head starts with B as the current operand set
-            if constexpr (R4 == 3) { fstep(B, A, v1, w1); fstep(A, B, v2, w2); fstep(B, A, v3, w3); }
-            if constexpr (R4 == 2) { fstep(A, B, v2, w2); fstep(B, A, v3, w3); }
-            if constexpr (R4 == 1) { fstep(B, A, v3, w3); }
-            for (int i = R4; i < nsteps; i += 4) {
-                fstep(A, B, v0, w0);
-                fstep(B, A, v1, w1);
-                fstep(A, B, v2, w2);
-                fstep(B, A, v3, w3);
+            if (may) {
+                if constexpr (R4 == 3) { fstep(with_copy, B, A, v1, w1); fstep(with_copy, A, B, v2, w2); fstep(with_copy, B, A, v3, w3); }
+                if constexpr (R4 == 2) { fstep(with_copy, A, B, v2, w2); fstep(with_copy, B, A, v3, w3); }
+                if constexpr (R4 == 1) { fstep(with_copy, B, A, v3, w3); }
+            } else {
+                if constexpr (R4 == 3) { fstep(no_copy, B, A, v1, w1); fstep(no_copy, A, B, v2, w2); fstep(no_copy, B, A, v3, w3); }
+                if constexpr (R4 == 2) { fstep(no_copy, A, B, v2, w2); fstep(no_copy, B, A, v3, w3); }
+                if constexpr (R4 == 1) { fstep(no_copy, B, A, v3, w3); }
+            }
+            // Two loops rather than one loop with a branch in it: a branch inside the body makes hipcc drain
+            // every outstanding memory operation (vmcnt(0)) at the loop latch, which exposes the full L2
+            // latency of the prefetch ring once per group. Loop 1 copies and re-tests; loop 2 finishes.
+            int i = R4;
+#if TINY_B_INPLACE
+            while (may && i < nsteps) {
+                fstep(with_copy, A, B, v0, w0);
+                fstep(with_copy, B, A, v1, w1);
+                fstep(with_copy, A, B, v2, w2);
+                fstep(with_copy, B, A, v3, w3);
+                i += 4;
+                const bool bad = st && !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                may = wave_may_converge<W>(__ballot(bad), __ballot(st));
+            }
+#endif
+            for (; i < nsteps; i += 4) {
+                fstep(no_copy, A, B, v0, w0);
+                fstep(no_copy, B, A, v1, w1);
+                fstep(no_copy, A, B, v2, w2);
+                fstep(no_copy, B, A, v3, w3);
             }
         }
         if (active) it_done = it + 1;  // admm.cpp:143
@@ -265,10 +330,17 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
     // V[(k-1)&1]. The canonical buffer (0) must end up holding the reference's workspace v/z:
     //   not converged (max_iter hit): v = vnew (admm.cpp:196-197)  -> copy if vnew sits in buffer 1
     //   converged: the solve returned before v <- vnew              -> copy if the previous iterate sits in buffer 1
+    // (In-place variant: vnew is always in buffer 0; a converged instance's previous iterate is the stale
+    //  copy in buffer 1, which then becomes the canonical v/z.)
     if (p.max_iter > 0 && inst_ok && it_done > 0) {
+#if TINY_B_INPLACE
+        const double *last = gV0;
+        const bool copy_1_to_0 = (status == 1);
+#else
         const bool last_is_1 = (it_done & 1) != 0;
         const double *last = last_is_1 ? gV1 : gV0;
         const bool copy_1_to_0 = (status == 1) ? !last_is_1 : last_is_1;
+#endif
         for (int kn = 0; kn < N; ++kn) {
             const int e = kn * 64 + lane;
             gG[e] = sG[e + 64];
