@@ -149,7 +149,10 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under torchrun (RANK / MASTER_ADDR set) the RCCL group is created even for a single rank, so that the
+    # collective path can be exercised on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 1 bench.py`.
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     prob = P.quadrotor(args.horizon)
@@ -171,7 +174,7 @@ def main() -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,7 +187,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_avg = float(t[0]), float(t[1])
 
@@ -257,7 +260,7 @@ def main() -> int:
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
     solver.reset()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -39,7 +39,7 @@ def allreduce_summary(summary: dict, device=None) -> dict:
 
     sums = torch.tensor(summary["sums"], dtype=torch.float64, device=device)
     maxs = torch.tensor(summary["maxs"], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
     sums, maxs = sums.cpu().numpy(), maxs.cpu().numpy()
