@@ -184,6 +184,14 @@ int tinympc_synchronize(tinympc_solver *s);
  * the handle's stream immediately around the launch. */
 int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
 
+/* One closed-loop control tick for every instance of the handle (the loop of
+ * examples/cartpole_example_mpc.m:36-44 / rocket_landing_constraints.m:86-121 as ONE call): upload the
+ * measured states x0s (nx x batch), run the warm-started solve, download the first control of each
+ * instance into u0_out (nu x batch). One stream submission (H2D, kernel, D2H through pinned staging
+ * buffers) and one synchronisation instead of three synchronous verbs; results are identical to
+ * tinympc_set_x0_batch + tinympc_solve + tinympc_get_first_controls_batch. */
+int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out);
+
 /* Launch geometry of the solve kernel, for reports: lanes per instance, instances per wavefront,
  * workgroups in the grid, dynamic LDS bytes per workgroup, and whether the per-knot bound/reference
  * tables are LDS-resident. Any pointer may be NULL. */

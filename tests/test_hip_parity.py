@@ -23,7 +23,7 @@ SINGLE = ["cartpole_unconstrained", "cartpole_box_tol", "cartpole_box_200", "qua
 @pytest.fixture(autouse=True, params=["A", "B"])
 def kernel_layout(request, monkeypatch):
     """Every test runs against both solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip)
-    and layout B (V as an HBM ping-pong pair, 4-wave workgroups, tinympc_solve_b.hip). The layout is
+    and layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip). The layout is
     chosen at setup time; where B does not apply (W > 16 or N < 8) the library falls back to A."""
     monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
     return request.param
@@ -345,3 +345,27 @@ def test_unimplemented_paths_fail_loudly(pkg):
     with pytest.raises(pkg.TinyMPCError):
         s2.update_settings(adaptive_rho=True)
     s2.reset()
+
+
+@pytest.mark.parametrize("batch", [1, 6])
+def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
+    """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a
+    warm-started closed loop (examples/cartpole_example_mpc.m:36-44 without the noise)."""
+    P = pkg.problems
+    prob = P.quadrotor(20)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
+    a = make_solver(pkg, prob, settings, batch=batch)
+    b = make_solver(pkg, prob, settings, batch=batch)
+    x = np.repeat(prob.x0[:, None], batch, axis=1) * np.linspace(0.4, 1.0, batch)[None, :]
+    xa, xb = x.copy(), x.copy()
+    for _ in range(6):
+        ua = a.mpc_step(xa)
+        b.set_x0_batch(xb)
+        b.solve()
+        ub = b.get_first_controls_batch()
+        np.testing.assert_array_equal(ua, ub)
+        np.testing.assert_array_equal(a.get_stats_batch()["iter"], b.get_stats_batch()["iter"])
+        xa = prob.A @ xa + prob.B @ ua
+        xb = prob.A @ xb + prob.B @ ub
+    a.reset()
+    b.reset()

@@ -85,6 +85,7 @@ struct tinympc_solver {
     std::vector<int> Acx, qcx, Acu, qcu;
     std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
     double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
+    double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch
     bool fam_dirty = true;
     size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
     bool tables_in_lds_a = false;
@@ -278,6 +279,8 @@ void destroy(tinympc_solver *s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
+    if (s->h_x0) (void)hipHostFree(s->h_x0);
+    if (s->h_u0) (void)hipHostFree(s->h_u0);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -534,6 +537,26 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     if (kernel_ms) *kernel_ms = ms;
+    return TINYMPC_OK;
+}
+
+int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0s || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "mpc_step: x0s and u0_out are required");
+    if ((rc = bind_device(s))) return rc;
+    const size_t nx0 = (size_t)s->batch * s->nx, nu0 = (size_t)s->batch * s->nu;
+    if (!s->h_x0) {  // pinned staging, so that the small copies are true async DMA and need no extra sync
+        HIP_TRY(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx0, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
+    }
+    std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
+    HIP_TRY(hipMemcpyAsync(s->dx0, s->h_x0, sizeof(double) * nx0, hipMemcpyHostToDevice, s->stream));
+    if ((rc = launch(s, false))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(s->h_u0, sizeof(double) * s->nu, s->dsolu, sizeof(double) * s->U(), sizeof(double) * s->nu,
+                             s->batch, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::memcpy(u0_out, s->h_u0, sizeof(double) * nu0);
     return TINYMPC_OK;
 }
 

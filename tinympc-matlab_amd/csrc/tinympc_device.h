@@ -108,6 +108,19 @@ size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
 constexpr int WAVES_PER_GROUP_B = 4;
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+// Raise a kernel's dynamic-LDS limit to `bytes` unless a previous launch on this device already did
+// (the attribute is sticky per function and device; re-setting it costs ~5 us per launch, which matters
+// for the per-tick latency of closed-loop callers). `cache` is one static array per kernel instantiation.
+inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cache)[16]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16 && cache[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 16) cache[dev] = bytes;
+    return e;
+}
+
 // Geometry helpers shared with the host layer.
 bool choose_geometry(int nx, int nu, int *W, int *KT);
 size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds);

@@ -367,8 +367,8 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
 template <int W, int KT, int R4>
 static hipError_t launch_b_r(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
     const int wgs = (p.groups + WPG - 1) / WPG;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_admm_solve_b<W, KT, R4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static size_t lds_set[16] = {0};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_b<W, KT, R4>), lds_bytes, lds_set);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_admm_solve_b<W, KT, R4>), dim3(wgs), dim3(64 * WPG), lds_bytes, stream, p);
     return hipGetLastError();

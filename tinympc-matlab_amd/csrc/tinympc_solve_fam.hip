@@ -292,15 +292,14 @@ template <int W, int KT>
 static hipError_t launch_fam_t(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
     constexpr int IPW = 64 / W;
     const int groups = (p.batch + IPW - 1) / IPW;
+    static size_t lds_set_t[16] = {0}, lds_set_f[16] = {0};
     hipError_t e;
     if (p.tables_in_lds) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_admm_solve_fam<W, KT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_fam<W, KT, true>), lds_bytes, lds_set_t);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_admm_solve_fam<W, KT, true>), dim3(groups), dim3(64), lds_bytes, stream, p);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_admm_solve_fam<W, KT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_fam<W, KT, false>), lds_bytes, lds_set_f);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_admm_solve_fam<W, KT, false>), dim3(groups), dim3(64), lds_bytes, stream, p);
     }

@@ -269,6 +269,16 @@ class TinyMPC:
         assert a.shape[0] == self.nx
         _lib.check(self._L.tinympc_set_x0_batch(self._h, _p(a), first, a.shape[1]))
 
+    def mpc_step(self, x0s) -> np.ndarray:
+        """One closed-loop tick for every instance: measured states in (nx x batch, or an nx-vector for
+        batch 1), warm-started solve, first controls out (nu x batch). One call, one synchronisation."""
+        self._check_setup()
+        a = _f(np.asarray(x0s, dtype=np.float64).reshape(self.nx, -1))
+        assert a.shape == (self.nx, self.batch), f"x0s must be {self.nx} x {self.batch}"
+        u0 = np.zeros((self.nu, self.batch), order="F")
+        _lib.check(self._L.tinympc_mpc_step_batch(self._h, _p(a), _p(u0)))
+        return u0
+
     def reset_workspace(self):
         self._check_setup()
         _lib.check(self._L.tinympc_reset_workspace(self._h))

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Dev tool: wall-clock latency of one closed-loop MPC tick through the C ABI (set_x0 -> solve -> u0),
+single instance and small batches, warm-started, realistic tolerances."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package(); P = pkg.problems
+for name, prob in (("cartpole N=10", P.cartpole(10, True)), ("quadrotor N=20", P.quadrotor(20)), ("quadrotor N=50", P.quadrotor(50))):
+    for B in (1, 64, 1024):
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        x = np.repeat(prob.x0[:, None], B, axis=1) * np.linspace(0.5, 1.0, B)[None, :]
+        t_set = t_solve = t_get = 0.0; iters = 0; n = 60
+        for k in range(n + 10):
+            t0 = time.perf_counter(); s.set_x0_batch(x); t1 = time.perf_counter(); s.solve(); t2 = time.perf_counter()
+            u0 = s.get_first_controls_batch(); t3 = time.perf_counter()
+            if k >= 10:
+                t_set += t1 - t0; t_solve += t2 - t1; t_get += t3 - t2; iters += int(s.get_stats_batch()["iter"].max())
+            x = prob.A @ x + prob.B @ u0
+        t_fused = 0.0
+        for k in range(n + 10):
+            t0 = time.perf_counter(); u0 = s.mpc_step(x); t1 = time.perf_counter()
+            if k >= 10: t_fused += t1 - t0
+            x = prob.A @ x + prob.B @ u0
+        print(f"{name:16s} B={B:5d}: fused mpc_step {1e6*t_fused/n:7.1f} us | 3-verb tick {1e6*(t_set+t_solve+t_get)/n:8.1f} us  (set_x0 {1e6*t_set/n:6.1f}, solve {1e6*t_solve/n:7.1f}, get_u0 {1e6*t_get/n:6.1f}; max iters/tick {iters/n:.1f})")
+        s.reset()
