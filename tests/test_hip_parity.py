@@ -424,3 +424,24 @@ def test_randomized_problems(pkg, seed):
         assert rel_err(sol2["controls"][:, :, b], o.solution()[1], eps=1e-12) < TOL_RANDOM
     s.reset()
     s2.reset()
+
+
+@pytest.mark.parametrize("N", [159, 400])
+def test_long_horizon_state_in_global_memory(pkg, N):
+    """Horizons whose ADMM state exceeds the 160 KB of LDS (quadrotor: N > 158) run the layout-A kernel on an
+    HBM working copy; results and iteration counts are unchanged."""
+    P = pkg.problems
+    prob = P.quadrotor(N)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=40)
+    x0s = P.quadrotor_batch_x0(5)
+    s = make_solver(pkg, prob, settings, batch=5)
+    assert s.launch_info()["lds_bytes"] == 0 and s.launch_info()["layout"] == "A"
+    s.set_x0_batch(x0s)
+    s.solve()
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, oit, ost, _ = orc.solve_batch(x0s)
+    st, sol = s.get_stats_batch(), s.get_solution_batch()
+    np.testing.assert_array_equal(st["iter"], oit)
+    np.testing.assert_array_equal(st["status"], ost)
+    assert rel_err(sol["states"], ox) < TOL and rel_err(sol["controls"], ou) < TOL
+    s.reset()

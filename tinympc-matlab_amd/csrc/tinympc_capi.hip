@@ -86,6 +86,8 @@ struct tinympc_solver {
     std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
     double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
     double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch
+    bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
+    double *dscratch_state = nullptr;
     bool fam_dirty = true;
     size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
     bool tables_in_lds_a = false;
@@ -258,6 +260,8 @@ int launch(tinympc_solver *s, bool timed) {
     p.istats = s->distats; p.dstats = s->ddstats;
     p.tables_in_lds = s->tables_in_lds ? 1 : 0;
     p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
+    p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
+    p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (fam) {
         // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
@@ -355,14 +359,13 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     const size_t with_tables = solve_lds_bytes(nx, nu, N, W, true);
     const size_t without = solve_lds_bytes(nx, nu, N, W, false);
     constexpr size_t kLdsMax = 160 * 1024;
-    if (without > kLdsMax) {
-        destroy(s);
-        return fail(TINYMPC_ERR_UNSUPPORTED, "horizon too long for the LDS-resident solve kernel: needs %zu bytes of LDS (max %zu)", without, kLdsMax);
-    }
+    // Horizons whose state does not fit a CU's LDS run the same kernels on an HBM working copy (GMEM variant).
+    s->state_in_global = without > kLdsMax;
     // Two workgroups per CU need <= 80 KB each; prefer LDS tables whenever they do not cost a workgroup slot.
-    const size_t slots_without = kLdsMax / without, slots_with = kLdsMax / with_tables;
-    s->tables_in_lds = (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
-    s->lds_bytes = s->tables_in_lds ? with_tables : without;
+    const size_t slots_without = s->state_in_global ? 0 : kLdsMax / without;
+    const size_t slots_with = kLdsMax / with_tables;
+    s->tables_in_lds = !s->state_in_global && (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
+    s->lds_bytes = s->state_in_global ? 0 : (s->tables_in_lds ? with_tables : without);
     s->lds_bytes_a = s->lds_bytes;
     s->tables_in_lds_a = s->tables_in_lds;
     // Layout A keeps all ADMM state in LDS (2 wavefronts per CU at quadrotor size); layout B keeps V as an
@@ -397,6 +400,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dops, ops_doubles(W, KT))); TRY(dalloc(s, &s->dtables, tables_doubles(W, N)));
     TRY(dalloc(s, &s->dx0, (size_t)batch * nx));
     TRY(dalloc(s, &s->dG, s->state_doubles())); TRY(dalloc(s, &s->dV, s->v_doubles())); TRY(dalloc(s, &s->dV2, s->v_doubles())); TRY(dalloc(s, &s->dD, s->d_doubles()));
+    if (s->state_in_global) TRY(dalloc(s, &s->dscratch_state, (size_t)s->groups * state_scratch_doubles(nu, N, W)));
     TRY(dalloc(s, &s->dsolx, X * batch)); TRY(dalloc(s, &s->dsolu, U * batch));
     TRY(dalloc(s, &s->distats, (size_t)batch * 2)); TRY(dalloc(s, &s->ddstats, (size_t)batch * 4));
 

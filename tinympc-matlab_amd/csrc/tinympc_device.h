@@ -75,6 +75,10 @@ struct SolveParams {
     int *istats;       // [batch][2]  iter, status
     double *dstats;    // [batch][4]  pri_x, dua_x, pri_u, dua_u
     int tables_in_lds;
+    // Long horizons whose ADMM state does not fit the 160 KB of LDS: the layout-A kernels then keep their
+    // working copy of (G, V, D) in this per-group HBM scratch instead (same code path, `GMEM` variant).
+    double *scratch;          // [groups][scratch_stride] or NULL
+    size_t scratch_stride;    // doubles per group: state_scratch_doubles()
     // Cone / linear-inequality slack families (k_admm_solve_fam only; PARITY UNPINNED upstream semantics)
     const double *fam;  // per-lane family description, see fam_doubles()
     double *GC, *GL;    // [groups][v_rows(N)][64]  duals gc|yc and gl|yl, persistent across solves
@@ -119,6 +123,11 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cach
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && dev >= 0 && dev < 16) cache[dev] = bytes;
     return e;
+}
+
+// Doubles of working state per group in layout A (G and V with N+2 rows, D with 64 dummy slots).
+__host__ __device__ inline size_t state_scratch_doubles(int nu, int N, int W) {
+    return (size_t)2 * (N + 2) * 64 + ((((size_t)(N - 1) * (64 / W) * nu + 64) + 1) & ~(size_t)1);
 }
 
 // Geometry helpers shared with the host layer.

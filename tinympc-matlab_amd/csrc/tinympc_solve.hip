@@ -56,7 +56,9 @@ bool choose_geometry(int nx, int nu, int *W, int *KT) {
 struct FwdOperands { double g, vold, lo, hi, dv; };
 struct BwdOperands { double bg, bv, blr; };
 
-template <int W, int KT, bool TLDS>
+// GMEM: the working copy of the state lives in p.scratch (HBM) instead of LDS -- the fallback for horizons
+// that do not fit 160 KB of LDS. Same code, same results; the row-local operands then come from L2.
+template <int W, int KT, bool TLDS, bool GMEM = false>
 __global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int IPW = 64 / W;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
     const int ldummy = (N + 1) * 64 + lane;    // this lane's dummy slot (LDS row N+1)
     const int gdummy = N * 64 + lane;          // same in the HBM layout (row N)
 
-    double *sG = smem;
+    double *sG = GMEM ? (p.scratch + (size_t)blockIdx.x * p.scratch_stride) : smem;
     double *sV = sG + VOFF;
     double *sD = sV + VOFF;
     double *sT = sD + ((dsize + 64 + 1) & ~1);
@@ -261,7 +263,9 @@ static hipError_t launch_solve_t(const SolveParams &p, size_t lds_bytes, hipStre
     const int groups = (p.batch + IPW - 1) / IPW;
     static size_t lds_set_t[16] = {0}, lds_set_f[16] = {0};
     hipError_t e;
-    if (p.tables_in_lds) {
+    if (p.scratch) {  // state in HBM scratch, tables from global memory, no dynamic LDS at all
+        hipLaunchKernelGGL((k_admm_solve<W, KT, false, true>), dim3(groups), dim3(64), 0, stream, p);
+    } else if (p.tables_in_lds) {
         e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve<W, KT, true>), lds_bytes, lds_set_t);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_admm_solve<W, KT, true>), dim3(groups), dim3(64), lds_bytes, stream, p);

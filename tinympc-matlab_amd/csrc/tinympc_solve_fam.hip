@@ -26,7 +26,9 @@ namespace tinympc {
 struct FamFwd { double g, vold, lo, hi, dv, gc, gl; };
 struct FamBwd { double bg, bv, blr, lx; };
 
-template <int W, int KT, bool TLDS>
+// GMEM: the working copy of the state lives in p.scratch (HBM) instead of LDS -- the fallback for horizons
+// that do not fit 160 KB of LDS. Same code, same results; the row-local operands then come from L2.
+template <int W, int KT, bool TLDS, bool GMEM = false>
 __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int IPW = 64 / W;
@@ -46,7 +48,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     const int ldummy = (N + 1) * 64 + lane;
     const int gdummy = N * 64 + lane;
 
-    double *sG = smem;
+    double *sG = GMEM ? (p.scratch + (size_t)blockIdx.x * p.scratch_stride) : smem;
     double *sV = sG + VOFF;
     double *sD = sV + VOFF;
     double *sT = sD + ((dsize + 64 + 1) & ~1);
@@ -294,7 +296,9 @@ static hipError_t launch_fam_t(const SolveParams &p, size_t lds_bytes, hipStream
     const int groups = (p.batch + IPW - 1) / IPW;
     static size_t lds_set_t[16] = {0}, lds_set_f[16] = {0};
     hipError_t e;
-    if (p.tables_in_lds) {
+    if (p.scratch) {  // state in HBM scratch, tables from global memory, no dynamic LDS at all
+        hipLaunchKernelGGL((k_admm_solve_fam<W, KT, false, true>), dim3(groups), dim3(64), 0, stream, p);
+    } else if (p.tables_in_lds) {
         e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_fam<W, KT, true>), lds_bytes, lds_set_t);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_admm_solve_fam<W, KT, true>), dim3(groups), dim3(64), lds_bytes, stream, p);
