@@ -139,6 +139,28 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
 int tinympc_print_problem_data(tinympc_solver *s);
 
 /* ---------------------------------------------------------------------------------------------
+ * Methods the reference implements in MATLAB inside the class (no MEX verb); here they run on the
+ * device and the .m class / Python mirror forward to them. Any output pointer may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+
+/* TinyMPC.compute_cache_terms (src/TinyMPC.m:194-221): Riccati recursion on the FULL user Q, R with rho
+ * added once, P0 = Q, gain solve regularised by 1e-8, at most 5000 steps, stop at ||K - Kprev||_2 < 1e-10.
+ * Outputs Kinf (nu x nx), Pinf (nx x nx), Quu_inv (nu x nu), AmBKt (nx x nx), column-major. */
+int tinympc_compute_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
+                                double *AmBKt, int *riccati_iters, int verbose);
+
+/* TinyMPC.solve_lqr (src/TinyMPC.m:336-366): stabilising DARE solution for Q + rho_val*I, R + rho_val*I
+ * (MATLAB calls idare; here the recursion runs until K is stationary to rounding). C1 = inv(R_rho + B'PB),
+ * C2 = (A - BK)'. */
+int tinympc_solve_lqr(tinympc_solver *s, double rho_val, double *K, double *P, double *C1, double *C2,
+                      int *riccati_iters);
+
+/* TinyMPC.compute_sensitivity_autograd (src/TinyMPC.m:223-241): forward differences of solve_lqr in rho
+ * with h = 1e-6. dK (nu x nx), dP (nx x nx), dC1 (nu x nu), dC2 (nx x nx). */
+int tinympc_compute_sensitivity(tinympc_solver *s, double *dK, double *dP, double *dC1, double *dC2,
+                                int verbose);
+
+/* ---------------------------------------------------------------------------------------------
  * Extensions (not in the reference): cache read-back, batched mode, timing.
  * ------------------------------------------------------------------------------------------- */
 

@@ -141,3 +141,24 @@ def test_one_solve_script_through_the_mex_verbs(mex, pkg):
     assert err is None and out[0][0, 0] != 0  # status != 0 -> TinyMPC.m raises TinyMPC:CodegenFailed
     assert mex.call("reset", 0.0)[0] is None
     assert mex.call("solve", 0.0)[0] == "TinyMPC:NotInitialized"
+
+
+@pytest.mark.gpu
+def test_cache_script_through_the_mex_verbs(mex, pkg):
+    """tests/test_cache.m of the reference (setup with N = 2, then compute_cache_terms), plus the two other
+    class-side recursions, as the MEX calls this build's TinyMPC.m makes for them."""
+    import matlab_class_oracle as M
+    p = pkg.problems.cartpole(2, False)
+    err, out = mex.call("setup", p.A, p.B, np.zeros((4, 1)), p.Q, p.R, 1.0, 4.0, 1.0, 2.0, 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] == 0
+    err, (K, P_, Qi, Am) = mex.call("compute_cache_terms", 0.0, nlhs=4)
+    assert err is None and K.shape == (1, 4) and P_.shape == (4, 4) and Qi.shape == (1, 1) and Am.shape == (4, 4)
+    Ko, Po, Qio, Amo, _ = M.compute_cache_terms(p.A, p.B, p.Q, p.R, 1.0)
+    assert rel_err(K, Ko) < 1e-8 and rel_err(P_, Po) < 1e-8 and rel_err(Qi, Qio) < 1e-8 and rel_err(Am, Amo) < 1e-8
+    err, (K2, P2, C1, C2) = mex.call("solve_lqr", 2.5, 0.0, nlhs=4)
+    assert err is None and rel_err(P2, M.solve_lqr(p.A, p.B, p.Q, p.R, 2.5)[1]) < 1e-9
+    err, outs = mex.call("compute_sensitivity", 0.0, nlhs=4)
+    assert err is None and [o.shape for o in outs] == [(1, 4), (4, 4), (1, 1), (4, 4)]
+    assert mex.call("compute_cache_terms")[0] == "TinyMPC:InvalidInput"
+    assert mex.call("reset", 0.0)[0] is None
+    assert mex.call("compute_cache_terms", 0.0, nlhs=4)[0] == "TinyMPC:NotInitialized"

@@ -59,6 +59,9 @@ SIGNATURES = {
     "tinympc_print_problem_data": (C.c_int, [Handle]),
     "tinympc_get_cache": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "tinympc_get_residuals": (C.c_int, [Handle, c_double_p]),
+    "tinympc_compute_cache_terms": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p, C.c_int]),
+    "tinympc_solve_lqr": (C.c_int, [Handle, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "tinympc_compute_sensitivity": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     "tinympc_setup_batch": (C.c_int, [C.POINTER(Handle), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                       C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tinympc_set_x0_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),

@@ -67,6 +67,9 @@ struct tinympc_solver {
     double *dKinf = nullptr, *dPinf = nullptr, *dQuu = nullptr, *dAmBKt = nullptr, *dAPf = nullptr, *dBPf = nullptr;
     double *dscratch = nullptr;
     int *dinfo = nullptr;
+    // the .m class's own Riccati helpers (compute_cache_terms / solve_lqr / compute_sensitivity_autograd)
+    double *dQfull = nullptr, *dRfull = nullptr, *dlqr_scratch = nullptr, *dlqr_out = nullptr;  // dlqr_out: 3 x cache_doubles()
+    size_t cache_doubles() const { return (size_t)nu * nx + (size_t)2 * nx * nx + (size_t)nu * nu; }  // K | P | C1 | C2
     // user-layout bounds / refs
     double *dxmin = nullptr, *dxmax = nullptr, *dumin = nullptr, *dumax = nullptr, *dXref = nullptr, *dUref = nullptr;
     // derived
@@ -395,6 +398,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dQuu, (size_t)nu * nu)); TRY(dalloc(s, &s->dAmBKt, (size_t)nx * nx));
     TRY(dalloc(s, &s->dAPf, nx)); TRY(dalloc(s, &s->dBPf, nu)); TRY(dalloc(s, &s->dinfo, 4));
     TRY(dalloc(s, &s->dscratch, precompute_scratch_doubles(nx, nu) + 8));
+    TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
+    TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));
     TRY(dalloc(s, &s->dops, ops_doubles(W, KT))); TRY(dalloc(s, &s->dtables, tables_doubles(W, N)));
@@ -411,6 +416,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(upload(s, s->dA, A, (size_t)nx * nx)); TRY(upload(s, s->dB, B, (size_t)nx * nu));
     TRY(upload(s, s->dfdyn, fdyn ? fdyn : fz.data(), nx));
     TRY(upload(s, s->dQd, qd.data(), nx)); TRY(upload(s, s->dRd, rd.data(), nu));
+    TRY(upload(s, s->dQfull, Q, (size_t)nx * nx)); TRY(upload(s, s->dRfull, R, (size_t)nu * nu));
     TRY(fill_host_upload(s, s->dxmin, X, -kBoundInf)); TRY(fill_host_upload(s, s->dxmax, X, kBoundInf));
     TRY(fill_host_upload(s, s->dumin, U, -kBoundInf)); TRY(fill_host_upload(s, s->dumax, U, kBoundInf));
     // Everything tiny_setup zeroes (tiny_api.cpp:41-44, 73-88, 100-111)
@@ -785,6 +791,76 @@ int tinympc_get_cache(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu
     if (Quu_inv && (rc = download(s, Quu_inv, s->dQuu, sizeof(double) * s->nu * s->nu))) return rc;
     if (AmBKt && (rc = download(s, AmBKt, s->dAmBKt, sizeof(double) * s->nx * s->nx))) return rc;
     if (riccati_iters && (rc = download(s, riccati_iters, s->dinfo, sizeof(int)))) return rc;
+    return TINYMPC_OK;
+}
+
+namespace {
+// One Riccati recursion of the .m class on the device; results land in slot `slot` of dlqr_out.
+int run_lqr(tinympc_solver *s, int slot, double rho, double reg, double tol, int norm_kind, int max_iter, int min_iter, int p0_augmented) {
+    LqrParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.rho = rho; p.reg = reg; p.tol = tol; p.norm_kind = norm_kind;
+    p.max_iter = max_iter; p.min_iter = min_iter; p.p0_augmented = p0_augmented;
+    p.A = s->dA; p.B = s->dB; p.Q = s->dQfull; p.R = s->dRfull;
+    double *o = s->dlqr_out + (size_t)slot * s->cache_doubles();
+    p.K = o; p.P = p.K + (size_t)s->nu * s->nx; p.C1 = p.P + (size_t)s->nx * s->nx; p.C2 = p.C1 + (size_t)s->nu * s->nu;
+    p.info = s->dinfo + 1 + slot; p.scratch = s->dlqr_scratch;
+    p.use_lds = lqr_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
+    HIP_TRY(launch_lqr(p, s->stream));
+    return TINYMPC_OK;
+}
+
+int download_cache_slot(tinympc_solver *s, int slot, double *K, double *P, double *C1, double *C2) {
+    const double *o = s->dlqr_out + (size_t)slot * s->cache_doubles();
+    const size_t nK = (size_t)s->nu * s->nx, nP = (size_t)s->nx * s->nx, nC1 = (size_t)s->nu * s->nu;
+    int rc;
+    if (K && (rc = download(s, K, o, sizeof(double) * nK))) return rc;
+    if (P && (rc = download(s, P, o + nK, sizeof(double) * nP))) return rc;
+    if (C1 && (rc = download(s, C1, o + nK + nP, sizeof(double) * nC1))) return rc;
+    if (C2 && (rc = download(s, C2, o + nK + nP + nC1, sizeof(double) * nP))) return rc;
+    return TINYMPC_OK;
+}
+}  // namespace
+
+// TinyMPC.m:194-221: P0 = Q, up to 5000 steps, 1e-8 regulariser in the gain solve, stop at norm(K-Kprev) < 1e-10.
+int tinympc_compute_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt, int *iters, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = run_lqr(s, 0, s->rho, 1e-8, 1e-10, 2, 5000, 1, 0))) return rc;
+    if ((rc = download_cache_slot(s, 0, Kinf, Pinf, Quu_inv, AmBKt))) return rc;
+    int it = 0;
+    if ((rc = download(s, &it, s->dinfo + 1, sizeof(int)))) return rc;
+    if (iters) *iters = it;
+    if (verbose) printf("Cache terms computed on the device after %d Riccati steps\n", it);
+    return TINYMPC_OK;
+}
+
+// TinyMPC.m:336-366: the stabilising solution of the DARE for Q + rho I, R + rho I (MATLAB: idare; here the same
+// fixed-point recursion as the class's fallback branch, without regulariser, run until K stops changing).
+int tinympc_solve_lqr(tinympc_solver *s, double rho_val, double *K, double *P, double *C1, double *C2, int *iters) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = run_lqr(s, 0, rho_val, 0.0, 1e-15, 0, 200000, 2, 1))) return rc;
+    if ((rc = download_cache_slot(s, 0, K, P, C1, C2))) return rc;
+    if (iters && (rc = download(s, iters, s->dinfo + 1, sizeof(int)))) return rc;
+    return TINYMPC_OK;
+}
+
+// TinyMPC.m:223-241: forward differences of solve_lqr in rho with h = 1e-6.
+int tinympc_compute_sensitivity(tinympc_solver *s, double *dK, double *dP, double *dC1, double *dC2, int verbose) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    const double h = 1e-6;
+    if ((rc = run_lqr(s, 0, s->rho, 0.0, 1e-15, 0, 200000, 2, 1))) return rc;
+    if ((rc = run_lqr(s, 1, s->rho + h, 0.0, 1e-15, 0, 200000, 2, 1))) return rc;
+    FiniteDiffParams f{};
+    f.count = (int)s->cache_doubles(); f.h = h;
+    f.lo = s->dlqr_out; f.hi = s->dlqr_out + s->cache_doubles(); f.out = s->dlqr_out + 2 * s->cache_doubles();
+    HIP_TRY(launch_finite_diff(f, s->stream));
+    if ((rc = download_cache_slot(s, 2, dK, dP, dC1, dC2))) return rc;
+    if (verbose) printf("Sensitivity matrices computed on the device (forward differences, h = %g)\n", h);
     return TINYMPC_OK;
 }
 

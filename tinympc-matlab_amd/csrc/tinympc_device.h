@@ -43,6 +43,32 @@ struct PrecomputeParams {
     int use_lds;
 };
 
+// The .m class's own Riccati recursions (TinyMPC.m:194-221 compute_cache_terms, :336-366 solve_lqr): full Q
+// and R, rho added ONCE, an optional regulariser inside the gain solve only, a matrix-norm stopping test.
+struct LqrParams {
+    int nx, nu;
+    double rho;         // Q_rho = Q + rho*I, R_rho = R + rho*I                         (TinyMPC.m:199-200, 341-342)
+    double reg;         // K = (R_rho + B'PB + reg*I) \ (B'PA)                          (:209, :354)
+    double tol;         // stop when the norm below of K - Kprev is < tol               (:211, :356)
+    int norm_kind;      // 2: spectral norm (MATLAB norm()); 0: max-abs relative to max(1, max|K|)
+    int max_iter;       // 5000 in the .m class
+    int min_iter;       // first iteration at which the test may stop the loop (solve_lqr: `iter > 1`)
+    int p0_augmented;   // initial P: 0 = Q (:204), 1 = Q_rho (:350)
+    const double *A, *B, *Q, *R;
+    double *K, *P, *C1, *C2;  // Kinf, Pinf, Quu_inv = inv(R_rho + B'PB), AmBKt = (A - B K)'
+    int *info;                // info[0] = iterations taken
+    double *scratch;
+    int use_lds;
+};
+
+// out[i] = (hi[i] - lo[i]) / h over the four cache matrices packed back to back (TinyMPC.m:237-240)
+struct FiniteDiffParams {
+    int count;
+    double h;
+    const double *lo, *hi;
+    double *out;
+};
+
 struct OperatorParams {
     int nx, nu, W, KT;
     const double *A, *B, *fdyn, *Qd, *Rd, *Kinf, *Quu_inv, *AmBKt, *APf, *BPf;
@@ -100,6 +126,9 @@ __host__ __device__ inline size_t fam_doubles(int W, int KT) { return (size_t)4 
 
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
+hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
+hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
+size_t lqr_scratch_doubles(int nx, int nu);
 hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream);
 hipError_t launch_build_tables(const TableParams &p, hipStream_t stream);
 // Layout A: one wavefront per workgroup, all ADMM state in LDS (lowest latency, 2 waves per CU).

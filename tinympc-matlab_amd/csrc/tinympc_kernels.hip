@@ -201,6 +201,204 @@ hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream) {
 }
 
 // =====================================================================================
+// The .m class's Riccati recursions (compute_cache_terms / solve_lqr), same workgroup scheme
+// =====================================================================================
+// Largest singular value of D (m x n, column-major) = sqrt(lambda_max) of the smaller Gram matrix,
+// by cyclic Jacobi rotations (thread 0; the matrix is at most 32 x 32). `gram` holds min(m,n)^2 doubles.
+__device__ double wg_spectral_norm(const double *D, int m, int n, double *gram, double *red) {
+    const int g = m < n ? m : n;
+    for (int idx = threadIdx.x; idx < g * g; idx += PRE_THREADS) {
+        const int i = idx % g, j = idx / g;
+        double acc = 0.0;
+        if (m <= n)
+            for (int l = 0; l < n; ++l) acc += D[i + (size_t)l * m] * D[j + (size_t)l * m];  // D D'
+        else
+            for (int l = 0; l < m; ++l) acc += D[l + (size_t)i * m] * D[l + (size_t)j * m];  // D' D
+        gram[idx] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            double off = 0.0, diag = 0.0;
+            for (int j = 0; j < g; ++j)
+                for (int i = 0; i < g; ++i) (i == j ? diag : off) += gram[i + j * g] * gram[i + j * g];
+            if (off <= 1e-30 * diag || off == 0.0) break;
+            for (int p = 0; p < g - 1; ++p)
+                for (int q = p + 1; q < g; ++q) {
+                    const double apq = gram[p + q * g];
+                    if (apq == 0.0) continue;
+                    const double theta = (gram[q + q * g] - gram[p + p * g]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                    for (int k = 0; k < g; ++k) {  // columns p, q
+                        const double akp = gram[k + p * g], akq = gram[k + q * g];
+                        gram[k + p * g] = c * akp - sn * akq;
+                        gram[k + q * g] = sn * akp + c * akq;
+                    }
+                    for (int k = 0; k < g; ++k) {  // rows p, q
+                        const double apk = gram[p + k * g], aqk = gram[q + k * g];
+                        gram[p + k * g] = c * apk - sn * aqk;
+                        gram[q + k * g] = sn * apk + c * aqk;
+                    }
+                }
+        }
+        double lmax = 0.0;
+        for (int i = 0; i < g; ++i) lmax = fmax(lmax, gram[i + i * g]);
+        red[0] = sqrt(lmax);
+    }
+    __syncthreads();
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ double wg_sum_sq_diff(const double *a, const double *b, int n, double *red) {
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += PRE_THREADS) m += (a[i] - b[i]) * (a[i] - b[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = PRE_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ double wg_max_abs(const double *a, int n, double *red) {
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += PRE_THREADS) m = fmax(m, fabs(a[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = PRE_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+size_t lqr_scratch_doubles(int nx, int nu) {
+    const int g = nx < nu ? nx : nu;
+    // Kprev,K,BtP,T1,dK (nu*nx) + Pprev,P,AtP,AmBK,T3 (nx*nx) + S,Sinv (nu*nu) + gram + perm
+    return (size_t)5 * nu * nx + (size_t)5 * nx * nx + (size_t)2 * nu * nu + (size_t)g * g + (nu + 2);
+}
+
+// TinyMPC.m:194-221 (compute_cache_terms) and :336-366 (solve_lqr, iterative branch run to stationarity in
+// place of MATLAB's idare): K = (R_rho + B'PB + reg I)^-1 B'PA ; P = Q_rho + A'P(A - BK), from P0.
+__global__ void __launch_bounds__(PRE_THREADS) k_lqr(const LqrParams p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *red = lds;
+    double *w = p.use_lds ? (lds + PRE_THREADS) : p.scratch;
+    const int nx = p.nx, nu = p.nu, tid = threadIdx.x;
+    double *Kprev = w;               w += nu * nx;
+    double *K = w;                   w += nu * nx;
+    double *BtP = w;                 w += nu * nx;
+    double *T1 = w;                  w += nu * nx;
+    double *dK = w;                  w += nu * nx;
+    double *Pprev = w;               w += nx * nx;
+    double *P = w;                   w += nx * nx;
+    double *AtP = w;                 w += nx * nx;
+    double *AmBK = w;                w += nx * nx;
+    double *T3 = w;                  w += nx * nx;
+    double *S = w;                   w += nu * nu;
+    double *Sinv = w;                w += nu * nu;
+    double *gram = w;                w += (nx < nu ? nx : nu) * (nx < nu ? nx : nu);
+    int *perm = reinterpret_cast<int *>(w);
+    const double *A = p.A, *B = p.B;
+    auto Qrho = [&](int i) { return p.Q[i] + ((i % nx == i / nx) ? p.rho : 0.0); };
+    auto Rrho = [&](int i) { return p.R[i] + ((i % nu == i / nu) ? p.rho : 0.0); };
+
+    for (int i = tid; i < nu * nx; i += PRE_THREADS) Kprev[i] = 0.0;
+    for (int i = tid; i < nx * nx; i += PRE_THREADS) Pprev[i] = p.p0_augmented ? Qrho(i) : p.Q[i];
+    __syncthreads();
+
+    int steps = p.max_iter;
+    double best = 1e300;
+    int since_best = 0;
+    const double rank_bound = sqrt((double)(nx < nu ? nx : nu));
+    for (int it = 1; it <= p.max_iter; ++it) {
+        wg_gemm<true, false>(BtP, B, Pprev, nu, nx, nx);
+        wg_gemm<false, false>(S, BtP, B, nu, nx, nu);
+        for (int i = tid; i < nu * nu; i += PRE_THREADS) S[i] = Rrho(i) + S[i] + ((i % nu == i / nu) ? p.reg : 0.0);
+        __syncthreads();
+        wg_lu_inverse(Sinv, S, perm, nu);
+        wg_gemm<false, false>(T1, BtP, A, nu, nx, nx);
+        wg_gemm<false, false>(K, Sinv, T1, nu, nu, nx);
+        wg_gemm<true, false>(AtP, A, Pprev, nx, nx, nx);
+        wg_gemm<false, false>(T3, B, K, nx, nu, nx);
+        for (int i = tid; i < nx * nx; i += PRE_THREADS) AmBK[i] = A[i] - T3[i];
+        __syncthreads();
+        wg_gemm<false, false>(T3, AtP, AmBK, nx, nx, nx);
+        for (int i = tid; i < nx * nx; i += PRE_THREADS) P[i] = Qrho(i) + T3[i];
+        __syncthreads();
+        bool stop = false;
+        if (p.norm_kind == 2) {
+            // ||.||_2 <= ||.||_F <= sqrt(rank) ||.||_2 decides almost every iteration without the eigen-solve
+            const double fro = sqrt(wg_sum_sq_diff(K, Kprev, nu * nx, red));
+            if (fro < p.tol) {
+                stop = true;
+            } else if (fro < p.tol * rank_bound) {
+                for (int i = tid; i < nu * nx; i += PRE_THREADS) dK[i] = K[i] - Kprev[i];
+                __syncthreads();
+                stop = wg_spectral_norm(dK, nu, nx, gram, red) < p.tol;
+            }
+        } else {
+            const double md = wg_max_abs_diff(K, Kprev, nu * nx, red);
+            const double scale = fmax(1.0, wg_max_abs(K, nu * nx, red));
+            stop = md < p.tol * scale;
+            // rounding noise can sit above a very small tol: a converging recursion sets a new minimum of the
+            // change every step, so 50 steps without one mean the noise floor has been reached
+            if (md < best) {
+                best = md;
+                since_best = 0;
+            } else if (++since_best >= 50 && md < 1e-9 * scale) {
+                stop = true;
+            }
+        }
+        for (int i = tid; i < nu * nx; i += PRE_THREADS) Kprev[i] = K[i];
+        for (int i = tid; i < nx * nx; i += PRE_THREADS) Pprev[i] = P[i];
+        __syncthreads();
+        if (stop && it >= p.min_iter) {
+            steps = it;
+            break;
+        }
+    }
+    // C1 = inv(R_rho + B'PB) (no regulariser, :219/:363), C2 = (A - BK)' with the final K (:218/:364)
+    wg_gemm<true, false>(BtP, B, P, nu, nx, nx);
+    wg_gemm<false, false>(S, BtP, B, nu, nx, nu);
+    for (int i = tid; i < nu * nu; i += PRE_THREADS) S[i] = Rrho(i) + S[i];
+    __syncthreads();
+    wg_lu_inverse(Sinv, S, perm, nu);
+    wg_gemm<false, false>(T3, B, K, nx, nu, nx);
+    for (int i = tid; i < nu * nu; i += PRE_THREADS) p.C1[i] = Sinv[i];
+    for (int i = tid; i < nu * nx; i += PRE_THREADS) p.K[i] = K[i];
+    for (int i = tid; i < nx * nx; i += PRE_THREADS) {
+        p.P[i] = P[i];
+        p.C2[(i / nx) + (size_t)(i % nx) * nx] = A[i] - T3[i];
+    }
+    if (tid == 0) p.info[0] = steps;
+}
+
+hipError_t launch_lqr(const LqrParams &p, hipStream_t stream) {
+    size_t lds = sizeof(double) * PRE_THREADS;
+    if (p.use_lds) lds += sizeof(double) * lqr_scratch_doubles(p.nx, p.nu);
+    hipLaunchKernelGGL(k_lqr, dim3(1), dim3(PRE_THREADS), lds, stream, p);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_finite_diff(const FiniteDiffParams p) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.count; i += gridDim.x * 256) p.out[i] = (p.hi[i] - p.lo[i]) / p.h;
+}
+
+hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finite_diff, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // Sweep operators: one (nx+nu)x(nx+nu) mat-vec per step instead of the reference's 2-3
 // =====================================================================================
 //  forward  (admm.cpp:29,33):  u_i = -Kinf x_i - d_i ;  x_{i+1} = A x_i + B u_i + f

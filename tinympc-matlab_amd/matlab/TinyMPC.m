@@ -8,8 +8,9 @@ classdef TinyMPC < handle
     % calls the C ABI of libtinympc_hip.so (include/tinympc_hip.h). The ADMM solve itself runs as one
     % HIP kernel on the GPU; this file only shapes arguments.
     %
-    % Out of scope on this build (they raise): codegen, codegen_with_sensitivity, adaptive_rho,
-    % compute_cache_terms, compute_sensitivity_autograd. get_stats and get_cache are additions.
+    % Out of scope on this build (they raise): codegen, codegen_with_sensitivity, adaptive_rho.
+    % compute_cache_terms / solve_lqr / compute_sensitivity_autograd run on the device (extra MEX verbs).
+    % get_stats and get_cache are additions.
 
     properties
         nx = 0; nu = 0; N = 0;
@@ -200,12 +201,22 @@ classdef TinyMPC < handle
             end
         end
 
-        function varargout = compute_cache_terms(~) %#ok<STOUT>
-            error('TinyMPC:NotAvailable', 'compute_cache_terms is not part of the HIP build; the device cache is computed at setup.');
+        function [Kinf, Pinf, Quu_inv, AmBKt] = compute_cache_terms(obj)
+            % Riccati recursion of the class (full Q and R, rho added once), run on the device.
+            obj.require_setup();
+            [Kinf, Pinf, Quu_inv, AmBKt] = tinympc_matlab('compute_cache_terms', false);
         end
 
-        function varargout = compute_sensitivity_autograd(~) %#ok<STOUT>
-            error('TinyMPC:NotAvailable', 'compute_sensitivity_autograd (adaptive rho) is not part of the HIP build.');
+        function [K, P, C1, C2] = solve_lqr(obj, rho_val)
+            % Stabilising DARE solution for Q + rho_val*I, R + rho_val*I, on the device (u = -K*x).
+            obj.require_setup();
+            [K, P, C1, C2] = tinympc_matlab('solve_lqr', rho_val, false);
+        end
+
+        function [dK, dP, dC1, dC2] = compute_sensitivity_autograd(obj)
+            % Forward differences of solve_lqr in rho (h = 1e-6), on the device.
+            obj.require_setup();
+            [dK, dP, dC1, dC2] = tinympc_matlab('compute_sensitivity', false);
         end
 
         function reset(obj)

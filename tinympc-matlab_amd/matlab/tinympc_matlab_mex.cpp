@@ -180,6 +180,39 @@ void verb_set_cache_terms(int, mxArray *[], int nrhs, const mxArray *prhs[]) {
                                   real_doubles(prhs[3]), as_int(prhs[4])));
 }
 
+// The three verbs below have no counterpart in bindings.cpp: the reference runs these recursions in MATLAB
+// inside TinyMPC.m (:194-241, :336-366); this build's TinyMPC.m forwards them to the device instead.
+void cache_outputs(mxArray *plhs[]) {
+    plhs[0] = matrix_out(g_nu, g_nx);
+    plhs[1] = matrix_out(g_nx, g_nx);
+    plhs[2] = matrix_out(g_nu, g_nu);
+    plhs[3] = matrix_out(g_nx, g_nx);
+}
+
+void verb_compute_cache_terms(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {  // -> Kinf,Pinf,Quu_inv,AmBKt
+    need_args(nrhs, 1, "compute_cache_terms");
+    need_solver();
+    cache_outputs(plhs);
+    check(tinympc_compute_cache_terms(g_handle, mxGetPr(plhs[0]), mxGetPr(plhs[1]), mxGetPr(plhs[2]), mxGetPr(plhs[3]),
+                                      nullptr, as_int(prhs[0])));
+}
+
+void verb_solve_lqr(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {  // rho_val -> K,P,C1,C2
+    need_args(nrhs, 2, "solve_lqr");
+    need_solver();
+    cache_outputs(plhs);
+    check(tinympc_solve_lqr(g_handle, mxGetScalar(prhs[0]), mxGetPr(plhs[0]), mxGetPr(plhs[1]), mxGetPr(plhs[2]),
+                            mxGetPr(plhs[3]), nullptr));
+}
+
+void verb_compute_sensitivity(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {  // -> dK,dP,dC1,dC2
+    need_args(nrhs, 1, "compute_sensitivity");
+    need_solver();
+    cache_outputs(plhs);
+    check(tinympc_compute_sensitivity(g_handle, mxGetPr(plhs[0]), mxGetPr(plhs[1]), mxGetPr(plhs[2]), mxGetPr(plhs[3]),
+                                      as_int(prhs[0])));
+}
+
 void verb_set_linear_constraints(int, mxArray *[], int nrhs, const mxArray *prhs[]) {  // Alin_x, blin_x, Alin_u, blin_u
     need_solver();
     if (nrhs < 4) mexErrMsgIdAndTxt("TinyMPC:InvalidInput", "set_linear_constraints requires 4 input arguments");
@@ -233,6 +266,8 @@ const Verb kVerbs[] = {
     {"codegen_with_sensitivity", verb_codegen_with_sensitivity}, {"update_settings", verb_update_settings},
     {"print_problem_data", verb_print_problem_data}, {"set_linear_constraints", verb_set_linear_constraints},
     {"set_cone_constraints", verb_set_cone_constraints},
+    {"compute_cache_terms", verb_compute_cache_terms}, {"solve_lqr", verb_solve_lqr},
+    {"compute_sensitivity", verb_compute_sensitivity},
 };
 
 }  // namespace

@@ -230,13 +230,35 @@ class TinyMPC:
         status = self._L.tinympc_codegen_with_sensitivity(self._h, str(output_dir).encode(), None, None, None, None, 0)
         raise TinyMPCError(status, f"Code generation with sensitivity failed with status: {status}: {_lib.last_error()}")
 
+    def _cache_buffers(self):
+        nx, nu = self.nx, self.nu
+        return (np.zeros((nu, nx), order="F"), np.zeros((nx, nx), order="F"),
+                np.zeros((nu, nu), order="F"), np.zeros((nx, nx), order="F"))
+
     def compute_cache_terms(self):
-        """OUT OF SCOPE helper of the .m class (TinyMPC.m:194-221: a MATLAB-side Riccati loop feeding
-        codegen / adaptive rho). The device cache is available from get_cache()."""
-        raise NotImplementedError("compute_cache_terms is out of scope (SURVEY.md section 2 #5); use get_cache()")
+        """[Kinf, Pinf, Quu_inv, AmBKt] of the class's own Riccati loop (TinyMPC.m:194-221: full Q and R, rho
+        added once, P0 = Q, 1e-8 regulariser, norm(K - Kprev) < 1e-10, at most 5000 steps), run on the device."""
+        self._check_setup()
+        K, P, Qi, Am = self._cache_buffers()
+        it = C.c_int()
+        _lib.check(self._L.tinympc_compute_cache_terms(self._h, _p(K), _p(P), _p(Qi), _p(Am), C.byref(it), 0))
+        self.cache_terms_iters = it.value
+        return K, P, Qi, Am
+
+    def solve_lqr(self, rho_val: float):
+        """[K, P, C1, C2] for Q + rho_val*I, R + rho_val*I (TinyMPC.m:336-366; idare there, a device-side
+        fixed-point recursion to stationarity here)."""
+        self._check_setup()
+        K, P, C1, C2 = self._cache_buffers()
+        _lib.check(self._L.tinympc_solve_lqr(self._h, float(rho_val), _p(K), _p(P), _p(C1), _p(C2), None))
+        return K, P, C1, C2
 
     def compute_sensitivity_autograd(self):
-        raise NotImplementedError("compute_sensitivity_autograd is out of scope (adaptive rho, SURVEY.md section 2 #6)")
+        """[dK, dP, dC1, dC2]: forward differences of solve_lqr in rho, h = 1e-6 (TinyMPC.m:223-241)."""
+        self._check_setup()
+        dK, dP, dC1, dC2 = self._cache_buffers()
+        _lib.check(self._L.tinympc_compute_sensitivity(self._h, _p(dK), _p(dP), _p(dC1), _p(dC2), 0))
+        return dK, dP, dC1, dC2
 
     def print_problem_data(self):
         self._check_setup()
