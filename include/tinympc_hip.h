@@ -91,9 +91,27 @@ int tinympc_get_solution(tinympc_solver *s, double *x_out, double *u_out, int ve
 int tinympc_get_stats(tinympc_solver *s, int *iter, int *status, double *pri_res_state,
                       double *pri_res_input, int verbose);
 
-/* verb 'codegen' (bindings.cpp:288-316): embedded-C++ emitter, OUT OF SCOPE for this build
- * (SURVEY.md section 2 #7). Always TINYMPC_ERR_NOT_IMPLEMENTED. */
+/* verb 'codegen' (bindings.cpp:288-316 -> tiny_codegen, codegen.cpp:56-68): writes
+ * <output_dir>/tinympc/tiny_data.hpp, <output_dir>/src/tiny_data.cpp and <output_dir>/src/tiny_main.cpp from
+ * the cache on the device, the settings, the dynamics and the bounds. Copying the solver sources next to them
+ * is the caller's job, as in the reference (TinyMPC.m:415-434). */
 int tinympc_codegen(tinympc_solver *s, const char *output_dir, int verbose);
+
+/* Everything the emitter writes, as plain host pointers (column-major). tinympc_codegen() fills this from a
+ * handle; tinympc_codegen_emit() is host-only file writing and needs no device. */
+typedef struct tinympc_codegen_data {
+    int nx, nu, N;
+    int iter, solved;                                              /* TinySolution.iter / .solved at the time of the call */
+    double rho;
+    const double *Kinf, *Pinf, *Quu_inv, *AmBKt;                   /* nu x nx, nx x nx, nu x nu, nx x nx */
+    const double *dKinf_drho, *dPinf_drho, *dC1_drho, *dC2_drho;   /* emitted only when adaptive_rho != 0; may be NULL */
+    double abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination, en_state_bound, en_input_bound, adaptive_rho;
+    const double *Q, *R;                                           /* cost diagonals INCLUDING rho: nx, nu (tiny_api.cpp:90-91) */
+    const double *Adyn, *Bdyn;                                     /* nx x nx, nx x nu */
+    const double *x_min, *x_max, *u_min, *u_max;                   /* nx x N, nx x N, nu x (N-1), nu x (N-1) */
+} tinympc_codegen_data;
+int tinympc_codegen_emit(const tinympc_codegen_data *data, const char *output_dir, int verbose);
 
 /* verb 'set_sensitivity_matrices' (bindings.cpp:319-361): the reference stores nothing (prints norms
  * when verbose); validated and accepted as a no-op here too. */
@@ -117,7 +135,8 @@ int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, cons
 int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *qcx, const double *cx,
                                  int ncx, const int *Acu, const int *qcu, const double *cu, int ncu);
 
-/* verb 'codegen_with_sensitivity' (bindings.cpp:481-529): OUT OF SCOPE, TINYMPC_ERR_NOT_IMPLEMENTED. */
+/* verb 'codegen_with_sensitivity' (bindings.cpp:481-529 -> codegen.cpp:70-90): as 'codegen'; the four
+ * sensitivity matrices are written into the generated cache only while adaptive_rho is enabled. */
 int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *output_dir, const double *dK,
                                      const double *dP, const double *dC1, const double *dC2,
                                      int verbose);

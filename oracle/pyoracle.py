@@ -259,6 +259,13 @@ class OracleRef(_Base):
 
     kind = "reference"
 
+    def codegen(self, output_dir: str) -> int:
+        """The reference's own tiny_codegen() (codegen.cpp:56-68) on this solver."""
+        return int(self.L.ref_codegen(self.h, str(output_dir).encode()))
+
+    def set_adaptive_rho(self, enabled: bool, rho_min: float = 1.0, rho_max: float = 100.0, clip: bool = True):
+        self.L.ref_set_adaptive_rho(self.h, int(enabled), float(rho_min), float(rho_max), int(clip))
+
     def __init__(self, prob):
         if not ref_available():
             raise FileNotFoundError(f"{REF_LIB} missing: run `make -C oracle ref` where /root/reference exists")
@@ -286,6 +293,9 @@ class OracleRef(_Base):
         L.ref_get_stats.argtypes = [C.c_void_p, _ip, _dp]
         L.ref_bench_solves.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int]
         L.ref_bench_solves.restype = C.c_long
+        if hasattr(L, "ref_codegen"):
+            L.ref_codegen.argtypes = [C.c_void_p, C.c_char_p]
+            L.ref_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
         self.nx, self.nu, self.N = prob.nx, prob.nu, prob.N
         nx, nu, N = self.nx, self.nu, self.N
         A, B, Q, R = _f(prob.A), _f(prob.B), _f(prob.Q), _f(prob.R)

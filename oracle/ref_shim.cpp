@@ -21,6 +21,7 @@
 #include <sstream>
 #include <string>
 
+#include "tinympc/codegen.hpp"
 #include "tinympc/tiny_api.hpp"
 #include "tinympc/types.hpp"
 
@@ -170,6 +171,22 @@ int ref_set_cache_terms(void *h, const double *Kinf, const double *Pinf, const d
 int ref_solve(void *h, int verbose) {
     CoutSilencer quiet(!verbose);
     return tiny_solve(static_cast<TinySolver *>(h));
+}
+
+// The reference's own emitter (codegen.cpp:56-68), so that tests can compare the data file this repository's
+// emitter writes with the one the reference writes from the same solver state.
+int ref_codegen(void *h, const char *output_dir) {
+    CoutSilencer quiet(true);
+    return tiny_codegen(static_cast<TinySolver *>(h), output_dir, 0);
+}
+
+int ref_set_adaptive_rho(void *h, int enabled, double rho_min, double rho_max, int clip) {
+    auto *s = static_cast<TinySolver *>(h);
+    s->settings->adaptive_rho = enabled;
+    s->settings->adaptive_rho_min = rho_min;
+    s->settings->adaptive_rho_max = rho_max;
+    s->settings->adaptive_rho_enable_clipping = clip;
+    return 0;
 }
 
 // Single phase functions, for phase-by-phase pinning of the restatement.

@@ -1,0 +1,245 @@
+"""Code generation (reference codegen.cpp:56-431, TinyMPC.m:159-182, 415-434).
+
+CPU tests: the host-only emitter against the REFERENCE's own emitter (oracle/_ref, line by line), and -- where the
+reference tree exists -- the generated project compiled with the reference's solver sources and run.
+GPU tests: `solver.codegen()` writes what the device computed."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from conftest import rel_err
+
+import pyoracle as O
+
+REF_SRC = "/root/reference/src/codegen_src"
+MEMBER = re.compile(r"\t\(tiny(?:Matrix|Vector)\(([\d, ]+)\) << (.*?)\)\.finished\(\),?\t// (\w+)")
+
+
+def _fp(a):
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _emit(pkg, out, prob, cache, settings, sens=None, it=0, solved=0):
+    """Drive tinympc_codegen_emit() with plain host arrays (no device involved)."""
+    lib = pkg.load_library()
+    d = pkg._lib.CodegenData()
+    keep = []
+
+    def put(name, arr):
+        a, p = _fp(arr)
+        keep.append(a)
+        setattr(d, name, p)
+
+    d.nx, d.nu, d.N, d.iter, d.solved, d.rho = prob.nx, prob.nu, prob.N, it, solved, prob.rho
+    for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+        put(n, cache[n])
+    if sens is not None:
+        for n, a in zip(("dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho"), sens):
+            put(n, a)
+    d.abs_pri_tol, d.abs_dua_tol = settings["abs_pri_tol"], settings["abs_dua_tol"]
+    d.max_iter, d.check_termination = settings["max_iter"], settings["check_termination"]
+    d.en_state_bound, d.en_input_bound = settings["en_state_bound"], settings["en_input_bound"]
+    d.adaptive_rho = settings.get("adaptive_rho", 0)
+    put("Q", np.diag(prob.Q) + prob.rho)
+    put("R", np.diag(prob.R) + prob.rho)
+    put("Adyn", prob.A)
+    put("Bdyn", prob.B)
+    for n, a in zip(("x_min", "x_max", "u_min", "u_max"), prob.expanded_bounds()):
+        put(n, a)
+    rc = lib.tinympc_codegen_emit(C.byref(d), str(out).encode(), 0)
+    assert rc == 0, pkg._lib.last_error()
+
+
+def _body(path):
+    """File content without the leading comment block (it carries a time stamp)."""
+    text = open(path).read()
+    return text[text.index("*/") + 2:].lstrip("\n").splitlines()
+
+
+def _members(path):
+    """name -> list of arrays (a name can occur in more than one struct), parsed back from tiny_data.cpp."""
+    out = {}
+    for line in open(path):
+        m = MEMBER.match(line)
+        if m:
+            dims = [int(v) for v in m.group(1).split(",")]
+            vals = np.array([float(v.replace("(tinytype)", "")) for v in m.group(2).split(",")])
+            out.setdefault(m.group(3), []).append(vals.reshape(dims if len(dims) == 2 else (dims[0],)))
+    return out
+
+
+SETTINGS = dict(abs_pri_tol=1e-4, abs_dua_tol=2e-4, max_iter=77, check_termination=3, en_state_bound=1, en_input_bound=1)
+
+
+@pytest.mark.parametrize("which", ["cartpole", "quadrotor"])
+def test_emitter_matches_the_reference_emitter_line_by_line(pkg, tmp_path, which):
+    if not O.ref_available():
+        pytest.fail("oracle/_ref/libtinympc_ref.so missing: run `python __graft_entry__.py` where /root/reference exists")
+    prob = pkg.problems.cartpole(20, True) if which == "cartpole" else pkg.problems.quadrotor(12)
+    ref = O.OracleRef(prob).load_problem(prob, SETTINGS)
+    if not hasattr(ref.L, "ref_codegen"):
+        pytest.fail("oracle/_ref was built before ref_codegen existed: rebuild it (`make -C oracle ref`)")
+    ref.set_x0(prob.x0)
+    ref.solve()  # so that TinySolution.iter / .solved are not trivially zero
+    st = ref.stats()
+    assert ref.codegen(tmp_path / "ref") == 0
+    cache = {n: ref.get(n) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt")}
+    _emit(pkg, tmp_path / "mine", prob, cache, SETTINGS, it=st["iter"], solved=st["solved"])
+
+    assert _body(tmp_path / "mine/tinympc/tiny_data.hpp") == _body(tmp_path / "ref/tinympc/tiny_data.hpp")
+    mine, theirs = _body(tmp_path / "mine/src/tiny_data.cpp"), _body(tmp_path / "ref/src/tiny_data.cpp")
+    assert len(mine) == len(theirs)
+    differing = [i for i, (a, b) in enumerate(zip(mine, theirs)) if a != b]
+    # the only line allowed to differ is C1: the reference prints nx*nx values out of an nu x nu matrix there
+    # (codegen.cpp:229-231), this build prints the nu x nu matrix
+    assert all(mine[i].endswith("// C1") for i in differing), [mine[i][:80] for i in differing]
+    assert len(differing) <= 1
+    c1 = _members(tmp_path / "mine/src/tiny_data.cpp")["C1"][0]
+    np.testing.assert_allclose(c1, cache["Quu_inv"], rtol=0, atol=1e-15)
+    assert os.path.exists(tmp_path / "mine/src/tiny_main.cpp")
+
+
+def test_emitter_sensitivity_block_and_errors(pkg, tmp_path):
+    prob = pkg.problems.cartpole(6, True)
+    rng = np.random.default_rng(0)
+    cache = dict(Kinf=rng.normal(size=(1, 4)), Pinf=rng.normal(size=(4, 4)), Quu_inv=rng.normal(size=(1, 1)), AmBKt=rng.normal(size=(4, 4)))
+    sens = (rng.normal(size=(1, 4)), rng.normal(size=(4, 4)), rng.normal(size=(1, 1)), rng.normal(size=(4, 4)))
+    _emit(pkg, tmp_path / "off", prob, cache, SETTINGS, sens=sens)
+    assert "dKinf_drho" not in _members(tmp_path / "off/src/tiny_data.cpp")  # adaptive_rho off: not emitted (codegen.cpp:237)
+    _emit(pkg, tmp_path / "on", prob, cache, dict(SETTINGS, adaptive_rho=1), sens=sens)
+    m = _members(tmp_path / "on/src/tiny_data.cpp")
+    for n, a in zip(("dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho"), sens):
+        np.testing.assert_allclose(m[n][0], a, rtol=0, atol=1e-15)
+    for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+        np.testing.assert_allclose(m[n][0], cache[n], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["u_max"][0], prob.expanded_bounds()[3], rtol=0, atol=0)
+    # writing twice into the same tree is fine (codegen.cpp:45-49); an unwritable target is an error code, not exit()
+    _emit(pkg, tmp_path / "on", prob, cache, SETTINGS)
+    lib = pkg.load_library()
+    assert lib.tinympc_codegen_emit(None, b"/tmp/x", 0) == pkg._lib.ERR_INVALID_INPUT
+    blocker = tmp_path / "file"
+    blocker.write_text("x")
+    d = pkg._lib.CodegenData()
+    assert lib.tinympc_codegen_emit(C.byref(d), str(blocker).encode(), 0) == pkg._lib.ERR_INVALID_INPUT
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="needs the reference's solver sources (absent on the GPU box)")
+def test_generated_project_compiles_against_the_reference_sources_and_solves(pkg, tmp_path):
+    """The generated tiny_data.cpp + the reference's own admm/tiny_api sources + a driver: the embedded solver
+    reproduces the oracle's solve of the same problem."""
+    if not O.port_available():
+        pytest.fail("oracle/liboracle_port.so missing: run `python __graft_entry__.py`")
+    prob = pkg.problems.cartpole(20, True)
+    settings = dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=100, check_termination=1, en_state_bound=1, en_input_bound=1)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    cache = {n: orc.get(n) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt")}
+    out = tmp_path / "gen"
+    _emit(pkg, out, prob, cache, settings)
+    driver = out / "src" / "driver.cpp"
+    driver.write_text(
+        '#include <cstdio>\n#include <tinympc/tiny_api.hpp>\n#include <tinympc/tiny_data.hpp>\n'
+        'int main() {\n'
+        '  tinyVector x0(4); x0 << %s;\n'
+        '  tiny_set_x0(&tiny_solver, x0);\n'
+        '  int rc = tiny_solve(&tiny_solver);\n'
+        '  std::printf("RC %%d ITER %%d\\n", rc, tiny_solver.work->iter);\n'
+        '  for (int k = 0; k < tiny_solver.work->N - 1; ++k) std::printf("U %%.17g\\n", (double)tiny_solver.solution->u(0, k));\n'
+        '  return 0;\n}\n' % ", ".join(repr(float(v)) for v in prob.x0))
+    exe = out / "driver"
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-I{out}", f"-I{REF_SRC}", f"-I{REF_SRC}/include", f"-I{REF_SRC}/include/Eigen",
+           f"-I{REF_SRC}/tinympc", str(driver), str(out / "src/tiny_data.cpp"), f"{REF_SRC}/tinympc/admm.cpp",
+           f"{REF_SRC}/tinympc/tiny_api.cpp", f"{REF_SRC}/tinympc/rho_benchmark.cpp", "-o", str(exe)]
+    subprocess.run(cmd, check=True, timeout=600)
+    res = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60).stdout.splitlines()
+    head = [l for l in res if l.startswith("RC")][0].split()
+    u = np.array([float(l.split()[1]) for l in res if l.startswith("U ")])
+    orc.set_x0(prob.x0)
+    rc = orc.solve()
+    assert int(head[1]) == rc and int(head[3]) == orc.stats()["iter"]
+    assert rel_err(u, orc.solution()[1].ravel()) < 1e-10
+    # the generated example main compiles too
+    subprocess.run([c if c != str(driver) else str(out / "src/tiny_main.cpp") for c in cmd[:-1]] + [str(out / "example")],
+                   check=True, timeout=600)
+    assert "tiny_solve returned" in subprocess.run([str(out / "example")], check=True, capture_output=True, text=True, timeout=60).stdout
+
+
+def test_python_mirror_copies_the_solver_sources(pkg, tmp_path):
+    """TinyMPC.m:415-434 copy_build_artifacts: the codegen_src tree lands beside the generated files, build/ exists."""
+    src = tmp_path / "codegen_src"
+    (src / "tinympc").mkdir(parents=True)
+    (src / "tinympc" / "admm.cpp").write_text("// stand-in\n")
+    (src / "CMakeLists.txt").write_text("# stand-in\n")
+    out = tmp_path / "out"
+    (out / "src").mkdir(parents=True)
+    pkg.TinyMPC._copy_build_artifacts(out, str(src))
+    assert (out / "tinympc" / "admm.cpp").exists() and (out / "CMakeLists.txt").exists() and (out / "build").is_dir()
+    pkg.TinyMPC._copy_build_artifacts(tmp_path / "out2", str(tmp_path / "missing"))  # no sources: only build/
+    assert (tmp_path / "out2" / "build").is_dir()
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cartpole", "quadrotor"])
+def test_codegen_writes_the_device_cache(pkg, tmp_path, which):
+    prob = pkg.problems.cartpole(20, True) if which == "cartpole" else pkg.problems.quadrotor(12)
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, max_iter=60, abs_pri_tol=1e-4, abs_dua_tol=1e-4)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    s.set_x0(prob.x0)
+    s.solve()
+    s.codegen(tmp_path / "gen")
+    m = _members(tmp_path / "gen/src/tiny_data.cpp")
+    cache = s.get_cache()
+    for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+        np.testing.assert_allclose(m[n][0], cache[n], rtol=0, atol=1e-15 * max(1.0, np.abs(cache[n]).max()))
+    np.testing.assert_allclose(m["C1"][0], cache["Quu_inv"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["C2"][0], cache["AmBKt"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["Q"][0], np.diag(prob.Q) + prob.rho, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["Adyn"][0], prob.A, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["Bdyn"][0], prob.B, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(m["u_min"][0], prob.expanded_bounds()[2], rtol=0, atol=0)
+    np.testing.assert_allclose(m["x_max"][0], prob.expanded_bounds()[1], rtol=0, atol=0)
+    text = open(tmp_path / "gen/src/tiny_data.cpp").read()
+    assert f"\t{s.get_stats()['iter']},\t\t// iter\n" in text and "\t60,\t\t// max iterations\n" in text
+    # against the oracle's cache: the generated file carries the same numbers the reference would have written
+    orc = O.OraclePort(prob)
+    for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+        assert rel_err(m[n][0], orc.get(n)) < 1e-10
+    assert (tmp_path / "gen/build").is_dir() and (tmp_path / "gen/tinympc/tiny_data.hpp").exists()
+    s.reset()
+
+
+@pytest.mark.gpu
+def test_codegen_with_sensitivity_and_error_paths(pkg, tmp_path):
+    prob = pkg.problems.quadrotor(10)
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho)
+    sens = s.compute_sensitivity_autograd()
+    s.codegen_with_sensitivity(tmp_path / "plain", *sens)
+    assert "dKinf_drho" not in _members(tmp_path / "plain/src/tiny_data.cpp")
+    s.settings["adaptive_rho"] = True
+    try:
+        s._push_settings()
+    except pkg.TinyMPCError:
+        pass  # stored; only solve refuses while adaptive rho is not implemented
+    s.codegen_with_sensitivity(tmp_path / "sens", *sens)
+    m = _members(tmp_path / "sens/src/tiny_data.cpp")
+    for n, a in zip(("dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho"), sens):
+        np.testing.assert_allclose(m[n][0], a, rtol=0, atol=1e-15 * max(1.0, np.abs(a).max()))
+    blocker = tmp_path / "file"
+    blocker.write_text("x")
+    with pytest.raises(pkg.TinyMPCError):
+        s.codegen(blocker)
+    s.reset()
+    with pytest.raises(Exception):
+        s.codegen(tmp_path / "after_reset")

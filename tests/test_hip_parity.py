@@ -336,12 +336,6 @@ def test_full_size_batch_properties(pkg):
 
 
 def test_unimplemented_paths_fail_loudly(pkg):
-    prob = pkg.problems.cartpole()
-    s = make_solver(pkg, prob, {})
-    with pytest.raises(pkg.TinyMPCError) as ei:
-        s.codegen("/tmp/out")
-    assert ei.value.code == pkg._lib.ERR_NOT_IMPLEMENTED
-    s.reset()
     s2 = make_solver(pkg, pkg.problems.cartpole(), {})
     with pytest.raises(pkg.TinyMPCError):
         s2.update_settings(adaptive_rho=True)

@@ -137,8 +137,13 @@ def test_one_solve_script_through_the_mex_verbs(mex, pkg):
     # wrong-shaped bounds and references are rejected with the reference's identifiers
     assert mex.call("set_bound_constraints", g["x_min"][:, :5], g["x_max"], g["u_min"], g["u_max"], 0.0)[0] == "TinyMPC:SetBoundConstraintsFailed"
     assert mex.call("set_x_ref", np.zeros((3, N)), 0.0)[0] == "TinyMPC:SetXRefFailed"
-    err, out = mex.call("codegen", "/tmp/out", 0.0, nlhs=1)
-    assert err is None and out[0][0, 0] != 0  # status != 0 -> TinyMPC.m raises TinyMPC:CodegenFailed
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        err, out = mex.call("codegen", os.path.join(tmp, "gen"), 0.0, nlhs=1)
+        assert err is None and out[0][0, 0] == 0 and os.path.exists(os.path.join(tmp, "gen", "src", "tiny_data.cpp"))
+        open(os.path.join(tmp, "blocker"), "w").close()
+        err, out = mex.call("codegen", os.path.join(tmp, "blocker"), 0.0, nlhs=1)
+        assert err is None and out[0][0, 0] != 0  # status != 0 -> TinyMPC.m raises TinyMPC:CodegenFailed
     assert mex.call("reset", 0.0)[0] is None
     assert mex.call("solve", 0.0)[0] == "TinyMPC:NotInitialized"
 

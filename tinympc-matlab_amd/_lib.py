@@ -32,6 +32,15 @@ MEX_ERROR_IDS = {
     ERR_ALLOC: "TinyMPC:SetupFailed",
 }
 
+class CodegenData(C.Structure):
+    """struct tinympc_codegen_data (include/tinympc_hip.h), for the host-only tinympc_codegen_emit()."""
+    _fields_ = ([("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int), ("iter", C.c_int), ("solved", C.c_int), ("rho", C.c_double)]
+                + [(n, c_double_p) for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho")]
+                + [("abs_pri_tol", C.c_double), ("abs_dua_tol", C.c_double)]
+                + [(n, C.c_int) for n in ("max_iter", "check_termination", "en_state_bound", "en_input_bound", "adaptive_rho")]
+                + [(n, c_double_p) for n in ("Q", "R", "Adyn", "Bdyn", "x_min", "x_max", "u_min", "u_max")])
+
+
 # name -> (restype, argtypes); mirrors include/tinympc_hip.h one to one
 SIGNATURES = {
     "tinympc_last_error": (C.c_char_p, []),
@@ -59,6 +68,7 @@ SIGNATURES = {
     "tinympc_print_problem_data": (C.c_int, [Handle]),
     "tinympc_get_cache": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "tinympc_get_residuals": (C.c_int, [Handle, c_double_p]),
+    "tinympc_codegen_emit": (C.c_int, [C.POINTER(CodegenData), C.c_char_p, C.c_int]),
     "tinympc_compute_cache_terms": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p, C.c_int]),
     "tinympc_solve_lqr": (C.c_int, [Handle, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "tinympc_compute_sensitivity": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),

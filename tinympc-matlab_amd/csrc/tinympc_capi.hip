@@ -16,12 +16,14 @@
 #include <vector>
 
 #include "tinympc_device.h"
+#include "tinympc_host.h"
 
-using namespace tinympc;
+namespace tinympc {
 
-namespace {
-
-thread_local std::string g_last_error;
+std::string &last_error_slot() {
+    thread_local std::string slot;
+    return slot;
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -29,9 +31,15 @@ int fail(int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    g_last_error = buf;
+    last_error_slot() = buf;
     return code;
 }
+
+}  // namespace tinympc
+
+using namespace tinympc;
+
+namespace {
 
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \
@@ -298,7 +306,7 @@ void destroy(tinympc_solver *s) {
 
 extern "C" {
 
-const char *tinympc_last_error(void) { return g_last_error.c_str(); }
+const char *tinympc_last_error(void) { return last_error_slot().c_str(); }
 int tinympc_abi_version(void) { return TINYMPC_ABI_VERSION; }
 
 int tinympc_device_count(void) {
@@ -635,16 +643,50 @@ int tinympc_get_residuals(tinympc_solver *s, double residuals[4]) {
     return tinympc_get_stats_batch(s, nullptr, nullptr, residuals, 0, 1);
 }
 
-int tinympc_codegen(tinympc_solver *s, const char *, int) {
+namespace {
+// Gather what the emitter needs from the device (the cache the kernels computed or the caller installed, the
+// rho-augmented cost diagonals, dynamics, bounds) and write the embedded project's data files.
+int codegen_from_handle(tinympc_solver *s, const char *output_dir, const double *dK, const double *dP, const double *dC1,
+                        const double *dC2, int verbose) {
+    int rc = bind_device(s);
+    if (rc) return rc;
+    const size_t nx = s->nx, nu = s->nu, X = s->X(), U = s->U();
+    std::vector<double> K(nu * nx), P(nx * nx), Qi(nu * nu), Am(nx * nx), qd(nx), rd(nu), A(nx * nx), B(nx * nu), xmin(X), xmax(X), umin(U), umax(U);
+    const struct { void *dst; const void *src; size_t n; } pulls[] = {
+        {K.data(), s->dKinf, K.size()}, {P.data(), s->dPinf, P.size()}, {Qi.data(), s->dQuu, Qi.size()}, {Am.data(), s->dAmBKt, Am.size()},
+        {qd.data(), s->dQd, nx}, {rd.data(), s->dRd, nu}, {A.data(), s->dA, A.size()}, {B.data(), s->dB, B.size()},
+        {xmin.data(), s->dxmin, X}, {xmax.data(), s->dxmax, X}, {umin.data(), s->dumin, U}, {umax.data(), s->dumax, U}};
+    for (const auto &p : pulls)
+        if ((rc = download(s, p.dst, p.src, sizeof(double) * p.n))) return rc;
+    int is[2] = {0, 0};  // iter, status of instance 0
+    if ((rc = download(s, is, s->distats, sizeof(is)))) return rc;
+    tinympc_codegen_data d{};
+    d.nx = s->nx; d.nu = s->nu; d.N = s->N; d.rho = s->rho;
+    d.iter = is[0]; d.solved = is[1] == TINYMPC_STATUS_SOLVED ? 1 : 0;
+    d.Kinf = K.data(); d.Pinf = P.data(); d.Quu_inv = Qi.data(); d.AmBKt = Am.data();
+    d.dKinf_drho = dK; d.dPinf_drho = dP; d.dC1_drho = dC1; d.dC2_drho = dC2;
+    d.abs_pri_tol = s->st.abs_pri_tol; d.abs_dua_tol = s->st.abs_dua_tol; d.max_iter = s->st.max_iter;
+    d.check_termination = s->st.check_termination; d.en_state_bound = s->st.en_state_bound; d.en_input_bound = s->st.en_input_bound;
+    d.adaptive_rho = s->st.adaptive_rho;
+    d.Q = qd.data(); d.R = rd.data(); d.Adyn = A.data(); d.Bdyn = B.data();
+    d.x_min = xmin.data(); d.x_max = xmax.data(); d.u_min = umin.data(); d.u_max = umax.data();
+    return tinympc_codegen_emit(&d, output_dir, verbose);
+}
+}  // namespace
+
+int tinympc_codegen(tinympc_solver *s, const char *output_dir, int verbose) {
     int rc = check_handle(s);
     if (rc) return rc;
-    return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "codegen is out of scope for the MI355X build (embedded C++ emitter, SURVEY.md section 2 #7)");
+    return codegen_from_handle(s, output_dir, nullptr, nullptr, nullptr, nullptr, verbose);
 }
 
-int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *, const double *, const double *, const double *, const double *, int) {
+int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *output_dir, const double *dK, const double *dP, const double *dC1,
+                                     const double *dC2, int verbose) {
     int rc = check_handle(s);
     if (rc) return rc;
-    return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "codegen_with_sensitivity is out of scope for the MI355X build (SURVEY.md section 2 #7)");
+    if (!dK || !dP || !dC1 || !dC2) return fail(TINYMPC_ERR_INVALID_INPUT, "codegen_with_sensitivity requires dK, dP, dC1, dC2");
+    // the four matrices reach the generated cache only while adaptive_rho is enabled (codegen.cpp:79-86, 237-252)
+    return codegen_from_handle(s, output_dir, dK, dP, dC1, dC2, verbose);
 }
 
 int tinympc_set_sensitivity_matrices(tinympc_solver *s, const double *dK, const double *dP, const double *dC1, const double *dC2, int verbose) {

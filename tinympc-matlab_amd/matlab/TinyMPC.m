@@ -8,7 +8,8 @@ classdef TinyMPC < handle
     % calls the C ABI of libtinympc_hip.so (include/tinympc_hip.h). The ADMM solve itself runs as one
     % HIP kernel on the GPU; this file only shapes arguments.
     %
-    % Out of scope on this build (they raise): codegen, codegen_with_sensitivity, adaptive_rho.
+    % Out of scope on this build (raises): adaptive_rho. codegen / codegen_with_sensitivity write the data files
+    % from the cache on the device.
     % compute_cache_terms / solve_lqr / compute_sensitivity_autograd run on the device (extra MEX verbs).
     % get_stats and get_cache are additions.
 
@@ -187,8 +188,10 @@ classdef TinyMPC < handle
             obj.require_setup();
             status = tinympc_matlab('codegen', output_dir, false);
             if status ~= 0
-                error('TinyMPC:CodegenFailed', 'Code generation failed with status: %d (not available on the HIP build)', status);
+                error('TinyMPC:CodegenFailed', 'Code generation failed with status: %d', status);
             end
+            TinyMPC.place_solver_sources(output_dir);
+            fprintf('Code generation completed successfully in: %s\n', output_dir);
         end
 
         function codegen_with_sensitivity(obj, output_dir, dK, dP, dC1, dC2)
@@ -197,8 +200,10 @@ classdef TinyMPC < handle
             status = tinympc_matlab('codegen_with_sensitivity', output_dir, dK, dP, dC1, dC2, false);
             if status ~= 0
                 error('TinyMPC:CodegenWithSensitivityFailed', ...
-                      'Code generation with sensitivity failed with status: %d (not available on the HIP build)', status);
+                      'Code generation with sensitivity failed with status: %d', status);
             end
+            TinyMPC.place_solver_sources(output_dir);
+            fprintf('Code generation with sensitivity matrices completed successfully in: %s\n', output_dir);
         end
 
         function [Kinf, Pinf, Quu_inv, AmBKt] = compute_cache_terms(obj)
@@ -248,6 +253,24 @@ classdef TinyMPC < handle
     end
 
     methods (Static, Access = private)
+        function place_solver_sources(output_dir)
+            % What the reference class does after the MEX call: put the embedded solver's sources (the
+            % codegen_src tree of a TinyMPC checkout: include/, tinympc/, CMakeLists.txt) beside the generated
+            % files and create build/. Looked up in $TINYMPC_CODEGEN_SRC, then next to this file.
+            src = getenv('TINYMPC_CODEGEN_SRC');
+            if isempty(src)
+                src = fullfile(fileparts(mfilename('fullpath')), 'codegen_src');
+            end
+            if isfolder(src)
+                copyfile(src, output_dir);
+            else
+                warning('TinyMPC:CopyArtifactsError', 'No codegen_src tree found (%s): only the generated files were written.', src);
+            end
+            if ~isfolder(fullfile(output_dir, 'build'))
+                mkdir(fullfile(output_dir, 'build'));
+            end
+        end
+
         function out = spread(v, rows, cols, fill)
             % Scalar -> constant matrix; rows-vector (either orientation) -> repeated over the horizon;
             % empty -> `fill` everywhere (bounds only); anything else is taken as already rows x cols.

@@ -219,16 +219,34 @@ class TinyMPC:
         _lib.check(self._L.tinympc_get_cache(self._h, _p(K), _p(P), _p(Qi), _p(Am), C.byref(it)))
         return dict(Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am, C1=Qi, C2=Am, riccati_iters=it.value)
 
-    def codegen(self, output_dir):
+    def codegen(self, output_dir, source_dir=None):
+        """Write the embedded project's data files from the cache on the device, then -- as the class does after
+        the MEX call (TinyMPC.m:159-169, 415-434) -- copy the solver sources next to them and create build/.
+        The sources are the `codegen_src` tree of a TinyMPC checkout: `source_dir`, else $TINYMPC_CODEGEN_SRC,
+        else a `codegen_src` directory beside this file; without one only the generated files are written."""
         self._check_setup()
         status = self._L.tinympc_codegen(self._h, str(output_dir).encode(), 0)
-        raise TinyMPCError(status, f"Code generation failed with status: {status}: {_lib.last_error()}")
+        if status != 0:
+            raise TinyMPCError(status, f"Code generation failed with status: {status}: {_lib.last_error()}")
+        self._copy_build_artifacts(output_dir, source_dir)
 
-    def codegen_with_sensitivity(self, output_dir, dK, dP, dC1, dC2):
+    def codegen_with_sensitivity(self, output_dir, dK, dP, dC1, dC2, source_dir=None):
         self._check_setup()
         self.set_sensitivity_matrices(dK, dP, dC1, dC2)
-        status = self._L.tinympc_codegen_with_sensitivity(self._h, str(output_dir).encode(), None, None, None, None, 0)
-        raise TinyMPCError(status, f"Code generation with sensitivity failed with status: {status}: {_lib.last_error()}")
+        dK, dP, dC1, dC2 = _f(dK), _f(dP), _f(dC1), _f(dC2)
+        status = self._L.tinympc_codegen_with_sensitivity(self._h, str(output_dir).encode(), _p(dK), _p(dP), _p(dC1), _p(dC2), 0)
+        if status != 0:
+            raise TinyMPCError(status, f"Code generation with sensitivity failed with status: {status}: {_lib.last_error()}")
+        self._copy_build_artifacts(output_dir, source_dir)
+
+    @staticmethod
+    def _copy_build_artifacts(output_dir, source_dir=None):
+        import os
+        import shutil
+        src = source_dir or os.environ.get("TINYMPC_CODEGEN_SRC") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "codegen_src")
+        if os.path.isdir(src):
+            shutil.copytree(src, str(output_dir), dirs_exist_ok=True)
+        os.makedirs(os.path.join(str(output_dir), "build"), exist_ok=True)
 
     def _cache_buffers(self):
         nx, nu = self.nx, self.nu
