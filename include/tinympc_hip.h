@@ -113,8 +113,10 @@ typedef struct tinympc_codegen_data {
 } tinympc_codegen_data;
 int tinympc_codegen_emit(const tinympc_codegen_data *data, const char *output_dir, int verbose);
 
-/* verb 'set_sensitivity_matrices' (bindings.cpp:319-361): the reference stores nothing (prints norms
- * when verbose); validated and accepted as a no-op here too. */
+/* verb 'set_sensitivity_matrices' (bindings.cpp:319-361; there it only prints the norms). dK (nu x nx) and
+ * dP (nx x nx) become the cache's dKinf_drho / dPinf_drho that the adaptive-rho update reads
+ * (rho_benchmark.cpp:205-206); dC1 / dC2 are validated and otherwise unused (they would update the copies
+ * C1 / C2, which no solve phase reads). Zero until set. */
 int tinympc_set_sensitivity_matrices(tinympc_solver *s, const double *dK, const double *dP,
                                      const double *dC1, const double *dC2, int verbose);
 
@@ -145,9 +147,10 @@ int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *output_dir, 
  * *s is set to NULL. Passing NULL / a NULL handle is a no-op, as in the reference. */
 int tinympc_reset(tinympc_solver **s, int verbose);
 
-/* verb 'update_settings' (bindings.cpp:548-603), same argument order as the MEX verb. adaptive_rho
- * must be 0: the adaptive-rho side-car is out of scope and enabling it fails
- * loudly with TINYMPC_ERR_NOT_IMPLEMENTED rather than silently solving something else. */
+/* verb 'update_settings' (bindings.cpp:548-603), same argument order as the MEX verb. With
+ * adaptive_rho != 0 solve runs the adaptive-rho loop of the old core (admm.cpp:117-174, rho_benchmark.cpp) on
+ * the device, per instance; it cannot be combined with the cone / linear families (TINYMPC_ERR_UNSUPPORTED
+ * at solve). */
 int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol, int max_iter,
                             int check_termination, int en_state_bound, int en_input_bound,
                             int en_state_soc, int en_input_soc, int en_state_linear,
@@ -204,8 +207,14 @@ int tinympc_set_x0_batch(tinympc_solver *s, const double *x0s, int first, int co
  * the handle's stream. */
 int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int first, int count);
 
-/* Zero the persistent ADMM state (cold start) of every instance; x0 is kept. */
+/* Zero the persistent ADMM state (cold start) of every instance and put every instance's rho back to
+ * the setup value; x0 is kept. */
 int tinympc_reset_workspace(tinympc_solver *s);
+
+/* Adaptive rho (settings adaptive_rho*, admm.cpp:117-174, rho_benchmark.cpp): every instance carries its own
+ * rho, adapted every 5th iteration and kept across solves like the reference's cache->rho. Reads it back for
+ * instances [first, first+count). Equals the setup rho while adaptive_rho has never been on. */
+int tinympc_get_rho_batch(tinympc_solver *s, double *rho_out, int first, int count);
 
 /* Solutions of instances [first, first+count): x_out nx*N*count, u_out nu*(N-1)*count. */
 int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count);

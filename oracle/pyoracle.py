@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_LIB = os.path.join(_HERE, "liboracle_port.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref.so")
+REF_ZEROINIT_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref_zeroinit.so")  # see oracle/Makefile: adaptive rho only
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -40,7 +41,8 @@ def _shape_of(name: str, nx: int, nu: int, N: int):
         return (nu, N - 1)
     return {"Kinf": (nu, nx), "Pinf": (nx, nx), "Quu_inv": (nu, nu), "AmBKt": (nx, nx), "C1": (nu, nu),
             "C2": (nx, nx), "Adyn": (nx, nx), "Bdyn": (nx, nu), "Q": (nx,), "R": (nu,), "fdyn": (nx,),
-            "APf": (nx,), "BPf": (nu,)}[name]
+            "APf": (nx,), "BPf": (nu,), "dKinf_drho": (nu, nx), "dPinf_drho": (nx, nx), "dC1_drho": (nu, nu),
+            "dC2_drho": (nx, nx)}[name]
 
 
 def port_available() -> bool:
@@ -206,6 +208,20 @@ class OraclePort(_Base):
     def reset_workspace(self):
         self.L.orc_reset_workspace(self.h)
 
+    def set_adaptive_rho(self, enabled: bool, rho_min: float = 1.0, rho_max: float = 100.0, clip: bool = True):
+        self.L.orc_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        self.L.orc_set_adaptive_rho(self.h, int(enabled), float(rho_min), float(rho_max), int(clip))
+
+    def set_sensitivity(self, dK, dP):
+        a, b = _f(dK), _f(dP)
+        self.L.orc_set_sensitivity.argtypes = [C.c_void_p, _dp, _dp]
+        self.L.orc_set_sensitivity(self.h, _p(a), _p(b))
+
+    def rho_adaptation(self) -> float:
+        self.L.orc_rho_adaptation.restype = C.c_double
+        self.L.orc_rho_adaptation.argtypes = [C.c_void_p]
+        return float(self.L.orc_rho_adaptation(self.h))
+
     def solve(self) -> int:
         return self.L.orc_solve(self.h)
 
@@ -266,12 +282,13 @@ class OracleRef(_Base):
     def set_adaptive_rho(self, enabled: bool, rho_min: float = 1.0, rho_max: float = 100.0, clip: bool = True):
         self.L.ref_set_adaptive_rho(self.h, int(enabled), float(rho_min), float(rho_max), int(clip))
 
-    def __init__(self, prob):
-        if not ref_available():
-            raise FileNotFoundError(f"{REF_LIB} missing: run `make -C oracle ref` where /root/reference exists")
+    def __init__(self, prob, zeroinit: bool = False):
+        lib = REF_ZEROINIT_LIB if zeroinit else REF_LIB
+        if not os.path.exists(lib):
+            raise FileNotFoundError(f"{lib} missing: run `make -C oracle ref ref_zeroinit` where /root/reference exists")
         if prob.fdyn is not None and np.any(prob.fdyn != 0) or prob.cones or prob.linear:
             raise ValueError("the reference snapshot has no fdyn / cone / linear support (SURVEY.md section 0.1)")
-        L = C.CDLL(REF_LIB)
+        L = C.CDLL(lib)
         self.L = L
         L.ref_setup.restype = C.c_void_p
         L.ref_setup.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int]

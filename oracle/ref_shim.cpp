@@ -85,6 +85,10 @@ const tinyMatrix *find_matrix(TinySolver *s, const std::string &n) {
     if (n == "AmBKt") return &c->AmBKt;
     if (n == "C1") return &c->C1;
     if (n == "C2") return &c->C2;
+    if (n == "dKinf_drho") return &c->dKinf_drho;
+    if (n == "dPinf_drho") return &c->dPinf_drho;
+    if (n == "dC1_drho") return &c->dC1_drho;
+    if (n == "dC2_drho") return &c->dC2_drho;
     if (n == "sol_x") return &s->solution->x;
     if (n == "sol_u") return &s->solution->u;
     return nullptr;

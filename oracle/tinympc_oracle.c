@@ -185,6 +185,9 @@ orc_solver *orc_setup(const double *A, const double *B, const double *fdyn, cons
     s->vl = zalloc(X); s->vlnew = zalloc(X); s->gl = zalloc(X);
     s->zl = zalloc(U); s->zlnew = zalloc(U); s->yl = zalloc(U);
     s->sol_x = zalloc(X); s->sol_u = zalloc(U);
+    s->dKinf_drho = zalloc((size_t)nu * nx); s->dPinf_drho = zalloc((size_t)nx * nx);
+    s->adaptive_rho = 0; s->adaptive_rho_min = 1.0; s->adaptive_rho_max = 100.0; /* tiny_api.cpp:226-229 */
+    s->adaptive_rho_enable_clipping = 1;
     memcpy(s->Adyn, A, sizeof(double) * nx * nx);
     memcpy(s->Bdyn, B, sizeof(double) * nx * nu);
     if (fdyn) memcpy(s->fdyn, fdyn, sizeof(double) * nx);
@@ -206,7 +209,7 @@ void orc_free(orc_solver *s) {
                       s->Bdyn, s->fdyn, s->x_min, s->x_max, s->u_min, s->u_max, s->Xref, s->Uref,
                       s->cx, s->cu, s->vc, s->vcnew, s->gc, s->zc, s->zcnew, s->yc, s->Alin_x,
                       s->blin_x, s->Alin_u, s->blin_u, s->vl, s->vlnew, s->gl, s->zl, s->zlnew,
-                      s->yl, s->sol_x, s->sol_u};
+                      s->yl, s->sol_x, s->sol_u, s->dKinf_drho, s->dPinf_drho};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(s->Acx); free(s->qcx); free(s->Acu); free(s->qcu);
     free(s);
@@ -503,6 +506,7 @@ int orc_solve(orc_solver *s) {
         orc_update_dual(s);         /* :138 */
         orc_update_linear_cost(s);  /* :141 */
         s->iter += 1;               /* :143 */
+        if (s->adaptive_rho && i > 0 && i % 5 == 0) orc_rho_adaptation(s); /* :147-174 */
         if (orc_termination_condition(s)) { /* :181 */
             s->status = 1;
             s->sol_iter = s->iter; s->solved = 1;
@@ -518,6 +522,100 @@ int orc_solve(orc_solver *s) {
     memcpy(s->sol_x, s->vnew, sizeof(double) * X);
     memcpy(s->sol_u, s->znew, sizeof(double) * U);
     return 1;
+}
+
+/* ---------------------------------------------------------------- adaptive rho
+ * benchmark_rho_adaptation (rho_benchmark.cpp:200-249) = format_matrices (:44-150) + compute_residuals (:152-180)
+ * + predict_rho (:182-198) + update_matrices_with_derivatives (:200-216 in the snapshot's numbering), evaluated on
+ * the block structure of the matrices the reference assembles densely:
+ *   x_decision = [x_0; u_0; x_1; u_1; ...; x_{N-1}]                                              (:62-71)
+ *   A_matrix   = [ rows (N-1)*nu : u_i ] ; [ rows (N-1)*nx : A x_i + B u_i - x_{i+1} ]            (:77-94)
+ *   z_vector   = [ znew_i ; vnew_{i+1} ],   y_vector = [ y_i ; g_{i+1} ]                          (:97-103)
+ *   P_matrix   = blkdiag(Q, R, Q, R, ..., Pinf)  with Q, R = the rho-augmented diagonals of the workspace (:106-124)
+ *   q_vector   = [ Q.*x_i ; R.*u_i ]  (zero reference)                                            (:127-147)
+ */
+static double amax(double m, double v) { v = fabs(v); return v > m ? v : m; }
+
+double orc_rho_adaptation(orc_solver *s) {
+    const int nx = s->nx, nu = s->nu, N = s->N;
+    double pri_res = 0.0, ax_max = 0.0, z_max = 0.0;          /* compute_residuals :160-164 */
+    double dual_res = 0.0, px_max = 0.0, aty_max = 0.0, q_max = 0.0; /* :167-179 */
+    for (int i = 0; i < N - 1; ++i) {
+        const double *xi = s->x + (size_t)i * nx, *xn = s->x + (size_t)(i + 1) * nx, *ui = s->u + (size_t)i * nu;
+        for (int j = 0; j < nu; ++j) { /* input rows: Ax = u_i, z = znew_i */
+            const double z = s->znew[(size_t)i * nu + j];
+            pri_res = amax(pri_res, ui[j] - z); ax_max = amax(ax_max, ui[j]); z_max = amax(z_max, z);
+        }
+        for (int r = 0; r < nx; ++r) { /* dynamics rows: Ax = A x_i + B u_i - x_{i+1}, z = vnew_{i+1} */
+            double ax = 0.0;
+            for (int c = 0; c < nx; ++c) ax += s->Adyn[r + (size_t)c * nx] * xi[c];
+            for (int c = 0; c < nu; ++c) ax += s->Bdyn[r + (size_t)c * nx] * ui[c];
+            ax -= xn[r];
+            const double z = s->vnew[(size_t)(i + 1) * nx + r];
+            pri_res = amax(pri_res, ax - z); ax_max = amax(ax_max, ax); z_max = amax(z_max, z);
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        const double *xi = s->x + (size_t)i * nx;
+        for (int r = 0; r < nx; ++r) { /* column block of x_i */
+            double px;
+            if (i == N - 1) { /* Pinf block (:112) */
+                px = 0.0;
+                for (int c = 0; c < nx; ++c) px += s->Pinf[r + (size_t)c * nx] * xi[c];
+            } else {
+                px = s->Q[r] * xi[r]; /* :114 */
+            }
+            const double qv = s->Q[r] * xi[r]; /* :133 */
+            double aty = 0.0;               /* A_matrix' * y_vector */
+            if (i < N - 1) {                /* A' g_{i+1} from dynamics row block i */
+                const double *gn = s->g + (size_t)(i + 1) * nx;
+                for (int c = 0; c < nx; ++c) aty += s->Adyn[c + (size_t)r * nx] * gn[c];
+            }
+            if (i > 0) aty -= s->g[(size_t)i * nx + r]; /* -I of dynamics row block i-1 */
+            px_max = amax(px_max, px); q_max = amax(q_max, qv); aty_max = amax(aty_max, aty);
+            dual_res = amax(dual_res, px + qv + aty);
+        }
+        if (i < N - 1) {
+            const double *ui = s->u + (size_t)i * nu, *gn = s->g + (size_t)(i + 1) * nx;
+            for (int j = 0; j < nu; ++j) { /* column block of u_i */
+                const double px = s->R[j] * ui[j], qv = px;
+                double aty = s->y[(size_t)i * nu + j];
+                for (int c = 0; c < nx; ++c) aty += s->Bdyn[c + (size_t)j * nx] * gn[c];
+                px_max = amax(px_max, px); q_max = amax(q_max, qv); aty_max = amax(aty_max, aty);
+                dual_res = amax(dual_res, px + qv + aty);
+            }
+        }
+    }
+    const double pri_norm = ax_max > z_max ? ax_max : z_max;
+    double dual_norm = px_max > aty_max ? px_max : aty_max;
+    if (q_max > dual_norm) dual_norm = q_max;
+    /* predict_rho (rho_benchmark.cpp:182-198) */
+    const double eps = 1e-10;
+    const double normalized_pri = pri_res / (pri_norm + eps);
+    const double normalized_dual = dual_res / (dual_norm + eps);
+    const double ratio = normalized_pri / (normalized_dual + eps);
+    double new_rho = s->rho * sqrt(ratio);
+    if (s->adaptive_rho_enable_clipping) {
+        if (new_rho < s->adaptive_rho_min) new_rho = s->adaptive_rho_min;
+        if (new_rho > s->adaptive_rho_max) new_rho = s->adaptive_rho_max;
+    }
+    /* update_matrices_with_derivatives: first-order update of Kinf and Pinf (C1/C2 are not read by any phase) */
+    const double delta = new_rho - s->rho;
+    for (int i = 0; i < nu * nx; ++i) s->Kinf[i] += delta * s->dKinf_drho[i];
+    for (int i = 0; i < nx * nx; ++i) s->Pinf[i] += delta * s->dPinf_drho[i];
+    s->rho = new_rho;
+    return new_rho;
+}
+
+void orc_set_adaptive_rho(orc_solver *s, int enabled, double rho_min, double rho_max, int clip) {
+    s->adaptive_rho = enabled; s->adaptive_rho_min = rho_min; s->adaptive_rho_max = rho_max;
+    s->adaptive_rho_enable_clipping = clip;
+}
+
+int orc_set_sensitivity(orc_solver *s, const double *dK, const double *dP) {
+    memcpy(s->dKinf_drho, dK, sizeof(double) * s->nu * s->nx);
+    memcpy(s->dPinf_drho, dP, sizeof(double) * s->nx * s->nx);
+    return 0;
 }
 
 long orc_bench_solves(orc_solver *s, const double *x0s, int count, int reps) {
@@ -568,6 +666,7 @@ static double *find_array(orc_solver *s, const char *n, size_t *count) {
     ORC_ARR("Quu_inv", s->Quu_inv, nu * nu) ORC_ARR("AmBKt", s->AmBKt, nx * nx)
     ORC_ARR("C1", s->Quu_inv, nu * nu) ORC_ARR("C2", s->AmBKt, nx * nx)
     ORC_ARR("APf", s->APf, nx) ORC_ARR("BPf", s->BPf, nu)
+    ORC_ARR("dKinf_drho", s->dKinf_drho, nu * nx) ORC_ARR("dPinf_drho", s->dPinf_drho, nx * nx)
     ORC_ARR("sol_x", s->sol_x, X) ORC_ARR("sol_u", s->sol_u, U)
     ORC_ARR("vcnew", s->vcnew, X) ORC_ARR("gc", s->gc, X) ORC_ARR("zcnew", s->zcnew, U) ORC_ARR("yc", s->yc, U)
     ORC_ARR("vlnew", s->vlnew, X) ORC_ARR("gl", s->gl, X) ORC_ARR("zlnew", s->zlnew, U) ORC_ARR("yl", s->yl, U)

@@ -59,6 +59,14 @@ typedef struct orc_solver {
     int en_state_bound, en_input_bound;
     int en_state_soc, en_input_soc, en_state_linear, en_input_linear;
 
+    /* adaptive rho (types.hpp:69-73, 50-54; admm.cpp:117-174; rho_benchmark.cpp). Pinned against the
+     * reference's own core compiled with zero-initialised automatic variables (oracle/Makefile, target
+     * ref_zeroinit): the snapshot reads RhoAdapter::matrices_initialized uninitialised (admm.cpp:118). */
+    int adaptive_rho;
+    double adaptive_rho_min, adaptive_rho_max;
+    int adaptive_rho_enable_clipping;
+    double *dKinf_drho, *dPinf_drho; /* nu x nx, nx x nx (dC1/dC2 only touch C1/C2, which no solve phase reads) */
+
     /* TinySolution (types.hpp:32-37) */
     int sol_iter, solved;
     double *sol_x, *sol_u;
@@ -115,6 +123,11 @@ void orc_update_settings(orc_solver *s, double abs_pri_tol, double abs_dua_tol, 
                          int en_state_soc, int en_input_soc, int en_state_linear,
                          int en_input_linear); /* bindings.cpp:548-603 */
 void orc_get_stats(orc_solver *s, int *istats, double *dstats);
+/* adaptive rho: settings (tiny_api.cpp:225-229 defaults: off, 1.0, 100.0, clip) and sensitivity matrices */
+void orc_set_adaptive_rho(orc_solver *s, int enabled, double rho_min, double rho_max, int clip);
+int orc_set_sensitivity(orc_solver *s, const double *dKinf_drho, const double *dPinf_drho);
+/* benchmark_rho_adaptation (rho_benchmark.cpp:200-249) on the current workspace; returns the new rho */
+double orc_rho_adaptation(orc_solver *s);
 void orc_set_iter(orc_solver *s, int iter);
 
 #ifdef __cplusplus

@@ -335,13 +335,6 @@ def test_full_size_batch_properties(pkg):
     s.reset()
 
 
-def test_unimplemented_paths_fail_loudly(pkg):
-    s2 = make_solver(pkg, pkg.problems.cartpole(), {})
-    with pytest.raises(pkg.TinyMPCError):
-        s2.update_settings(adaptive_rho=True)
-    s2.reset()
-
-
 @pytest.mark.parametrize("batch", [1, 6])
 def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a

@@ -77,6 +77,7 @@ SIGNATURES = {
     "tinympc_set_x0_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
     "tinympc_set_x0_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_int, C.c_int]),
     "tinympc_reset_workspace": (C.c_int, [Handle]),
+    "tinympc_get_rho_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
     "tinympc_get_solution_batch": (C.c_int, [Handle, c_double_p, c_double_p, C.c_int, C.c_int]),
     "tinympc_get_first_controls_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
     "tinympc_get_stats_batch": (C.c_int, [Handle, c_int_p, c_int_p, c_double_p, C.c_int, C.c_int]),

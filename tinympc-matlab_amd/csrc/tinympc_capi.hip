@@ -77,6 +77,8 @@ struct tinympc_solver {
     int *dinfo = nullptr;
     // the .m class's own Riccati helpers (compute_cache_terms / solve_lqr / compute_sensitivity_autograd)
     double *dQfull = nullptr, *dRfull = nullptr, *dlqr_scratch = nullptr, *dlqr_out = nullptr;  // dlqr_out: 3 x cache_doubles()
+    // adaptive rho: sensitivities dKinf/drho, dPinf/drho (zeros until set), kernel tables, per-instance rho
+    double *ddK = nullptr, *ddP = nullptr, *dadapt = nullptr, *drho_inst = nullptr;
     size_t cache_doubles() const { return (size_t)nu * nx + (size_t)2 * nx * nx + (size_t)nu * nu; }  // K | P | C1 | C2
     // user-layout bounds / refs
     double *dxmin = nullptr, *dxmax = nullptr, *dumin = nullptr, *dumax = nullptr, *dXref = nullptr, *dUref = nullptr;
@@ -255,11 +257,18 @@ int refresh_families(tinympc_solver *s) {
 }
 
 int launch(tinympc_solver *s, bool timed) {
-    if (s->st.adaptive_rho)
-        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6)");
     int rc = refresh_derived(s);
     if (rc) return rc;
     const bool fam = s->families_active();
+    const bool adaptive = s->st.adaptive_rho != 0;
+    if (adaptive && fam)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
+    if (adaptive) {  // tiny tables from the current cache, sensitivities and Xref; rebuilt per launch (a few microseconds)
+        AdaptTableParams a{};
+        a.nx = s->nx; a.nu = s->nu; a.N = s->N; a.W = s->W; a.KT = s->KT;
+        a.A = s->dA; a.B = s->dB; a.Pinf = s->dPinf; a.dK = s->ddK; a.dP = s->ddP; a.Xref = s->dXref; a.out = s->dadapt;
+        HIP_TRY(launch_build_adapt(a, s->stream));
+    }
     if (fam && (rc = refresh_families(s))) return rc;
     SolveParams p{};
     p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = s->batch;
@@ -273,8 +282,14 @@ int launch(tinympc_solver *s, bool timed) {
     p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
+    p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
+    p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-    if (fam) {
+    if (adaptive) {
+        // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
+        p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
+        HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (fam) {
         // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
         // handle can switch between them from one solve to the next.
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
@@ -407,6 +422,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dAPf, nx)); TRY(dalloc(s, &s->dBPf, nu)); TRY(dalloc(s, &s->dinfo, 4));
     TRY(dalloc(s, &s->dscratch, precompute_scratch_doubles(nx, nu) + 8));
     TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
+    TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
+    TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));
     TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));
@@ -428,6 +445,9 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(fill_host_upload(s, s->dxmin, X, -kBoundInf)); TRY(fill_host_upload(s, s->dxmax, X, kBoundInf));
     TRY(fill_host_upload(s, s->dumin, U, -kBoundInf)); TRY(fill_host_upload(s, s->dumax, U, kBoundInf));
     // Everything tiny_setup zeroes (tiny_api.cpp:41-44, 73-88, 100-111)
+    HIP_TRY_S(hipMemsetAsync(s->ddK, 0, sizeof(double) * nu * nx, s->stream));
+    HIP_TRY_S(hipMemsetAsync(s->ddP, 0, sizeof(double) * nx * nx, s->stream));
+    TRY(fill_host_upload(s, s->drho_inst, batch, rho));
     HIP_TRY_S(hipMemsetAsync(s->dXref, 0, sizeof(double) * X, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dUref, 0, sizeof(double) * U, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->dx0, 0, sizeof(double) * batch * nx, s->stream));
@@ -685,7 +705,12 @@ int tinympc_codegen_with_sensitivity(tinympc_solver *s, const char *output_dir, 
     int rc = check_handle(s);
     if (rc) return rc;
     if (!dK || !dP || !dC1 || !dC2) return fail(TINYMPC_ERR_INVALID_INPUT, "codegen_with_sensitivity requires dK, dP, dC1, dC2");
-    // the four matrices reach the generated cache only while adaptive_rho is enabled (codegen.cpp:79-86, 237-252)
+    // the four matrices reach the cache (and the generated file) only while adaptive_rho is enabled (codegen.cpp:79-86, 237-252)
+    if (s->st.adaptive_rho) {
+        if ((rc = bind_device(s))) return rc;
+        if ((rc = upload(s, s->ddK, dK, (size_t)s->nu * s->nx))) return rc;
+        if ((rc = upload(s, s->ddP, dP, (size_t)s->nx * s->nx))) return rc;
+    }
     return codegen_from_handle(s, output_dir, dK, dP, dC1, dC2, verbose);
 }
 
@@ -693,8 +718,13 @@ int tinympc_set_sensitivity_matrices(tinympc_solver *s, const double *dK, const 
     int rc = check_handle(s);
     if (rc) return rc;
     if (!dK || !dP || !dC1 || !dC2) return fail(TINYMPC_ERR_INVALID_INPUT, "set_sensitivity_matrices requires 4 matrices");
-    // The reference stores nothing here either (bindings.cpp:338-352): the matrices only feed codegen.
-    if (verbose) printf("Sensitivity matrices accepted (unused: adaptive rho / codegen are out of scope)\n");
+    // bindings.cpp:338-352 only prints their norms; the old core's adaptive-rho update reads them from the cache
+    // (rho_benchmark.cpp:205-208), which is where they go here: dKinf/drho and dPinf/drho feed k_admm_solve_adapt
+    // (dC1/dC2 would update C1/C2, which no solve phase reads).
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = upload(s, s->ddK, dK, (size_t)s->nu * s->nx))) return rc;
+    if ((rc = upload(s, s->ddP, dP, (size_t)s->nx * s->nx))) return rc;
+    if (verbose) printf("Sensitivity matrices set\n");
     return TINYMPC_OK;
 }
 
@@ -804,8 +834,6 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
     s->st.adaptive_rho_max = adaptive_rho_max; s->st.adaptive_rho_enable_clipping = adaptive_rho_enable_clipping;
     if (bounds_changed) s->tables_dirty = true;
     s->fam_dirty = true;  // the family enable flags are folded into the per-lane family description
-    if (adaptive_rho)
-        return fail(TINYMPC_ERR_NOT_IMPLEMENTED, "adaptive_rho is out of scope for this build (SURVEY.md section 2 #6); solve will refuse to run while it is enabled");
     if (verbose) printf("Settings updated successfully\n");
     return TINYMPC_OK;
 }
@@ -944,7 +972,16 @@ int tinympc_reset_workspace(tinympc_solver *s) {
     HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));
     HIP_TRY(hipMemsetAsync(s->ddstats, 0, sizeof(double) * s->batch * 4, s->stream));
-    return TINYMPC_OK;
+    return fill_host_upload(s, s->drho_inst, s->batch, s->rho);  // adapted rho back to the setup value
+}
+
+int tinympc_get_rho_batch(tinympc_solver *s, double *rho_out, int first, int count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!rho_out || first < 0 || count < 0 || first + count > s->batch)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "get_rho_batch: range [%d, %d) outside the batch of %d", first, first + count, s->batch);
+    if ((rc = bind_device(s))) return rc;
+    return download(s, rho_out, s->drho_inst + first, sizeof(double) * count);
 }
 
 int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u) {

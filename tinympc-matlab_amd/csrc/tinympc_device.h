@@ -109,6 +109,24 @@ struct SolveParams {
     const double *fam;  // per-lane family description, see fam_doubles()
     double *GC, *GL;    // [groups][v_rows(N)][64]  duals gc|yc and gl|yl, persistent across solves
     double *LX;         // [groups][v_rows(N)][64]  -rho*(vcnew-gc) - rho*(vlnew-gl), forward -> backward
+    // Adaptive rho (k_admm_solve_adapt only)
+    const double *adapt;  // tables of k_build_adapt, see adapt_doubles()
+    double *rho_inst;     // [batch] current rho of every instance; persists across solves like the reference's cache->rho
+    double rho_min, rho_max;
+    int rho_clip;
+};
+
+// Tables of the adaptive-rho kernel, doubles: mt | pinf | dpinf | dmf | dmb, each [W][KT], then dpnref[W]
+//   mt     [A'; B'] rows                       (the A_matrix' * y_vector term of the dual residual)
+//   pinf   rows of the base Pinf, dpinf of dPinf/drho
+//   dmf    d/drho of the forward operator rows  [ -B*dK | 0 ] / [ -dK | 0 ]
+//   dmb    d/drho of the backward operator rows [ 0 | -dK' ] / 0
+//   dpnref d/drho of -(Xref_{N-1}' Pinf)'
+__host__ __device__ inline size_t adapt_doubles(int W, int KT) { return (size_t)5 * W * KT + W; }
+struct AdaptTableParams {
+    int nx, nu, N, W, KT;
+    const double *A, *B, *Pinf, *dK, *dP, *Xref;
+    double *out;
 };
 
 // Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
@@ -141,6 +159,9 @@ size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
 constexpr int WAVES_PER_GROUP_B = 4;
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+// Layout A plus adaptive rho (per-instance rho, Taylor-updated operators).
+hipError_t launch_solve_adapt(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_build_adapt(const AdaptTableParams &p, hipStream_t stream);
 // Raise a kernel's dynamic-LDS limit to `bytes` unless a previous launch on this device already did
 // (the attribute is sticky per function and device; re-setting it costs ~5 us per launch, which matters
 // for the per-tick latency of closed-loop callers). `cache` is one static array per kernel instantiation.

@@ -8,8 +8,8 @@ classdef TinyMPC < handle
     % calls the C ABI of libtinympc_hip.so (include/tinympc_hip.h). The ADMM solve itself runs as one
     % HIP kernel on the GPU; this file only shapes arguments.
     %
-    % Out of scope on this build (raises): adaptive_rho. codegen / codegen_with_sensitivity write the data files
-    % from the cache on the device.
+    % codegen / codegen_with_sensitivity write the data files from the cache on the device; adaptive_rho runs the
+    % old core's adaptive-rho loop on the device (per instance).
     % compute_cache_terms / solve_lqr / compute_sensitivity_autograd run on the device (extra MEX verbs).
     % get_stats and get_cache are additions.
 

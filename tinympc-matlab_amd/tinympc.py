@@ -363,6 +363,14 @@ class TinyMPC:
                                                    _p(res), first, count))
         return dict(iter=it, status=st, residuals=res)
 
+    def get_rho_batch(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """Current rho of every instance (adaptive rho adapts it per instance and keeps it across solves)."""
+        self._check_setup()
+        count = self.batch - first if count is None else count
+        rho = np.zeros(count)
+        _lib.check(self._L.tinympc_get_rho_batch(self._h, _p(rho), first, count))
+        return rho
+
     def launch_info(self) -> dict:
         self._check_setup()
         v = [C.c_int() for _ in range(5)]
