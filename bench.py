@@ -233,11 +233,12 @@ def main() -> int:
             "solves_per_s": value / args.iters,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                         "kernel": "k_admm_solve<16,16>", "kernel_ms_avg": kernel_ms_avg,
+                         "kernel": {"A": "k_admm_solve", "B": "k_admm_solve_b", "C": "k_admm_solve_c"}.get(info.get("layout"), "k_admm_solve")
+                                   + "<%d lanes/instance>" % info["lanes_per_instance"], "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_instance_iteration": bytes_iter,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "note": "ADMM state is LDS-resident for the whole solve, so measured HBM traffic is far below the "
-                                 "algorithmic (streaming) bytes and frac may exceed 1; the kernel is FP64-issue bound",
+                         "note": "ADMM state stays on chip for the whole solve (LDS + L2), so measured HBM traffic is far below "
+                                 "the algorithmic (streaming) bytes and frac may exceed 1; the kernel is FP64-issue bound",
                          "fp64_tflops": count * args.iters * flops_iter / kernel_s / 1e12,
                          "fp64_frac_of_vector_peak": count * args.iters * flops_iter / kernel_s / 1e12 / PEAK_FP64_TFLOPS},
             "launch": info,
@@ -256,7 +257,8 @@ def main() -> int:
             ms = sorted(ms[3:])
             med = ms[len(ms) // 2]
             out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
-                                      "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                                      "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      "layout": one.launch_info()["layout"]}
             one.reset()
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -21,11 +21,12 @@ assert TOL < TOL_BAR
 SINGLE = ["cartpole_unconstrained", "cartpole_box_tol", "cartpole_box_200", "quadrotor_box_200", "quadrotor_box_tol"]
 
 
-@pytest.fixture(autouse=True, params=["A", "B"])
+@pytest.fixture(autouse=True, params=["A", "B", "C"])
 def kernel_layout(request, monkeypatch):
-    """Every test runs against both solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip)
-    and layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip). The layout is
-    chosen at setup time; where B does not apply (W > 16 or N < 8) the library falls back to A."""
+    """Every test runs against all three solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip),
+    layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip) and layout C (one instance per
+    workgroup, horizon swept in 16 concurrent chunks, tinympc_solve_c.hip). The layout is chosen at setup time;
+    where B does not apply (W > 16 or N < 8) or C does not (W > 16 or N > 129) the library falls back."""
     monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
     return request.param
 
@@ -63,10 +64,19 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     monkeypatch.delenv("TINYMPC_LAYOUT")
     s = make_solver(pkg, P.quadrotor(50), {}, batch=8)
     info = s.launch_info()
-    assert info["layout"] == "B" and info["workgroups"] == 1 and info["lds_bytes"] <= 160 * 1024  # default: B where it fits
+    assert info["layout"] == "C" and info["workgroups"] == 8  # default for small batches: the latency kernel
     s.reset()
+    s = make_solver(pkg, P.quadrotor(50), {}, batch=1024)
+    info = s.launch_info()
+    assert info["layout"] == "B" and info["workgroups"] == 64 and info["lds_bytes"] <= 160 * 1024  # large batch: B where it fits
+    s.reset()
+    monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})
     assert s.launch_info()["layout"] == "A"  # N < 8: layout B's 4-deep prefetch ring does not apply
+    s.reset()
+    monkeypatch.setenv("TINYMPC_LAYOUT", "C")
+    s = make_solver(pkg, P.cartpole(200, True), {})
+    assert s.launch_info()["layout"] in ("A", "B")  # N > 129: more than 8 steps per chunk, layout C does not apply
     s.reset()
 
 

@@ -60,6 +60,7 @@ struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings
 };
 
 constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
+constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
 
 }  // namespace
 
@@ -92,6 +93,10 @@ struct tinympc_solver {
     size_t lds_bytes = 0;
     bool tables_in_lds = false;
     bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
+    bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
+    int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
+    size_t lds_bytes_c = 0;
+    double *dctab = nullptr;
     double *dV2 = nullptr;
     int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
     // cone / linear families (host copies of what the verbs received; k_admm_solve_fam consumes `dfam`)
@@ -178,6 +183,12 @@ int refresh_derived(tinympc_solver *s) {
         p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
         p.ops = s->dops;
         HIP_TRY(launch_build_operators(p, s->stream));
+        if (s->layout_c) {  // powers of the sweep operators for the chunked kernel
+            ChunkTableParams c{};
+            c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->chunk_len; c.Lc = s->chunk_levels;
+            c.ops = s->dops; c.out = s->dctab;
+            HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        }
         s->ops_dirty = false;
         s->tables_dirty = true;
     }
@@ -294,6 +305,9 @@ int launch(tinympc_solver *s, bool timed) {
         // handle can switch between them from one solve to the next.
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (s->layout_c) {
+        p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
+        HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
     } else if (s->layout_b) {
         HIP_TRY(launch_solve_b(p, s->W, s->KT, s->lds_bytes, s->stream));
     } else {
@@ -412,6 +426,18 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
             s->tables_in_lds = true;
             s->lds_bytes = b_bytes;
         }
+        // Layout C gives every instance a whole workgroup and cuts the horizon into 16 concurrent chunks: a
+        // 2-3x shorter iteration for one instance, lower throughput once the batch fills the chip's wave slots.
+        // Default for small batches; TINYMPC_LAYOUT=C forces it, =A / =B exclude it.
+        chunk_plan(N, &s->chunk_len, &s->chunk_count, &s->chunk_levels);
+        s->lds_bytes_c = solve_c_lds_bytes(KT, s->chunk_levels);
+        const bool c_possible = (W == 16) && (s->chunk_len <= 8) && (s->lds_bytes_c <= kLdsMax);
+        bool want_c = c_possible && batch <= kLayoutCBatchMax;
+        if (const char *env = getenv("TINYMPC_LAYOUT")) {
+            if (env[0] == 'C' || env[0] == 'c') want_c = c_possible;
+            else if (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b') want_c = false;
+        }
+        s->layout_c = want_c;
     }
 
     const size_t X = s->X(), U = s->U();
@@ -424,6 +450,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
     TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
     TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));
+    if (s->layout_c) TRY(dalloc(s, &s->dctab, chunk_table_doubles(KT, s->chunk_levels)));
     TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));
@@ -998,13 +1025,13 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)s->lds_bytes;
     if (tables_in_lds) *tables_in_lds = s->tables_in_lds ? 1 : 0;
     return TINYMPC_OK;
 }
 
-int tinympc_get_layout(tinympc_solver *s) { return s ? (s->layout_b ? 'B' : 'A') : 0; }
+int tinympc_get_layout(tinympc_solver *s) { return s ? (s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
 
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 

@@ -114,6 +114,15 @@ struct SolveParams {
     double *rho_inst;     // [batch] current rho of every instance; persists across solves like the reference's cache->rho
     double rho_min, rho_max;
     int rho_clip;
+    // Layout C (k_admm_solve_c): horizon cut into chunk_count chunks of chunk_len steps, see chunk_plan()
+    const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][KT]: powers S*2^l of the sweeps' state blocks
+    int chunk_len, chunk_count, chunk_levels;
+};
+
+struct ChunkTableParams {
+    int nx, nu, KT, S, Lc;
+    const double *ops;  // fused operators of k_build_operators
+    double *out;        // chunk_table_doubles(KT, Lc)
 };
 
 // Tables of the adaptive-rho kernel, doubles: mt | pinf | dpinf | dmf | dmb, each [W][KT], then dpnref[W]
@@ -159,6 +168,13 @@ size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
 constexpr int WAVES_PER_GROUP_B = 4;
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+// Layout C: one instance per 256-thread workgroup, the horizon swept in 16 concurrent chunks (latency kernel
+// for small batches). W = 16, N <= 129.
+hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_build_chunk_tables(const ChunkTableParams &p, hipStream_t stream);
+void chunk_plan(int N, int *S, int *C, int *Lc);
+size_t solve_c_lds_bytes(int KT, int Lc);
+size_t chunk_table_doubles(int KT, int Lc);
 // Layout A plus adaptive rho (per-instance rho, Taylor-updated operators).
 hipError_t launch_solve_adapt(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_build_adapt(const AdaptTableParams &p, hipStream_t stream);

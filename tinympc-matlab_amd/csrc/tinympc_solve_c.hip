@@ -1,0 +1,380 @@
+// tinympc_solve_c.hip -- k_admm_solve_c ("layout C"): ONE MPC instance per workgroup, horizon cut into chunks
+// that 16 lane groups sweep concurrently. The latency kernel: small batches and the single-instance solve.
+//
+// Layouts A/B give an instance 16 lanes and walk the N-1 steps of each Riccati-style sweep one after the other:
+// 98 dependent mat-vecs per ADMM iteration, ~100 ns each, whatever the batch size. Both sweeps are linear
+// time-invariant recurrences, so they can be cut in time:
+//     forward   [x_{k+1}; u_k] = Mf [x_k; d_k] + cf                  (admm.cpp:25-35,  Phi = A - B*Kinf)
+//     backward  [p_k;    d_k] = Mb [p_{k+1}; r_k] + [q_k;0] + cb     (admm.cpp:13-20,  Psi = AmBKt)
+//   pass 1  every chunk c (S consecutive steps, one 16-lane group) runs its S steps from a ZERO incoming state
+//           (chunk 0: from x_0; the last chunk of the backward sweep: from p_{N-1}) -- only the end value is kept;
+//   carry   the true state after chunk c is  X_c = end_c + Phi^S X_{c-1}: a Hillis-Steele scan over the C <= 16
+//           chunks with the precomputed powers Phi^(S*2^l) -- log2(C) mat-vecs, values exchanged through LDS;
+//   pass 2  the chunk is swept again from its true incoming state X_{c-1}: these are the sweep's real values.
+// Depth per sweep: 2*S + log2(C) mat-vecs instead of N-1 (quadrotor N=50: 12 instead of 49). Passes 1 and 2 use
+// the lane's rows of Mf / Mb, resident in registers; only the carry matrices come from LDS. (A variant that
+// replaced pass 2 by S independent "fix-up" mat-vecs with precomputed [Phi^(i+1); -Kinf Phi^i] was slower: four
+// wavefronts fetching 2 KB matrix rows per mat-vec saturate the CU's single 128 B/clk LDS port.)
+// Everything row-local (slack projection, dual update, linear cost, residual maxima) happens where the row lives,
+// exactly as in the other layouts; each lane keeps its <= SMAX (knot,row) elements of g|y, v|z, d and the matching
+// table entries in REGISTERS for the whole solve -- HBM is read once and written once.
+// Given exact carries pass 2 IS the sequential sweep, so results differ from layouts A/B only through the rounding
+// of the carries (~1e-14 relative); iteration counts match the reference in every test.
+#include "tinympc_device.h"
+#include "tinympc_sweep.h"
+
+namespace tinympc {
+
+namespace {
+constexpr int CW = 16;          // lanes per group
+constexpr int CGROUPS = 16;     // groups per workgroup (256 threads)
+constexpr int CTHREADS = CW * CGROUPS;
+
+// Rows of the LDS-resident matrices are KT + 2 doubles apart: with a stride of KT the 16 lanes of a group would
+// hit 2 (KT = 16) or 4 (KT = 8) bank groups with their 16-byte reads; +2 spreads them over all 64 banks.
+template <int KT>
+__device__ __forceinline__ void load_row(const double *M, int r, double (&m)[KT]) {
+    const double *row = M + r * (KT + 2);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) m[k] = row[k];
+}
+
+// Max over the 16 lanes of a DPP row with rotations inside the row (no LDS crossbar round trips). 64-bit DPP moves
+// only exist for row_newbcast on this target, so the value travels as two 32-bit halves; the max is asm because
+// fmax() adds a canonicalising v_max_f64 per operand. Nothing is volatile: callers reduce four quantities back to
+// back and the scheduler interleaves them.
+__device__ __forceinline__ double row_max(double v) {
+#define TINY_STAGE(n)                                                                                        \
+    {                                                                                                        \
+        const int tlo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + (n), 0xf, 0xf, false);     \
+        const int thi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + (n), 0xf, 0xf, false);     \
+        const double t = __hiloint2double(thi, tlo);                                                         \
+        asm("v_max_f64 %[o], %[a], %[b]" : [o] "=v"(v) : [a] "v"(v), [b] "v"(t));                            \
+    }
+    TINY_STAGE(8) TINY_STAGE(4) TINY_STAGE(2) TINY_STAGE(1)
+#undef TINY_STAGE
+    return v;
+}
+}  // namespace
+
+// ---- carry matrices PhiS_l = Phi^(S 2^l) | PsiS_l = Psi^(S 2^l)  (l < Lc), each [16][KT] row-major, zero outside
+//      the nx x nx state block; Phi, Psi are the state blocks of the fused operators of k_build_operators
+__global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTableParams p) {
+    __shared__ double Base[256], Cur[256], Tmp[256];
+    const int nx = p.nx, KT = p.KT, S = p.S, Lc = p.Lc, tid = threadIdx.x;
+    const int r = tid / 16, k = tid % 16;  // 16 x 16 working matrices
+    const size_t M = (size_t)CW * KT;
+    const bool in = (r < nx) && (k < nx);
+    for (size_t i = tid; i < (size_t)2 * Lc * M; i += 256) p.out[i] = 0.0;
+    __syncthreads();
+    auto mul = [&](double *Cm, const double *Am, const double *Bm) {  // Cm = Am * Bm (16 x 16, LDS)
+        double acc = 0.0;
+        for (int j = 0; j < nx; ++j) acc += Am[r * 16 + j] * Bm[j * 16 + k];
+        __syncthreads();
+        Cm[tid] = in ? acc : 0.0;
+        __syncthreads();
+    };
+    for (int which = 0; which < 2; ++which) {
+        const double *Op = p.ops + (size_t)which * M;  // Mf, then Mb
+        double *dst = p.out + (size_t)which * Lc * M;
+        Base[tid] = in ? Op[r * KT + k] : 0.0;
+        Cur[tid] = (r == k && r < nx) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int i = 0; i < S; ++i) {  // Cur = Base^S
+            mul(Tmp, Base, Cur);
+            Cur[tid] = Tmp[tid];
+            __syncthreads();
+        }
+        for (int l = 0; l < Lc; ++l) {  // Base^(S 2^l)
+            if (in) dst[(size_t)l * M + r * KT + k] = Cur[tid];
+            mul(Tmp, Cur, Cur);
+            Cur[tid] = Tmp[tid];
+            __syncthreads();
+        }
+    }
+}
+
+hipError_t launch_build_chunk_tables(const ChunkTableParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_chunk_tables, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+void chunk_plan(int N, int *S, int *C, int *Lc) {
+    const int T = N - 1;
+    *S = (T + CGROUPS - 1) / CGROUPS;
+    *C = (T + *S - 1) / *S;
+    int l = 0;
+    while ((1 << l) < *C) ++l;
+    *Lc = l;
+}
+
+size_t chunk_table_doubles(int KT, int Lc) { return (size_t)2 * Lc * CW * KT; }
+
+size_t solve_c_lds_bytes(int KT, int Lc) {
+    // carry matrices + carry ping-pong Y[2][256] + boundary q Q[256] + residual partials R[16][4]
+    return sizeof(double) * ((size_t)2 * Lc * CW * (KT + 2) + 2 * 256 + 256 + 64);
+}
+
+template <int KT, int SMAX>
+__global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
+    const int nx = p.nx, nu = p.nu, N = p.N, T = N - 1, nxu = nx + nu;
+    const int S = p.chunk_len, C = p.chunk_count, Lc = p.chunk_levels;
+    const long inst = blockIdx.x;
+    const bool is_x = r < nx;
+    const bool is_u = (r >= nx) && (r < nxu);
+    const bool row_ok = r < nxu;
+    const size_t M = (size_t)CW * KT;         // one matrix in the global tables
+    const size_t ML = (size_t)CW * (KT + 2);  // and in LDS (padded rows)
+    double *sTab = smem;
+    double *sY = sTab + (size_t)2 * Lc * ML;  // [2][256]
+    double *sQ = sY + 512;                    // [256]
+    double *sR = sQ + 256;                    // [16][4]
+    const double *PH = sTab, *PS = PH + (size_t)Lc * ML;
+    for (int i = tid; i < 2 * Lc * (int)M; i += CTHREADS) {
+        const int mat = i / (int)M, rem = i % (int)M;
+        sTab[(size_t)mat * ML + (rem / KT) * (KT + 2) + rem % KT] = p.ctab[i];
+    }
+
+    // canonical HBM layout shared with the other kernels (instance = lane group inst%4 of wave group inst/4)
+    const long wg = inst >> 2;
+    const int jj = (int)(inst & 3);
+    const int dstride = 4 * nu;
+    double *gG = p.G + (size_t)wg * (N + 1) * 64 + jj * 16 + r;
+    double *gV = p.V + ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;
+    double *gD = p.D + (size_t)wg * (N - 1) * dstride + jj * nu + (is_u ? r - nx : 0);
+    const int TOFF = (int)table_rows(N) * CW;
+
+    // ---- this lane's elements: slot i <-> step k = c*S + i; state lanes own knot k+1, input lanes knot k
+    double g[SMAX], v[SMAX], lo[SMAX], hi[SMAX], lr[SMAX], dd[SMAX];
+    bool ok[SMAX];     // slot holds a real element of this lane
+    bool step[SMAX];   // slot is a real step of this group (uniform over the group)
+    const int koff = is_x ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i) {
+        const int k = c * S + i;
+        step[i] = (i < S) && (k < T);
+        ok[i] = step[i] && row_ok;
+        const int kn = k + koff;
+        g[i] = ok[i] ? gG[(size_t)kn * 64] : 0.0;
+        v[i] = ok[i] ? gV[(size_t)kn * 64] : 0.0;
+        dd[i] = (step[i] && is_u) ? gD[(size_t)k * dstride] : 0.0;
+        lo[i] = ok[i] ? p.tables[(size_t)(kn + 1) * CW + r] : 0.0;
+        hi[i] = ok[i] ? p.tables[(size_t)TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
+        lr[i] = ok[i] ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
+    }
+    // knot 0 of the state rows: group 0, state lanes
+    const bool k0 = (c == 0) && is_x;
+    double g0 = k0 ? gG[0] : 0.0, v0 = k0 ? gV[0] : 0.0;
+    const double lo0 = k0 ? p.tables[CW + r] : 0.0, hi0 = k0 ? p.tables[(size_t)TOFF + CW + r] : 0.0;
+    const double x0v = k0 ? p.x0[inst * nx + r] : 0.0;
+
+    double mf[KT], mb[KT];
+    {
+        const double *Mf = p.ops + (size_t)r * KT, *Mb = p.ops + M + (size_t)r * KT;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            mf[k] = Mf[k];
+            mb[k] = Mb[k];
+        }
+    }
+    const double cf = p.ops[2 * M + r];
+    const double cb = p.ops[2 * M + CW + r];
+    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    const double rho = p.rho;
+    const int ct = p.check_termination;
+    const int i_last = (T - 1) - (C - 1) * S;  // slot of the last step, in group C-1
+    __syncthreads();
+
+    int it_done = 0, status = 11;
+    bool res_valid = false, converged = false;
+    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    double vprev[SMAX], v0prev = v0;
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i) vprev[i] = v[i];
+    int cur = 0;  // carry ping-pong buffer
+
+    // Carry scan: acc_c += Pm_l * acc_(c + dir*2^l), l = 0..Lc-1. The rows of a level are requested before its
+    // exchange; only the state lanes hold non-zero rows, so only they load (a quarter less LDS traffic).
+    auto carry_scan = [&](int dir, const double *Pm, double &acc) {
+        for (int l = 0; l < Lc; ++l) {
+            double m[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) m[k] = 0.0;
+            if (is_x) load_row<KT>(Pm + (size_t)l * ML, r, m);
+            const int nb = c + dir * (1 << l);
+            sY[cur * 256 + tid] = acc;
+            __syncthreads();
+            const double o = (nb >= 0 && nb < CGROUPS && is_x) ? sY[cur * 256 + nb * 16 + r] : 0.0;
+            acc += group_matvec<CW, KT>(m, o, 0.0);
+            cur ^= 1;
+        }
+    };
+
+    for (int it = 0; it < p.max_iter; ++it) {
+        const bool check = (ct > 0) && (((it + 1) % ct) == 0);
+        // ================= forward sweep =================
+        double out[SMAX];
+        {   // pass 1: end state of the chunk from a zero incoming state (chunk 0: from x_0)
+            double xt = x0v;
+#pragma unroll
+            for (int i = 0; i < SMAX; ++i)
+                if (i < S) {
+                    const double o = group_matvec<CW, KT>(mf, is_x ? xt : dd[i], cf);
+                    xt = step[i] ? o : xt;
+                }
+            double Xc = (is_x && c < C) ? xt : 0.0;
+            carry_scan(-1, PH, Xc);
+            sY[cur * 256 + tid] = Xc;
+            __syncthreads();
+            // pass 2: the real sweep, from the true state entering the chunk
+            xt = (c >= 1 && is_x) ? sY[cur * 256 + (c - 1) * 16 + r] : x0v;
+            cur ^= 1;
+#pragma unroll
+            for (int i = 0; i < SMAX; ++i) {
+                out[i] = 0.0;
+                if (i < S) {
+                    out[i] = group_matvec<CW, KT>(mf, is_x ? xt : dd[i], cf);  // state lanes x_{k+1}, input lanes u_k
+                    xt = step[i] ? out[i] : xt;
+                }
+            }
+        }
+
+        // ================= row-local phases (S1, D1, R1) =================
+        double pri = 0.0, dua = 0.0;
+        if (k0) {
+            const double s = x0v + g0;
+            const double snew = fmin(hi0, fmax(lo0, s));
+            pri = fabs(x0v - snew);
+            dua = fabs(v0 - snew);
+            v0prev = v0;
+            g0 = s - snew;
+            v0 = snew;
+        }
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) {
+            double gnew, snew, tp = 0.0, td = 0.0;
+            project_element(out[i], g[i], lo[i], hi[i], v[i], gnew, snew, tp, td);
+            vprev[i] = v[i];
+            if (ok[i]) {
+                g[i] = gnew;
+                v[i] = snew;
+                pri = fmax(pri, tp);
+                dua = fmax(dua, td);
+            }
+        }
+        it_done = it + 1;
+        // linear cost of the backward sweep; its chunk-boundary exchange shares the barrier of the residual exchange
+        double lin[SMAX];
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) lin[i] = lr[i] - rho * (v[i] - g[i]);  // q_{k+1} (state lanes) | r_k (input lanes)
+        {   // q_k of a chunk's first step lives in the previous group (its last state slot)
+            double qlast = 0.0;
+#pragma unroll
+            for (int i = 0; i < SMAX; ++i) qlast = (i == S - 1) ? lin[i] : qlast;
+            sQ[tid] = qlast;
+        }
+        if (check) {
+            const double gpx = row_max(is_x ? pri : 0.0), gpu_ = row_max(is_u ? pri : 0.0);
+            const double gdx = row_max(is_x ? dua : 0.0), gdu = row_max(is_u ? dua : 0.0);
+            if (r < 4) sR[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gpu_ : (r == 2) ? gdx : gdu;
+        }
+        __syncthreads();
+        if (check) {
+            const double px = row_max(sR[r * 4 + 0]), pu = row_max(sR[r * 4 + 1]);
+            const double dx = row_max(sR[r * 4 + 2]) * rho, du = row_max(sR[r * 4 + 3]) * rho;
+            res_px = px; res_dx = dx; res_pu = pu; res_du = du;
+            res_valid = true;
+            if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
+                status = 1;  // uniform over the workgroup: one instance
+                converged = true;
+                break;
+            }
+        }
+
+        // ================= backward sweep =================
+        {
+            double pterm = 0.0;
+#pragma unroll
+            for (int i = 0; i < SMAX; ++i) pterm = (i == i_last) ? (pnref - rho * (v[i] - g[i])) : pterm;  // p_{N-1}, admm.cpp:81-82
+            const double qin = (c >= 1 && is_x) ? sQ[(c - 1) * 16 + r] : 0.0;
+            const double pend = (c == C - 1 && is_x) ? pterm : 0.0;
+            // pass 1: p at the chunk's first knot from a zero incoming p (last chunk: from p_{N-1})
+            double pcur = pend;
+#pragma unroll
+            for (int i = SMAX - 1; i >= 0; --i)
+                if (i < S) {
+                    const double qk = (i >= 1) ? lin[i >= 1 ? i - 1 : 0] : qin;
+                    const double o = group_matvec<CW, KT>(mb, is_x ? pcur : lin[i], cb);
+                    pcur = step[i] ? (qk + o) : pcur;
+                }
+            double Pc = (is_x && c < C) ? pcur : 0.0;
+            carry_scan(+1, PS, Pc);
+            sY[cur * 256 + tid] = Pc;
+            __syncthreads();
+            // pass 2: the real sweep, from the true p entering the chunk; only d_k is kept
+            pcur = (c < C - 1 && is_x) ? sY[cur * 256 + (c + 1) * 16 + r] : pend;
+            cur ^= 1;
+#pragma unroll
+            for (int i = SMAX - 1; i >= 0; --i)
+                if (i < S) {
+                    const double qk = (i >= 1) ? lin[i >= 1 ? i - 1 : 0] : qin;
+                    const double o = group_matvec<CW, KT>(mb, is_x ? pcur : lin[i], cb);
+                    dd[i] = (step[i] && is_u) ? o : dd[i];
+                    pcur = step[i] ? (qk + o) : pcur;
+                }
+        }
+    }
+
+    // ---- write-back (state for the next solve, solution, stats)
+    if (p.max_iter > 0) {
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) {
+            if (ok[i]) {
+                const int k = c * S + i, kn = k + koff;
+                gG[(size_t)kn * 64] = g[i];
+                gV[(size_t)kn * 64] = converged ? vprev[i] : v[i];  // converged: the reference returns before v <- vnew
+                if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
+                else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
+            }
+            if (step[i] && is_u) gD[(size_t)(c * S + i) * dstride] = dd[i];
+        }
+        if (k0) {
+            gG[0] = g0;
+            gV[0] = converged ? v0prev : v0;
+            p.sol_x[(size_t)inst * N * nx + r] = v0;
+        }
+    }
+    if (tid == 0) {
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            p.dstats[inst * 4 + 0] = res_px;
+            p.dstats[inst * 4 + 1] = res_dx;
+            p.dstats[inst * 4 + 2] = res_pu;
+            p.dstats[inst * 4 + 3] = res_du;
+        }
+    }
+}
+
+template <int KT, int SMAX>
+static hipError_t launch_c_t(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
+    static size_t lds_set[16] = {0};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, SMAX>), lds_bytes, lds_set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_admm_solve_c<KT, SMAX>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+// One instance per workgroup; W must be 16 and the chunk length at most 8 (N <= 129).
+hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream) {
+    if (W != 16 || !p.ctab || p.chunk_len < 1 || p.chunk_len > 8 || p.chunk_count > CGROUPS) return hipErrorInvalidValue;
+    const bool small = p.chunk_len <= 4;
+    if (KT == 8) return small ? launch_c_t<8, 4>(p, lds_bytes, stream) : launch_c_t<8, 8>(p, lds_bytes, stream);
+    if (KT == 12) return small ? launch_c_t<12, 4>(p, lds_bytes, stream) : launch_c_t<12, 8>(p, lds_bytes, stream);
+    if (KT == 16) return small ? launch_c_t<16, 4>(p, lds_bytes, stream) : launch_c_t<16, 8>(p, lds_bytes, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace tinympc
