@@ -442,3 +442,43 @@ def test_long_horizon_state_in_global_memory(pkg, N):
     np.testing.assert_array_equal(st["status"], ost)
     assert rel_err(sol["states"], ox) < TOL and rel_err(sol["controls"], ou) < TOL
     s.reset()
+
+
+@pytest.mark.parametrize("N", [2, 3, 16, 17, 18, 33, 34, 49, 65, 66, 100, 129, 130])
+def test_chunked_layout_horizon_boundaries(pkg, kernel_layout, N):
+    """Layout C cuts the N-1 steps into <= 16 chunks of S = ceil((N-1)/16) steps: horizons on either side of every
+    change of S and of the chunk count, the 8-slot variant (N > 65), a partial last chunk, and N = 130 where layout
+    C no longer applies. Cold solve, warm-started second solve and a converging solve, against the oracle."""
+    if kernel_layout != "C":
+        pytest.skip("layout C only")
+    P = pkg.problems
+    for prob in (P.cartpole(N, True), P.quadrotor(N)):
+        settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=23, check_termination=2)
+        s = make_solver(pkg, prob, settings, batch=3)
+        assert (s.launch_info()["layout"] == "C") == (N <= 129)
+        x0s = np.stack([prob.x0, -0.6 * prob.x0, 0.3 * prob.x0], axis=1)
+        s.set_x0_batch(x0s)
+        orcs = [O.OraclePort(prob).load_problem(prob, settings) for _ in range(3)]
+        for solve in range(2):
+            s.solve()
+            sol, st = s.get_solution_batch(), s.get_stats_batch()
+            for b, o in enumerate(orcs):
+                o.set_x0(x0s[:, b])
+                o.solve()
+                assert st["iter"][b] == o.stats()["iter"]
+                assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL, (N, solve, b)
+                assert rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, (N, solve, b)
+        s.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=400, check_termination=1)
+        s.solve()
+        st = s.get_stats_batch()
+        for b, o in enumerate(orcs):
+            o.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=400, check_termination=1)
+            o.solve()
+            assert (st["iter"][b], st["status"][b]) == (o.stats()["iter"], o.stats()["status"]), (N, b)
+        # one more solve from the state a converged solve leaves behind (stale v/z, admm.cpp:181-197)
+        s.solve()
+        st = s.get_stats_batch()
+        for b, o in enumerate(orcs):
+            o.solve()
+            assert st["iter"][b] == o.stats()["iter"], (N, b)
+        s.reset()
