@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--worker-index", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-rocket", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -78,6 +79,27 @@ def cpu_worker(seconds: float, iters: int, horizon: int, index: int) -> int:
     while time.perf_counter() - t0 < seconds:
         total += solver.bench_solves(x0s, 1)
     print(cls.kind, total, time.perf_counter() - t0, flush=True)
+    return 0
+
+
+def cpu_worker_rocket(seconds: float, iters: int) -> int:
+    """BASELINE config 4 (rocket landing N=100, cones + linear + fdyn) on ONE host core with this repo's C
+    restatement (the reference snapshot has no source for these families). Prints 'iterations seconds'."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, ROOT)
+    import pyoracle as O  # checker / baseline only
+    import __graft_entry__ as ge
+
+    prob = ge.load_package().problems.rocket(100)
+    solver = O.OraclePort(prob).load_problem(prob, dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1))
+    total = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        solver.reset_workspace()
+        solver.set_x0(prob.x0)
+        solver.solve()
+        total += solver.stats()["iter"]
+    print(total, time.perf_counter() - t0, flush=True)
     return 0
 
 
@@ -115,7 +137,10 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     except OSError:
         pass
     value = sum(rates)
-    return {"value": value, "unit": "ADMM iters/s", "cores": len(rates), "kind": kind,
+    rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.split()
+    rocket_us = 1e6 * float(rocket[-1]) / int(rocket[-2]) if len(rocket) >= 2 and int(rocket[-2]) > 0 else None
+    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates), "kind": kind,
             "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={horizon} solves, {len(rates)} single-threaded "
                       f"processes x {seconds:.0f} s each ({wall:.1f} s wall; seeded x0, same settings as the GPU run)",
             "single_process_iters_per_s": single, "us_per_iter_single_process": 1e6 / single if single == single else None,
@@ -126,6 +151,8 @@ def main() -> int:
     args = parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_seconds, args.iters, args.horizon, args.worker_index)
+    if args.cpu_worker_rocket:
+        return cpu_worker_rocket(args.cpu_seconds, args.iters)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         return relaunch_under_torchrun(args)  # nothing has touched the GPU yet
@@ -259,6 +286,29 @@ def main() -> int:
             out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
                                       "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                       "layout": one.launch_info()["layout"]}
+            one.reset()
+            # BASELINE config 4: one rocket-landing instance, N=100, second-order cones + a linear row + fdyn
+            rk = P.rocket(100)
+            one = pkg.TinyMPC()
+            one.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=local_rank, rho=rk.rho, fdyn=rk.fdyn,
+                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
+            one.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
+            if rk.x_ref is not None:
+                one.set_x_ref(rk.x_ref)
+            if rk.u_ref is not None:
+                one.set_u_ref(rk.u_ref)
+            one.set_cone_constraints(**rk.cones)
+            if rk.linear:
+                one.set_linear_constraints(**rk.linear)
+            one.set_x0(rk.x0)
+            ms = []
+            for k in range(9):
+                one.reset_workspace()
+                ms.append(one.solve_timed())
+            med = sorted(ms[2:])[len(ms[2:]) // 2]
+            out["rocket_instance"] = {"workload": "rocket landing nx=6 nu=3 N=100, state + input cones, 1 linear row, fdyn, %d forced iterations" % args.iters,
+                                      "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
+                                      "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None}
             one.reset()
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
+@pytest.fixture(autouse=True, params=["A", "C"])
+def kernel_layout(request, monkeypatch):
+    """The families run in two kernels: k_admm_solve_fam (layout A: batches, wide systems, long horizons) and the
+    FAM variant of the latency kernel k_admm_solve_c (one instance per workgroup); every test runs against both."""
+    monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
+    return request.param
+
+
 def make(pkg, prob, settings, batch=1):
     s = pkg.TinyMPC()
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn,

@@ -300,6 +300,11 @@ int launch(tinympc_solver *s, bool timed) {
         // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (fam && s->layout_c) {
+        // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
+        p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
+        p.families = 1;
+        HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
     } else if (fam) {
         // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
         // handle can switch between them from one solve to the next.

@@ -117,6 +117,7 @@ struct SolveParams {
     // Layout C (k_admm_solve_c): horizon cut into chunk_count chunks of chunk_len steps, see chunk_plan()
     const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][KT]: powers S*2^l of the sweeps' state blocks
     int chunk_len, chunk_count, chunk_levels;
+    int families;         // layout C: run the cone / linear families too (the other layouts use k_admm_solve_fam)
 };
 
 struct ChunkTableParams {

@@ -115,7 +115,10 @@ size_t solve_c_lds_bytes(int KT, int Lc) {
     return sizeof(double) * ((size_t)2 * Lc * CW * (KT + 2) + 2 * 256 + 256 + 64);
 }
 
-template <int KT, int SMAX>
+// FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there)
+// ride on the row-local phase: every slot carries the extra duals gc|yc, gl|yl (persistent, HBM arrays GC / GL) and
+// the extra linear-cost term lx (forward -> backward, registers).
+template <int KT, int SMAX, bool FAM>
 __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
@@ -145,9 +148,12 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     double *gV = p.V + ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;
     double *gD = p.D + (size_t)wg * (N - 1) * dstride + jj * nu + (is_u ? r - nx : 0);
     const int TOFF = (int)table_rows(N) * CW;
+    const size_t vrow0 = ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;  // knot 0 in the V-shaped arrays
+    double *gGC = p.GC + (FAM ? vrow0 : 0), *gGL = p.GL + (FAM ? vrow0 : 0);
 
     // ---- this lane's elements: slot i <-> step k = c*S + i; state lanes own knot k+1, input lanes knot k
     double g[SMAX], v[SMAX], lo[SMAX], hi[SMAX], lr[SMAX], dd[SMAX];
+    double gc[SMAX], gl[SMAX], lx[SMAX];  // FAM only
     bool ok[SMAX];     // slot holds a real element of this lane
     bool step[SMAX];   // slot is a real step of this group (uniform over the group)
     const int koff = is_x ? 1 : 0;
@@ -163,12 +169,16 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         lo[i] = ok[i] ? p.tables[(size_t)(kn + 1) * CW + r] : 0.0;
         hi[i] = ok[i] ? p.tables[(size_t)TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
         lr[i] = ok[i] ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
+        gc[i] = (FAM && ok[i]) ? gGC[(size_t)kn * 64] : 0.0;
+        gl[i] = (FAM && ok[i]) ? gGL[(size_t)kn * 64] : 0.0;
+        lx[i] = 0.0;
     }
     // knot 0 of the state rows: group 0, state lanes
     const bool k0 = (c == 0) && is_x;
     double g0 = k0 ? gG[0] : 0.0, v0 = k0 ? gV[0] : 0.0;
     const double lo0 = k0 ? p.tables[CW + r] : 0.0, hi0 = k0 ? p.tables[(size_t)TOFF + CW + r] : 0.0;
     const double x0v = k0 ? p.x0[inst * nx + r] : 0.0;
+    double gc0 = (FAM && k0) ? gGC[0] : 0.0, gl0 = (FAM && k0) ? gGL[0] : 0.0;
 
     double mf[KT], mb[KT];
     {
@@ -181,6 +191,80 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }
     const double cf = p.ops[2 * M + r];
     const double cb = p.ops[2 * M + CW + r];
+    // ---- families: mask rows and coefficients (layout of fam_doubles(), built on the host from the verbs' data)
+    double cn[KT], ct_[KT], ty[KT];
+    double ak[MAX_LIN_ROWS], bk[MAX_LIN_ROWS], nk[MAX_LIN_ROWS];
+    int role = 0, nl = 0;
+    double mu = 0.0;
+    bool famc = false, faml = false, any_cone = false, any_lin = false;
+    if (FAM) {
+        const double *Cn = p.fam + 4 * CW + (size_t)r * KT, *Ct = Cn + M, *Ty = Ct + M;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            cn[k] = Cn[k];
+            ct_[k] = Ct[k];
+            ty[k] = Ty[k];
+        }
+        role = (int)p.fam[r];
+        mu = p.fam[CW + r];
+        famc = p.fam[2 * CW + r] != 0.0;
+        faml = p.fam[3 * CW + r] != 0.0;
+        const double *lin_rows = p.fam + 4 * CW + 3 * M;
+        nl = (int)lin_rows[0];
+#pragma unroll
+        for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+            ak[k] = lin_rows[1 + (size_t)(3 * k + 0) * CW + r];
+            bk[k] = lin_rows[1 + (size_t)(3 * k + 1) * CW + r];
+            nk[k] = lin_rows[1 + (size_t)(3 * k + 2) * CW + r];
+        }
+        any_cone = __ballot(famc) != 0ull;  // the same in every wavefront: rows repeat per group
+        any_lin = __ballot(faml) != 0ull;
+    }
+    // One (row, knot) element of the two extra families, exactly as in k_admm_solve_fam: returns the element's
+    // contribution to the linear cost and the new duals. Must run with all 16 lanes of the group enabled.
+    auto families = [&](double val, double gc_old, double gl_old, double &gc_new, double &gl_new) -> double {
+        double lxv = 0.0;
+        gc_new = gc_old;
+        gl_new = gl_old;
+        if (any_cone) {
+            const double sv = val + gc_old;
+            const double a2 = group_matvec<CW, KT>(cn, sv * sv, 0.0);
+            const double t = group_matvec<CW, KT>(ct_, sv, 0.0);
+            const double u0 = t * mu;
+            const double a = sqrt(a2);
+            double vc = sv;
+            if (role != 0) {
+                if (a <= -u0) vc = 0.0;
+                else if (a <= u0) vc = sv;
+                else {
+                    const double scale = 0.5 * (1.0 + u0 / a);
+                    vc = (role == 1) ? scale * sv : scale * (a / mu);
+                }
+            }
+            const double gcn = sv - vc;
+            if (famc) {
+                gc_new = gcn;
+                lxv -= p.rho * (vc - gcn);
+            }
+        }
+        if (any_lin) {
+            const double s0 = val + gl_old;
+            double sv = s0;
+#pragma unroll
+            for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+                if (k < nl) {
+                    const double dot = group_matvec<CW, KT>(ty, ak[k] * sv, 0.0);
+                    if (dot > bk[k]) sv -= ((dot - bk[k]) / nk[k]) * ak[k];
+                }
+            }
+            const double gln = s0 - sv;
+            if (faml) {
+                gl_new = gln;
+                lxv -= p.rho * (sv - gln);
+            }
+        }
+        return lxv;
+    };
     const double pnref = p.tables[(size_t)3 * TOFF + r];
     const double rho = p.rho;
     const int ct = p.check_termination;
@@ -195,21 +279,27 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     for (int i = 0; i < SMAX; ++i) vprev[i] = v[i];
     int cur = 0;  // carry ping-pong buffer
 
-    // Carry scan: acc_c += Pm_l * acc_(c + dir*2^l), l = 0..Lc-1. The rows of a level are requested before its
-    // exchange; only the state lanes hold non-zero rows, so only they load (a quarter less LDS traffic).
-    auto carry_scan = [&](int dir, const double *Pm, double &acc) {
+    // Carry scan over the chunks (Hillis-Steele). In: the chunk's pass-1 end value. Out: the true value ENTERING
+    // the chunk from its neighbour n = c + dir,  I_c = sum_j Pm^(j) end_(n + j*dir)  -- the scan runs on the
+    // shifted sequence (level 0 reads the neighbour's and the next neighbour's end values in one exchange), so no
+    // extra exchange is needed afterwards to fetch the neighbour's result. The rows of a level are requested
+    // before its exchange; only the state lanes hold non-zero rows, so only they load (a quarter less LDS traffic).
+    auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
+        double acc = 0.0;
         for (int l = 0; l < Lc; ++l) {
             double m[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) m[k] = 0.0;
             if (is_x) load_row<KT>(Pm + (size_t)l * ML, r, m);
-            const int nb = c + dir * (1 << l);
-            sY[cur * 256 + tid] = acc;
+            const int n1 = c + dir, nb = c + dir * (l == 0 ? 2 : (1 << l));
+            sY[cur * 256 + tid] = (l == 0) ? end_val : acc;
             __syncthreads();
+            if (l == 0) acc = (n1 >= 0 && n1 < CGROUPS && is_x) ? sY[cur * 256 + n1 * 16 + r] : 0.0;
             const double o = (nb >= 0 && nb < CGROUPS && is_x) ? sY[cur * 256 + nb * 16 + r] : 0.0;
             acc += group_matvec<CW, KT>(m, o, 0.0);
             cur ^= 1;
         }
+        return acc;
     };
 
     for (int it = 0; it < p.max_iter; ++it) {
@@ -224,13 +314,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     const double o = group_matvec<CW, KT>(mf, is_x ? xt : dd[i], cf);
                     xt = step[i] ? o : xt;
                 }
-            double Xc = (is_x && c < C) ? xt : 0.0;
-            carry_scan(-1, PH, Xc);
-            sY[cur * 256 + tid] = Xc;
-            __syncthreads();
+            const double xin = carry_scan(-1, PH, (is_x && c < C) ? xt : 0.0);
             // pass 2: the real sweep, from the true state entering the chunk
-            xt = (c >= 1 && is_x) ? sY[cur * 256 + (c - 1) * 16 + r] : x0v;
-            cur ^= 1;
+            xt = (c >= 1) ? xin : x0v;
 #pragma unroll
             for (int i = 0; i < SMAX; ++i) {
                 out[i] = 0.0;
@@ -252,6 +338,14 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             g0 = s - snew;
             v0 = snew;
         }
+        if (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
+            double gcn, gln;
+            (void)families(x0v, gc0, gl0, gcn, gln);
+            if (k0) {
+                gc0 = gcn;
+                gl0 = gln;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < SMAX; ++i) {
             double gnew, snew, tp = 0.0, td = 0.0;
@@ -263,12 +357,21 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 pri = fmax(pri, tp);
                 dua = fmax(dua, td);
             }
+            if (FAM && i < S) {
+                double gcn, gln;
+                const double l = families(out[i], gc[i], gl[i], gcn, gln);
+                if (ok[i]) {
+                    gc[i] = gcn;
+                    gl[i] = gln;
+                    lx[i] = l;
+                }
+            }
         }
         it_done = it + 1;
         // linear cost of the backward sweep; its chunk-boundary exchange shares the barrier of the residual exchange
         double lin[SMAX];
 #pragma unroll
-        for (int i = 0; i < SMAX; ++i) lin[i] = lr[i] - rho * (v[i] - g[i]);  // q_{k+1} (state lanes) | r_k (input lanes)
+        for (int i = 0; i < SMAX; ++i) lin[i] = lr[i] - rho * (v[i] - g[i]) + lx[i];  // q_{k+1} (state lanes) | r_k (input lanes)
         {   // q_k of a chunk's first step lives in the previous group (its last state slot)
             double qlast = 0.0;
 #pragma unroll
@@ -297,7 +400,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         {
             double pterm = 0.0;
 #pragma unroll
-            for (int i = 0; i < SMAX; ++i) pterm = (i == i_last) ? (pnref - rho * (v[i] - g[i])) : pterm;  // p_{N-1}, admm.cpp:81-82
+            for (int i = 0; i < SMAX; ++i) pterm = (i == i_last) ? (pnref - rho * (v[i] - g[i]) + lx[i]) : pterm;  // p_{N-1}, admm.cpp:81-82
             const double qin = (c >= 1 && is_x) ? sQ[(c - 1) * 16 + r] : 0.0;
             const double pend = (c == C - 1 && is_x) ? pterm : 0.0;
             // pass 1: p at the chunk's first knot from a zero incoming p (last chunk: from p_{N-1})
@@ -309,13 +412,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     const double o = group_matvec<CW, KT>(mb, is_x ? pcur : lin[i], cb);
                     pcur = step[i] ? (qk + o) : pcur;
                 }
-            double Pc = (is_x && c < C) ? pcur : 0.0;
-            carry_scan(+1, PS, Pc);
-            sY[cur * 256 + tid] = Pc;
-            __syncthreads();
+            const double pin = carry_scan(+1, PS, (is_x && c < C) ? pcur : 0.0);
             // pass 2: the real sweep, from the true p entering the chunk; only d_k is kept
-            pcur = (c < C - 1 && is_x) ? sY[cur * 256 + (c + 1) * 16 + r] : pend;
-            cur ^= 1;
+            pcur = (c < C - 1) ? pin : pend;
 #pragma unroll
             for (int i = SMAX - 1; i >= 0; --i)
                 if (i < S) {
@@ -337,6 +436,10 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 gV[(size_t)kn * 64] = converged ? vprev[i] : v[i];  // converged: the reference returns before v <- vnew
                 if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
                 else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
+                if (FAM) {
+                    gGC[(size_t)kn * 64] = gc[i];
+                    gGL[(size_t)kn * 64] = gl[i];
+                }
             }
             if (step[i] && is_u) gD[(size_t)(c * S + i) * dstride] = dd[i];
         }
@@ -344,6 +447,10 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             gG[0] = g0;
             gV[0] = converged ? v0prev : v0;
             p.sol_x[(size_t)inst * N * nx + r] = v0;
+            if (FAM) {
+                gGC[0] = gc0;
+                gGL[0] = gl0;
+            }
         }
     }
     if (tid == 0) {
@@ -358,13 +465,22 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }
 }
 
+template <int KT, int SMAX, bool FAM>
+static hipError_t launch_c_f(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
+    static size_t lds_set[16] = {0};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, SMAX, FAM>), lds_bytes, lds_set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_admm_solve_c<KT, SMAX, FAM>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
 template <int KT, int SMAX>
 static hipError_t launch_c_t(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
-    static size_t lds_set[16] = {0};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, SMAX>), lds_bytes, lds_set);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_admm_solve_c<KT, SMAX>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
-    return hipGetLastError();
+    if (p.families) {
+        if (!p.fam || !p.GC || !p.GL) return hipErrorInvalidValue;
+        return launch_c_f<KT, SMAX, true>(p, lds_bytes, stream);
+    }
+    return launch_c_f<KT, SMAX, false>(p, lds_bytes, stream);
 }
 
 // One instance per workgroup; W must be 16 and the chunk length at most 8 (N <= 129).
