@@ -94,6 +94,8 @@ struct tinympc_solver {
     bool tables_in_lds = false;
     bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
     bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
+    bool c_tables = false;  // the chunk tables exist (layout C is possible for this shape and not excluded)
+    bool fam_c = false;     // the cone / linear families run in the latency kernel's FAM variant
     int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
     size_t lds_bytes_c = 0;
     double *dctab = nullptr;
@@ -183,7 +185,7 @@ int refresh_derived(tinympc_solver *s) {
         p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
         p.ops = s->dops;
         HIP_TRY(launch_build_operators(p, s->stream));
-        if (s->layout_c) {  // powers of the sweep operators for the chunked kernel
+        if (s->c_tables) {  // powers of the sweep operators for the chunked kernel
             ChunkTableParams c{};
             c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->chunk_len; c.Lc = s->chunk_levels;
             c.ops = s->dops; c.out = s->dctab;
@@ -300,7 +302,7 @@ int launch(tinympc_solver *s, bool timed) {
         // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
-    } else if (fam && s->layout_c) {
+    } else if (fam && s->fam_c) {
         // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         p.families = 1;
@@ -443,6 +445,14 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
             else if (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b') want_c = false;
         }
         s->layout_c = want_c;
+        // The families: k_admm_solve_fam keeps the whole ADMM state in LDS (layout A), so a long horizon leaves it
+        // one wavefront = 4 instances per CU; the latency kernel then wins at EVERY batch size (rocket N=100:
+        // 30 vs 15.6 M iterations/s at 4096 instances, profiles/r01d_rocket_sweep.txt). Otherwise as for the box path.
+        bool c_excluded = false;
+        if (const char *env = getenv("TINYMPC_LAYOUT")) c_excluded = (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b');
+        const size_t fam_a_waves_per_cu = s->state_in_global ? 1 : kLdsMax / (s->lds_bytes_a ? s->lds_bytes_a : kLdsMax);
+        s->fam_c = c_possible && !c_excluded && (want_c || fam_a_waves_per_cu <= 1);
+        s->c_tables = s->layout_c || s->fam_c;
     }
 
     const size_t X = s->X(), U = s->U();
@@ -455,7 +465,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
     TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
     TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));
-    if (s->layout_c) TRY(dalloc(s, &s->dctab, chunk_table_doubles(KT, s->chunk_levels)));
+    if (s->c_tables) TRY(dalloc(s, &s->dctab, chunk_table_doubles(KT, s->chunk_levels)));
     TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));

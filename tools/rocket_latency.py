@@ -1,23 +1,28 @@
-"""Kernel time per ADMM iteration of BASELINE config 4 (rocket landing, SOC + linear + fdyn), single instance and small batches."""
+"""Kernel time per ADMM iteration of BASELINE config 4 (rocket landing, SOC + linear + fdyn) for the two kernels
+that carry the families: k_admm_solve_fam (TINYMPC_LAYOUT=A) and k_admm_solve_c<FAM> (TINYMPC_LAYOUT=C)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package(); P = pkg.problems
-for N in (10, 100):
+for N in (20, 100):
     prob = P.rocket(N)
-    for batch in (1, 64, 1024):
-        s = pkg.TinyMPC()
-        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, max_iter=200, abs_pri_tol=0.0, abs_dua_tol=0.0)
-        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-        if prob.x_ref is not None: s.set_x_ref(prob.x_ref)
-        if prob.u_ref is not None: s.set_u_ref(prob.u_ref)
-        s.set_cone_constraints(**prob.cones)
-        if prob.linear: s.set_linear_constraints(**prob.linear)
-        s.set_x0_batch(np.repeat(prob.x0[:, None], batch, axis=1))
-        ms = []
-        for _ in range(7):
-            s.reset_workspace(); ms.append(s.solve_timed())
-        t = float(np.median(ms[2:]))
-        print(f"rocket N={N:3d} batch={batch:5d}: {t:8.3f} ms per 200 iterations = {5*t:7.2f} us/iter  layout {s.launch_info()['layout']}", flush=True)
-        s.reset()
+    for batch in (1, 256, 512, 1024, 2048, 4096):
+        row = [f"rocket N={N:3d} batch={batch:5d}"]
+        for layout in ("A", "C"):
+            os.environ["TINYMPC_LAYOUT"] = layout
+            s = pkg.TinyMPC()
+            s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, max_iter=200, abs_pri_tol=0.0, abs_dua_tol=0.0)
+            s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            if prob.x_ref is not None: s.set_x_ref(prob.x_ref)
+            if prob.u_ref is not None: s.set_u_ref(prob.u_ref)
+            s.set_cone_constraints(**prob.cones)
+            if prob.linear: s.set_linear_constraints(**prob.linear)
+            s.set_x0_batch(np.repeat(prob.x0[:, None], batch, axis=1))
+            ms = []
+            for _ in range(6):
+                s.reset_workspace(); ms.append(s.solve_timed())
+            t = float(np.median(ms[2:]))
+            row.append(f"{layout}: {5*t:8.2f} us/it {batch*200/t/1e3:7.1f} M/s")
+            s.reset()
+        print(" | ".join(row), flush=True)
