@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
 
     int it_done = 0, status = 11;
     bool res_valid = false, converged = false;
-    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    double snap_pri = 0.0, snap_dua = 0.0;  // this lane's residual maxima at the last termination check
     double vprev[SMAX], v0prev = v0;
 #pragma unroll
     for (int i = 0; i < SMAX; ++i) vprev[i] = v[i];
@@ -378,18 +378,22 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             for (int i = 0; i < SMAX; ++i) qlast = (i == S - 1) ? lin[i] : qlast;
             sQ[tid] = qlast;
         }
+        // R1 (admm.cpp:93-101). "All four inf-norms below their tolerances" is decided element-wise: max_i a_i < tol
+        // iff every a_i < tol, and scaling by rho > 0 is monotone, so one ballot per wavefront and four flags through
+        // LDS replace the eight row reductions of the norms themselves; the norms (for get_stats) are reduced once,
+        // after the loop, from the snapshot taken at the last check.
         if (check) {
-            const double gpx = row_max(is_x ? pri : 0.0), gpu_ = row_max(is_u ? pri : 0.0);
-            const double gdx = row_max(is_x ? dua : 0.0), gdu = row_max(is_u ? dua : 0.0);
-            if (r < 4) sR[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gpu_ : (r == 2) ? gdx : gdu;
+            snap_pri = pri;
+            snap_dua = dua;
+            res_valid = true;
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            const bool wave_ok = __ballot(!below) == 0ull;
+            if ((tid & 63) == 0) reinterpret_cast<int *>(sR)[tid >> 6] = wave_ok ? 1 : 0;
         }
         __syncthreads();
         if (check) {
-            const double px = row_max(sR[r * 4 + 0]), pu = row_max(sR[r * 4 + 1]);
-            const double dx = row_max(sR[r * 4 + 2]) * rho, du = row_max(sR[r * 4 + 3]) * rho;
-            res_px = px; res_dx = dx; res_pu = pu; res_du = du;
-            res_valid = true;
-            if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
+            const int *flags = reinterpret_cast<const int *>(sR);
+            if ((flags[0] & flags[1] & flags[2] & flags[3]) != 0) {
                 status = 1;  // uniform over the workgroup: one instance
                 converged = true;
                 break;
@@ -424,6 +428,20 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     pcur = step[i] ? (qk + o) : pcur;
                 }
         }
+    }
+
+    // ---- the four residual norms of the last check, for get_stats (two-stage max: rows, then groups through LDS)
+    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    if (res_valid) {
+        __syncthreads();  // the flags in sR have been read by everyone
+        const double gpx = row_max(is_x ? snap_pri : 0.0), gpu_ = row_max(is_u ? snap_pri : 0.0);
+        const double gdx = row_max(is_x ? snap_dua : 0.0), gdu = row_max(is_u ? snap_dua : 0.0);
+        if (r < 4) sR[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gpu_ : (r == 2) ? gdx : gdu;
+        __syncthreads();
+        res_px = row_max(sR[r * 4 + 0]);
+        res_pu = row_max(sR[r * 4 + 1]);
+        res_dx = row_max(sR[r * 4 + 2]) * rho;
+        res_du = row_max(sR[r * 4 + 3]) * rho;
     }
 
     // ---- write-back (state for the next solve, solution, stats)
