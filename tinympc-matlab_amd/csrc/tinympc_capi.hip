@@ -437,7 +437,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         // 2-3x shorter iteration for one instance, lower throughput once the batch fills the chip's wave slots.
         // Default for small batches; TINYMPC_LAYOUT=C forces it, =A / =B exclude it.
         chunk_plan(N, &s->chunk_len, &s->chunk_count, &s->chunk_levels);
-        s->lds_bytes_c = solve_c_lds_bytes(KT, s->chunk_levels);
+        s->lds_bytes_c = solve_c_lds_bytes(nx, s->chunk_levels);
         const bool c_possible = (W == 16) && (s->chunk_len <= 8) && (s->lds_bytes_c <= kLdsMax);
         bool want_c = c_possible && batch <= kLayoutCBatchMax;
         if (const char *env = getenv("TINYMPC_LAYOUT")) {
@@ -465,7 +465,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
     TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
     TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));
-    if (s->c_tables) TRY(dalloc(s, &s->dctab, chunk_table_doubles(KT, s->chunk_levels)));
+    if (s->c_tables) TRY(dalloc(s, &s->dctab, chunk_table_doubles(nx, s->chunk_levels)));
     TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));

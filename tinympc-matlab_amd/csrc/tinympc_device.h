@@ -115,7 +115,7 @@ struct SolveParams {
     double rho_min, rho_max;
     int rho_clip;
     // Layout C (k_admm_solve_c): horizon cut into chunk_count chunks of chunk_len steps, see chunk_plan()
-    const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][KT]: powers S*2^l of the sweeps' state blocks
+    const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][chunk_ks(nx)]: powers S*2^l of the sweeps' state blocks
     int chunk_len, chunk_count, chunk_levels;
     int families;         // layout C: run the cone / linear families too (the other layouts use k_admm_solve_fam)
 };
@@ -174,8 +174,9 @@ hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_byte
 hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_build_chunk_tables(const ChunkTableParams &p, hipStream_t stream);
 void chunk_plan(int N, int *S, int *C, int *Lc);
-size_t solve_c_lds_bytes(int KT, int Lc);
-size_t chunk_table_doubles(int KT, int Lc);
+size_t solve_c_lds_bytes(int nx, int Lc);
+size_t chunk_table_doubles(int nx, int Lc);
+int chunk_ks(int nx);
 // Layout A plus adaptive rho (per-instance rho, Taylor-updated operators).
 hipError_t launch_solve_adapt(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_build_adapt(const AdaptTableParams &p, hipStream_t stream);

@@ -57,15 +57,20 @@ __device__ __forceinline__ double row_max(double v) {
 }
 }  // namespace
 
-// ---- carry matrices PhiS_l = Phi^(S 2^l) | PsiS_l = Psi^(S 2^l)  (l < Lc), each [16][KT] row-major, zero outside
-//      the nx x nx state block; Phi, Psi are the state blocks of the fused operators of k_build_operators
+// Columns of a carry matrix: the state dimension rounded up to what the fused DPP chain supports.
+__host__ __device__ inline int chunk_ks_impl(int nx) { return nx <= 8 ? 8 : nx <= 12 ? 12 : 16; }
+int chunk_ks(int nx) { return chunk_ks_impl(nx); }
+
+// ---- carry matrices PhiS_l = Phi^(S 2^l) | PsiS_l = Psi^(S 2^l)  (l < Lc), each [16][KS] row-major (KS = nx rounded
+//      up to 8 / 12 / 16: their operand is a state vector), zero outside the nx x nx state block; Phi, Psi are the
+//      state blocks of the fused operators of k_build_operators
 __global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTableParams p) {
     __shared__ double Base[256], Cur[256], Tmp[256];
-    const int nx = p.nx, KT = p.KT, S = p.S, Lc = p.Lc, tid = threadIdx.x;
+    const int nx = p.nx, KT = p.KT, KS = chunk_ks_impl(nx), S = p.S, Lc = p.Lc, tid = threadIdx.x;
     const int r = tid / 16, k = tid % 16;  // 16 x 16 working matrices
-    const size_t M = (size_t)CW * KT;
+    const size_t M = (size_t)CW * KT, MS = (size_t)CW * KS;
     const bool in = (r < nx) && (k < nx);
-    for (size_t i = tid; i < (size_t)2 * Lc * M; i += 256) p.out[i] = 0.0;
+    for (size_t i = tid; i < (size_t)2 * Lc * MS; i += 256) p.out[i] = 0.0;
     __syncthreads();
     auto mul = [&](double *Cm, const double *Am, const double *Bm) {  // Cm = Am * Bm (16 x 16, LDS)
         double acc = 0.0;
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTablePara
     };
     for (int which = 0; which < 2; ++which) {
         const double *Op = p.ops + (size_t)which * M;  // Mf, then Mb
-        double *dst = p.out + (size_t)which * Lc * M;
+        double *dst = p.out + (size_t)which * Lc * MS;
         Base[tid] = in ? Op[r * KT + k] : 0.0;
         Cur[tid] = (r == k && r < nx) ? 1.0 : 0.0;
         __syncthreads();
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTablePara
             __syncthreads();
         }
         for (int l = 0; l < Lc; ++l) {  // Base^(S 2^l)
-            if (in) dst[(size_t)l * M + r * KT + k] = Cur[tid];
+            if (in) dst[(size_t)l * MS + r * KS + k] = Cur[tid];
             mul(Tmp, Cur, Cur);
             Cur[tid] = Tmp[tid];
             __syncthreads();
@@ -108,17 +113,17 @@ void chunk_plan(int N, int *S, int *C, int *Lc) {
     *Lc = l;
 }
 
-size_t chunk_table_doubles(int KT, int Lc) { return (size_t)2 * Lc * CW * KT; }
+size_t chunk_table_doubles(int nx, int Lc) { return (size_t)2 * Lc * CW * chunk_ks(nx); }
 
-size_t solve_c_lds_bytes(int KT, int Lc) {
+size_t solve_c_lds_bytes(int nx, int Lc) {
     // carry matrices + carry ping-pong Y[2][256] + boundary q Q[256] + residual partials R[16][4]
-    return sizeof(double) * ((size_t)2 * Lc * CW * (KT + 2) + 2 * 256 + 256 + 64);
+    return sizeof(double) * ((size_t)2 * Lc * CW * (chunk_ks(nx) + 2) + 2 * 256 + 256 + 64);
 }
 
 // FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there)
 // ride on the row-local phase: every slot carries the extra duals gc|yc, gl|yl (persistent, HBM arrays GC / GL) and
 // the extra linear-cost term lx (forward -> backward, registers).
-template <int KT, int SMAX, bool FAM>
+template <int KT, int KS, int SMAX, bool FAM>
 __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
@@ -128,16 +133,17 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     const bool is_x = r < nx;
     const bool is_u = (r >= nx) && (r < nxu);
     const bool row_ok = r < nxu;
-    const size_t M = (size_t)CW * KT;         // one matrix in the global tables
-    const size_t ML = (size_t)CW * (KT + 2);  // and in LDS (padded rows)
+    const size_t M = (size_t)CW * KT;         // one fused operator / mask matrix in the global tables
+    const size_t MS = (size_t)CW * KS;        // one carry matrix in the global tables
+    const size_t ML = (size_t)CW * (KS + 2);  // and in LDS (padded rows)
     double *sTab = smem;
     double *sY = sTab + (size_t)2 * Lc * ML;  // [2][256]
     double *sQ = sY + 512;                    // [256]
     double *sR = sQ + 256;                    // [16][4]
     const double *PH = sTab, *PS = PH + (size_t)Lc * ML;
-    for (int i = tid; i < 2 * Lc * (int)M; i += CTHREADS) {
-        const int mat = i / (int)M, rem = i % (int)M;
-        sTab[(size_t)mat * ML + (rem / KT) * (KT + 2) + rem % KT] = p.ctab[i];
+    for (int i = tid; i < 2 * Lc * (int)MS; i += CTHREADS) {
+        const int mat = i / (int)MS, rem = i % (int)MS;
+        sTab[(size_t)mat * ML + (rem / KS) * (KS + 2) + rem % KS] = p.ctab[i];
     }
 
     // canonical HBM layout shared with the other kernels (instance = lane group inst%4 of wave group inst/4)
@@ -287,16 +293,16 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
         double acc = 0.0;
         for (int l = 0; l < Lc; ++l) {
-            double m[KT];
+            double m[KS];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) m[k] = 0.0;
-            if (is_x) load_row<KT>(Pm + (size_t)l * ML, r, m);
+            for (int k = 0; k < KS; ++k) m[k] = 0.0;
+            if (is_x) load_row<KS>(Pm + (size_t)l * ML, r, m);
             const int n1 = c + dir, nb = c + dir * (l == 0 ? 2 : (1 << l));
             sY[cur * 256 + tid] = (l == 0) ? end_val : acc;
             __syncthreads();
             if (l == 0) acc = (n1 >= 0 && n1 < CGROUPS && is_x) ? sY[cur * 256 + n1 * 16 + r] : 0.0;
             const double o = (nb >= 0 && nb < CGROUPS && is_x) ? sY[cur * 256 + nb * 16 + r] : 0.0;
-            acc += group_matvec<CW, KT>(m, o, 0.0);
+            acc += group_matvec<CW, KS>(m, o, 0.0);
             cur ^= 1;
         }
         return acc;
@@ -483,31 +489,39 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }
 }
 
-template <int KT, int SMAX, bool FAM>
+template <int KT, int KS, int SMAX, bool FAM>
 static hipError_t launch_c_f(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
     static size_t lds_set[16] = {0};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, SMAX, FAM>), lds_bytes, lds_set);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, KS, SMAX, FAM>), lds_bytes, lds_set);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_admm_solve_c<KT, SMAX, FAM>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
+    hipLaunchKernelGGL((k_admm_solve_c<KT, KS, SMAX, FAM>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-template <int KT, int SMAX>
+template <int KT, int KS>
 static hipError_t launch_c_t(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
-    if (p.families) {
-        if (!p.fam || !p.GC || !p.GL) return hipErrorInvalidValue;
-        return launch_c_f<KT, SMAX, true>(p, lds_bytes, stream);
+    if constexpr (KS > KT) {
+        return hipErrorInvalidValue;
+    } else {
+        const bool small = p.chunk_len <= 4;
+        if (p.families) {
+            if (!p.fam || !p.GC || !p.GL) return hipErrorInvalidValue;
+            return small ? launch_c_f<KT, KS, 4, true>(p, lds_bytes, stream) : launch_c_f<KT, KS, 8, true>(p, lds_bytes, stream);
+        }
+        return small ? launch_c_f<KT, KS, 4, false>(p, lds_bytes, stream) : launch_c_f<KT, KS, 8, false>(p, lds_bytes, stream);
     }
-    return launch_c_f<KT, SMAX, false>(p, lds_bytes, stream);
 }
 
 // One instance per workgroup; W must be 16 and the chunk length at most 8 (N <= 129).
 hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream) {
     if (W != 16 || !p.ctab || p.chunk_len < 1 || p.chunk_len > 8 || p.chunk_count > CGROUPS) return hipErrorInvalidValue;
-    const bool small = p.chunk_len <= 4;
-    if (KT == 8) return small ? launch_c_t<8, 4>(p, lds_bytes, stream) : launch_c_t<8, 8>(p, lds_bytes, stream);
-    if (KT == 12) return small ? launch_c_t<12, 4>(p, lds_bytes, stream) : launch_c_t<12, 8>(p, lds_bytes, stream);
-    if (KT == 16) return small ? launch_c_t<16, 4>(p, lds_bytes, stream) : launch_c_t<16, 8>(p, lds_bytes, stream);
+    const int KS = chunk_ks(p.nx);
+    if (KT == 8 && KS == 8) return launch_c_t<8, 8>(p, lds_bytes, stream);
+    if (KT == 12 && KS == 8) return launch_c_t<12, 8>(p, lds_bytes, stream);
+    if (KT == 12 && KS == 12) return launch_c_t<12, 12>(p, lds_bytes, stream);
+    if (KT == 16 && KS == 8) return launch_c_t<16, 8>(p, lds_bytes, stream);
+    if (KT == 16 && KS == 12) return launch_c_t<16, 12>(p, lds_bytes, stream);
+    if (KT == 16 && KS == 16) return launch_c_t<16, 16>(p, lds_bytes, stream);
     return hipErrorInvalidValue;
 }
 
