@@ -160,19 +160,19 @@ def test_unsupported_family_shapes_fail_loudly(pkg):
 
 def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
     """Default kernel choice (no TINYMPC_LAYOUT): a long horizon leaves k_admm_solve_fam one wavefront per CU, so the
-    families then run in the latency kernel at every batch size -- here 900 instances (beyond the box path's
-    768-instance switch-over), spot-checked against the restatement."""
+    families then run in the latency kernel at every batch size -- here 1100 instances (beyond the box path's
+    1024-instance switch-over), spot-checked against the restatement."""
     monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
     prob = pkg.problems.rocket(100)
     settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=12, check_termination=1)
-    batch = 900
+    batch = 1100
     s = make(pkg, prob, settings, batch=batch)
     scale = np.linspace(0.6, 1.2, batch)
     x0s = prob.x0[:, None] * scale[None, :]
     s.set_x0_batch(x0s)
     s.solve()
     sol = s.get_solution_batch()
-    for b in (0, 451, 899):
+    for b in (0, 451, 1099):
         o = O.OraclePort(prob).load_problem(prob, settings)
         o.set_x0(x0s[:, b])
         o.solve()

@@ -66,9 +66,9 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     info = s.launch_info()
     assert info["layout"] == "C" and info["workgroups"] == 8  # default for small batches: the latency kernel
     s.reset()
-    s = make_solver(pkg, P.quadrotor(50), {}, batch=1024)
+    s = make_solver(pkg, P.quadrotor(50), {}, batch=2048)
     info = s.launch_info()
-    assert info["layout"] == "B" and info["workgroups"] == 64 and info["lds_bytes"] <= 160 * 1024  # large batch: B where it fits
+    assert info["layout"] == "B" and info["workgroups"] == 128 and info["lds_bytes"] <= 160 * 1024  # large batch: B where it fits
     s.reset()
     monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})

@@ -60,7 +60,7 @@ struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings
 };
 
 constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
-constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
+constexpr int kLayoutCBatchMax = 1024;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
 
 }  // namespace
 
