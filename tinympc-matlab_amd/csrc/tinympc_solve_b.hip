@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
     int it_done = 0;
     int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
     bool res_valid = false;
-    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    double snap_pri = 0.0, snap_dua = 0.0;  // this lane's residual maxima at its instance's last termination check
 
     // vold operands of the next forward sweep's first steps: knot 0 (state lanes) and the 4-slot ring.
     // Slot of forward step i is (i - R4) & 3, so that the sweep always ENDS on slot 3.
@@ -261,16 +261,19 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
         }
         request_forward_head(Vw);
 
-        // ---------------- R1: inf-norm residuals (admm.cpp:93-101), one butterfly per iteration
+        // ---------------- R1: termination (admm.cpp:93-101). "All four inf-norms below tolerance" is decided element-
+        // wise (max_i a_i < tol iff every a_i < tol; scaling by rho > 0 is monotone): one ballot instead of four
+        // shuffle butterflies per iteration. The norms themselves (for get_stats) are reduced once, after the loop,
+        // from the snapshot each lane takes at its instance's last check.
         if (check) {
-            const double px = group_max<W>(is_x ? pri : 0.0);
-            const double pu = group_max<W>(is_u ? pri : 0.0);
-            const double dx = group_max<W>(is_x ? dua : 0.0) * rho;
-            const double du = group_max<W>(is_u ? dua : 0.0) * rho;
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+            const bool conv = ((__ballot(below) >> (j * W)) & ones) == ones;
             if (active) {
-                res_px = px; res_dx = dx; res_pu = pu; res_du = du;
+                snap_pri = pri;
+                snap_dua = dua;
                 res_valid = true;
-                if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
+                if (conv) {
                     status = 1;  // TINY_SOLVED: stop this instance before the backward pass (admm.cpp:181-192)
                     active = false;
                 }
@@ -325,6 +328,9 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             (void)i;
         }
     }
+
+    const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
 
     // ---- write-back. k = it_done sweeps ran for this instance: vnew is in V[k&1], the previous iterate in
     // V[(k-1)&1]. The canonical buffer (0) must end up holding the reference's workspace v/z:
