@@ -94,6 +94,9 @@ struct tinympc_solver {
     bool tables_in_lds = false;
     bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
     bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
+    // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
+    bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
+    bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
     bool c_tables = false;  // the chunk tables exist (layout C is possible for this shape and not excluded)
     bool fam_c = false;     // the cone / linear families run in the latency kernel's FAM variant
     int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
@@ -140,6 +143,14 @@ int dalloc(tinympc_solver *s, T **p, size_t count) {
 int bind_device(tinympc_solver *s) {
     HIP_TRY(hipSetDevice(s->device));
     return TINYMPC_OK;
+}
+
+// true if every row of the column-major rows x cols matrix holds one value (bit-wise; inf == inf)
+bool rows_constant(const double *m, int rows, int cols) {
+    for (int c = 1; c < cols; ++c)
+        for (int r = 0; r < rows; ++r)
+            if (!(m[r + (size_t)c * rows] == m[r])) return false;
+    return true;
 }
 
 int upload(tinympc_solver *s, double *dst, const double *src, size_t count) {
@@ -295,6 +306,7 @@ int launch(tinympc_solver *s, bool timed) {
     p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
+    p.const_tables = s->tables_const() ? 1 : 0;
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -544,6 +556,7 @@ int tinympc_set_x_ref(tinympc_solver *s, const double *Xref, int rows, int cols,
         return fail(TINYMPC_ERR_INVALID_INPUT, "State reference trajectory (x_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nx, s->N);
     if ((rc = bind_device(s))) return rc;
     rc = upload(s, s->dXref, Xref, s->X());
+    s->xref_const = rows_constant(Xref, s->nx, s->N);
     s->tables_dirty = true;
     if (!rc && verbose) printf("State reference set\n");
     return rc;
@@ -557,6 +570,7 @@ int tinympc_set_u_ref(tinympc_solver *s, const double *Uref, int rows, int cols,
         return fail(TINYMPC_ERR_INVALID_INPUT, "Control/input reference trajectory (u_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nu, s->N - 1);
     if ((rc = bind_device(s))) return rc;
     rc = upload(s, s->dUref, Uref, s->U());
+    s->uref_const = rows_constant(Uref, s->nu, s->N - 1);
     s->tables_dirty = true;
     if (!rc && verbose) printf("Input reference set\n");
     return rc;
@@ -573,6 +587,8 @@ int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const 
     if ((rc = upload(s, s->dxmax, x_max, s->X()))) return rc;
     if ((rc = upload(s, s->dumin, u_min, s->U()))) return rc;
     if ((rc = upload(s, s->dumax, u_max, s->U()))) return rc;
+    s->xmin_const = rows_constant(x_min, s->nx, s->N); s->xmax_const = rows_constant(x_max, s->nx, s->N);
+    s->umin_const = rows_constant(u_min, s->nu, s->N - 1); s->umax_const = rows_constant(u_max, s->nu, s->N - 1);
     s->st.en_state_bound = 1;  // bindings.cpp:206-207
     s->st.en_input_bound = 1;
     s->tables_dirty = true;

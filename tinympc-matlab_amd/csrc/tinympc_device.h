@@ -118,6 +118,7 @@ struct SolveParams {
     const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][chunk_ks(nx)]: powers S*2^l of the sweeps' state blocks
     int chunk_len, chunk_count, chunk_levels;
     int families;         // layout C: run the cone / linear families too (the other layouts use k_admm_solve_fam)
+    int const_tables;     // bounds and references are the same at every knot (layout B keeps them in registers)
 };
 
 struct ChunkTableParams {

@@ -60,7 +60,10 @@ struct BwdLds { double bg, blr; };
 
 // R4 = (N-1) & 3 is a template parameter so that the rotation of the prefetch rings is resolved at
 // compile time: with a run-time rotation hipcc demotes the ring to scratch memory (pointer table).
-template <int W, int KT, int R4>
+// CT ("constant tables"): bounds and references do not vary over the horizon (p.const_tables, decided on the host from
+// what the verbs received) -- the per-knot table entries lo / hi / linref of a lane are then the same at every
+// knot and live in three registers instead of being fetched from LDS at every sweep step.
+template <int W, int KT, int R4, bool CT>
 __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int IPW = 64 / W;
@@ -123,6 +126,7 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
     const int dIdx = is_u ? (j * nu + (r - nx)) : 0;
     const int koff = is_x ? 1 : 0;  // at step i a state lane finishes knot i+1, an input lane knot i
     const int ct = p.check_termination;
+    const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];  // knot 0 (CT)
     // The forward sweep runs its R4 = nsteps % 4 odd steps FIRST, then whole groups of four.
 
     bool active = inst_ok;
@@ -198,13 +202,14 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
                 pg += 64;
                 pt += W;
                 pd += dstride;
-                nxt.g = pg[0]; nxt.lo = pt[0]; nxt.hi = pt[TOFF]; nxt.dv = pd[0];
+                nxt.g = pg[0]; nxt.dv = pd[0];
+                if constexpr (!CT) { nxt.lo = pt[0]; nxt.hi = pt[TOFF]; }
                 const double vold = vslot;
                 vslot = pvr[4 * 64];  // vold of the step four ahead (same ring slot)
                 pvr += 64;
                 const double out = group_matvec<W, KT>(mf, w, cf);  // state lanes: x_{i+1}; input lanes: u_i
                 double gnew;
-                project_element(out, cur.g, cur.lo, cur.hi, vold, gnew, wslot, pri, dua);
+                project_element(out, cur.g, CT ? lo_c : cur.lo, CT ? hi_c : cur.hi, vold, gnew, wslot, pri, dua);
                 ps[0] = gnew;
                 *pvw = wslot;
 #if TINY_B_INPLACE
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             constexpr std::true_type with_copy{};
             constexpr std::false_type no_copy{};
             // Head: the R4 odd steps, on the ring slots that make the sweep end on slot 3.
-            A.g = pg[0]; A.lo = pt[0]; A.hi = pt[TOFF]; A.dv = pd[0];
+            A.g = pg[0]; A.lo = pt[0]; A.hi = pt[TOFF]; A.dv = pd[0];  // (lo / hi unused under CT)
             if constexpr (R4 & 1) B = A;  // an odd head starts with B as the current operand set
             if (may) {
                 if constexpr (R4 == 3) { fstep(with_copy, B, A, v1, w1); fstep(with_copy, A, B, v2, w2); fstep(with_copy, B, A, v3, w3); }
@@ -292,11 +297,12 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             const int ddec = stb ? dstride : 0;
             BwdLds A{pb[0], pl[0]}, B;
             auto bcore = [&](const BwdLds &cur, BwdLds &nxt, double bv) {
-                const double lin = cur.blr - rho * (bv - cur.bg);  // q_i (state lanes) / r_i (input lanes), admm.cpp:77-80
+                const double lin = (CT ? lr_c : cur.blr) - rho * (bv - cur.bg);  // q_i (state lanes) / r_i (input lanes), admm.cpp:77-80
                 const double w = is_x ? pcur : lin;
                 pb -= 64;
                 pl -= W;
-                nxt.bg = pb[0]; nxt.blr = pl[0];
+                nxt.bg = pb[0];
+                if constexpr (!CT) nxt.blr = pl[0];
                 const double out = group_matvec<W, KT>(mb, w, cb);
                 *pdst = out;  // d_i (input lanes)
                 pdst -= ddec;
@@ -370,14 +376,19 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
     }
 }
 
-template <int W, int KT, int R4>
-static hipError_t launch_b_r(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
+template <int W, int KT, int R4, bool CT>
+static hipError_t launch_b_c(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
     const int wgs = (p.groups + WPG - 1) / WPG;
     static size_t lds_set[16] = {0};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_b<W, KT, R4>), lds_bytes, lds_set);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_b<W, KT, R4, CT>), lds_bytes, lds_set);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_admm_solve_b<W, KT, R4>), dim3(wgs), dim3(64 * WPG), lds_bytes, stream, p);
+    hipLaunchKernelGGL((k_admm_solve_b<W, KT, R4, CT>), dim3(wgs), dim3(64 * WPG), lds_bytes, stream, p);
     return hipGetLastError();
+}
+
+template <int W, int KT, int R4>
+static hipError_t launch_b_r(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
+    return p.const_tables ? launch_b_c<W, KT, R4, true>(p, lds_bytes, stream) : launch_b_c<W, KT, R4, false>(p, lds_bytes, stream);
 }
 
 template <int W, int KT>
