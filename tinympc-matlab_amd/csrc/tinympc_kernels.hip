@@ -13,7 +13,6 @@ namespace tinympc {
 // P1: LQR cache precompute -- one workgroup, matrices in LDS (global scratch if too big)
 // =====================================================================================
 constexpr int PRE_THREADS = 256;
-constexpr int PRE_LDS_LIMIT_DOUBLES = 7000;  // ~55 KB: stay under the 64 KB default dynamic-LDS cap
 
 // C (m x n) = op(A) (m x k) * op(B) (k x n), column-major. TA: A is stored k x m. TB: B is stored n x k.
 // k-loop order l = 0..k-1 per output element, as in the oracle's matmul.
