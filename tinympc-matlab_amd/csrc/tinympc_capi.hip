@@ -1019,18 +1019,19 @@ int tinympc_reset_workspace(tinympc_solver *s) {
     if ((rc = bind_device(s))) return rc;
     HIP_TRY(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
     HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->v_doubles(), s->stream));
-    HIP_TRY(hipMemsetAsync(s->dV2, 0, sizeof(double) * s->v_doubles(), s->stream));
+    // (V2, the stale-copy buffer of layout B, and LX, the families' forward -> backward term, are always written
+    //  before they are read within a solve: nothing to reset)
     HIP_TRY(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
     if (s->dGC) {
         HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
         HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
-        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
     }
     HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
     HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));
     HIP_TRY(hipMemsetAsync(s->ddstats, 0, sizeof(double) * s->batch * 4, s->stream));
-    return fill_host_upload(s, s->drho_inst, s->batch, s->rho);  // adapted rho back to the setup value
+    HIP_TRY(launch_fill(s->drho_inst, (size_t)s->batch, s->rho, s->stream));  // adapted rho back to the setup value
+    return TINYMPC_OK;
 }
 
 int tinympc_get_rho_batch(tinympc_solver *s, double *rho_out, int first, int count) {

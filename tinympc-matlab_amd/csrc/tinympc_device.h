@@ -157,6 +157,7 @@ __host__ __device__ inline size_t fam_doubles(int W, int KT) { return (size_t)4 
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
+hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream);  // asynchronous constant fill
 size_t lqr_scratch_doubles(int nx, int nu);
 hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream);
 hipError_t launch_build_tables(const TableParams &p, hipStream_t stream);

@@ -392,6 +392,16 @@ __global__ void __launch_bounds__(256) k_finite_diff(const FiniteDiffParams p) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < p.count; i += gridDim.x * 256) p.out[i] = (p.hi[i] - p.lo[i]) / p.h;
 }
 
+__global__ void __launch_bounds__(256) k_fill(double *dst, size_t count, double value) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = value;
+}
+
+hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_fill, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, count, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(k_finite_diff, dim3(1), dim3(256), 0, stream, p);
     return hipGetLastError();
