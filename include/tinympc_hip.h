@@ -34,7 +34,7 @@ extern "C" {
 #define TINYMPC_ERR_NOT_INITIALIZED (-2) /* MEX id TinyMPC:NotInitialized (bindings.cpp:113,...)   */
 #define TINYMPC_ERR_HIP (-3)             /* a HIP runtime call failed (message has the hipError)   */
 #define TINYMPC_ERR_UNSUPPORTED (-4)     /* problem shape outside what the kernels support         */
-#define TINYMPC_ERR_NOT_IMPLEMENTED (-5) /* verb exported for ABI completeness, out of scope       */
+#define TINYMPC_ERR_NOT_IMPLEMENTED (-5) /* reserved: no verb returns it any more (every verb is implemented) */
 #define TINYMPC_ERR_NO_DEVICE (-6)       /* no HIP device visible                                  */
 #define TINYMPC_ERR_ALLOC (-7)
 
