@@ -345,10 +345,12 @@ def test_full_size_batch_properties(pkg):
     s.reset()
 
 
-@pytest.mark.parametrize("batch", [1, 6])
+@pytest.mark.parametrize("batch", [1, 6, 300])
 def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a
-    warm-started closed loop (examples/cartpole_example_mpc.m:36-44 without the noise)."""
+    warm-started closed loop (examples/cartpole_example_mpc.m:36-44 without the noise). Up to 256 instances the
+    tick exchanges x0 / u0 through pinned host memory (no copy engine), beyond that through two async copies; after
+    a zero-copy tick the device copy of x0 must be current too (a plain solve() follows below)."""
     P = pkg.problems
     prob = P.quadrotor(20)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
@@ -365,6 +367,14 @@ def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
         np.testing.assert_array_equal(a.get_stats_batch()["iter"], b.get_stats_batch()["iter"])
         xa = prob.A @ xa + prob.B @ ua
         xb = prob.A @ xb + prob.B @ ub
+    # the x0 of the last tick is what a following plain solve() starts from, in both handles
+    a.mpc_step(xa)
+    b.set_x0_batch(xb)
+    b.solve()
+    a.solve()
+    b.solve()
+    np.testing.assert_array_equal(a.get_first_controls_batch(), b.get_first_controls_batch())
+    np.testing.assert_array_equal(a.get_stats_batch()["iter"], b.get_stats_batch()["iter"])
     a.reset()
     b.reset()
 

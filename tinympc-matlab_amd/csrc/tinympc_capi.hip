@@ -60,6 +60,7 @@ struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings
 };
 
 constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
+constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
 constexpr int kLayoutCBatchMax = 1024;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
 
 }  // namespace
@@ -97,6 +98,7 @@ struct tinympc_solver {
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
     bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
+    bool zero_copy_tick = false;  // this launch reads x0 from / writes u0 to pinned host memory (mpc_step, small batches)
     bool c_tables = false;  // the chunk tables exist (layout C is possible for this shape and not excluded)
     bool fam_c = false;     // the cone / linear families run in the latency kernel's FAM variant
     int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
@@ -307,6 +309,11 @@ int launch(tinympc_solver *s, bool timed) {
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     p.const_tables = s->tables_const() ? 1 : 0;
+    if (s->zero_copy_tick) {  // set by tinympc_mpc_step_batch for the duration of one launch
+        p.x0 = s->h_x0;
+        p.x0_mirror = s->dx0;
+        p.u0_host = s->h_u0;
+    }
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -647,11 +654,22 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
-    HIP_TRY(hipMemcpyAsync(s->dx0, s->h_x0, sizeof(double) * nx0, hipMemcpyHostToDevice, s->stream));
-    if ((rc = launch(s, false))) return rc;
-    HIP_TRY(hipMemcpy2DAsync(s->h_u0, sizeof(double) * s->nu, s->dsolu, sizeof(double) * s->U(), sizeof(double) * s->nu,
-                             s->batch, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0) {
+        // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
+        // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
+        // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
+        s->zero_copy_tick = true;
+        rc = launch(s, false);
+        s->zero_copy_tick = false;
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(s->dx0, s->h_x0, sizeof(double) * nx0, hipMemcpyHostToDevice, s->stream));
+        if ((rc = launch(s, false))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(s->h_u0, sizeof(double) * s->nu, s->dsolu, sizeof(double) * s->U(), sizeof(double) * s->nu,
+                                 s->batch, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     std::memcpy(u0_out, s->h_u0, sizeof(double) * nu0);
     return TINYMPC_OK;
 }

@@ -119,6 +119,10 @@ struct SolveParams {
     int chunk_len, chunk_count, chunk_levels;
     int families;         // layout C: run the cone / linear families too (the other layouts use k_admm_solve_fam)
     int const_tables;     // bounds and references are the same at every knot (layout B keeps them in registers)
+    // Zero-copy closed-loop tick (tinympc_mpc_step_batch, small batches): x0 points into pinned host memory and is
+    // mirrored into the device copy; the first controls are also written straight into pinned host memory.
+    double *x0_mirror;    // [batch][nx] or NULL
+    double *u0_host;      // [batch][nu] or NULL
 };
 
 struct ChunkTableParams {

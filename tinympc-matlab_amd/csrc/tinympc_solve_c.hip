@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     double g0 = k0 ? gG[0] : 0.0, v0 = k0 ? gV[0] : 0.0;
     const double lo0 = k0 ? p.tables[CW + r] : 0.0, hi0 = k0 ? p.tables[(size_t)TOFF + CW + r] : 0.0;
     const double x0v = k0 ? p.x0[inst * nx + r] : 0.0;
+    if (p.x0_mirror && k0) p.x0_mirror[inst * nx + r] = x0v;  // zero-copy tick: x0 came from host memory
     double gc0 = (FAM && k0) ? gGC[0] : 0.0, gl0 = (FAM && k0) ? gGL[0] : 0.0;
 
     double mf[KT], mb[KT];
@@ -459,7 +460,10 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 gG[(size_t)kn * 64] = g[i];
                 gV[(size_t)kn * 64] = converged ? vprev[i] : v[i];  // converged: the reference returns before v <- vnew
                 if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
-                else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
+                else {
+                    p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
+                    if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * nu + (r - nx)] = v[i];  // first controls straight to the host
+                }
                 if (FAM) {
                     gGC[(size_t)kn * 64] = gc[i];
                     gGL[(size_t)kn * 64] = gl[i];

@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     const double pnref = p.tables[(size_t)3 * TOFF + r];
     const double rho = p.rho;
     const double x0v = (inst_ok && is_x) ? p.x0[inst * nx + r] : 0.0;
+    if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * nx + r] = x0v;  // zero-copy tick: x0 came from host memory
     const int dIdx = is_u ? (j * nu + (r - nx)) : 0;
     const int koff = is_x ? 1 : 0;
     const int ct_ = p.check_termination;
@@ -274,6 +275,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             const double sol = sV[e];
             if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = sol;
             if (is_u && kn < N - 1) p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = sol;
+            if (is_u && kn == 0 && p.u0_host) p.u0_host[(size_t)inst * nu + (r - nx)] = sol;  // first controls straight to the host
         }
         if (is_u)
             for (int i = 0; i < N - 1; ++i) gD[i * dstride + dIdx] = sD[i * dstride + dIdx];
