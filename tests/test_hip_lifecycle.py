@@ -118,3 +118,50 @@ def test_scalar_and_vector_argument_expansion_through_the_boundary(pkg):
     np.testing.assert_array_equal(a.get_solution()["controls"], b.get_solution()["controls"])
     np.testing.assert_array_equal(a.get_solution()["states"], b.get_solution()["states"])
     a.reset(); b.reset()
+
+
+def test_single_instance_host_path_states(pkg):
+    """Single-instance handles serve set_x0 / get_solution / get_stats from pinned host memory (no device copies around
+    the launch). Every ordering of the verbs must still read what the device would have returned."""
+    P = pkg.problems
+    prob = P.quadrotor(20)
+    settings = dict(max_iter=40, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    s = _new(pkg, prob, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    o = O.OraclePort(prob).load_problem(prob, settings)
+    # x0 set twice before the solve: the last one counts; nothing solved yet -> zeros
+    s.set_x0(0.3 * prob.x0)
+    s.set_x0(prob.x0)
+    assert not s.get_solution()["controls"].any() and s.get_stats()["iter"] == 0
+    o.set_x0(prob.x0)
+    for tick in range(3):
+        s.solve_async()          # asynchronous launch: the getters must wait for it
+        sol, st = s.get_solution(), s.get_stats()
+        o.solve()
+        assert st["iter"] == o.stats()["iter"] and st["status"] == o.stats()["status"]
+        assert rel_err(sol["states"], o.solution()[0]) < TOL and rel_err(sol["controls"], o.solution()[1]) < TOL
+        np.testing.assert_array_equal(s.get_solution_batch()["controls"][:, :, 0], sol["controls"])
+        np.testing.assert_array_equal(s.get_first_controls_batch()[:, 0], sol["controls"][:, 0])  # device copy agrees
+        x = prob.A @ (prob.x0 * (1 - 0.2 * tick)) + prob.B @ sol["controls"][:, 0]
+        s.set_x0(x)
+        o.set_x0(x)
+    # a 0-iteration solve changes nothing; mpc_step and set_x0_batch override a pending host x0
+    before = s.get_solution()["controls"].copy()
+    s.update_settings(max_iter=0)
+    s.solve()
+    np.testing.assert_array_equal(s.get_solution()["controls"], before)
+    s.update_settings(max_iter=40)
+    s.set_x0(5.0 * prob.x0)                       # pending on the host ...
+    s.set_x0_batch(prob.x0[:, None])               # ... replaced through the batch verb
+    o.set_x0(prob.x0)
+    s.solve()
+    o.solve()
+    assert rel_err(s.get_solution()["controls"], o.solution()[1]) < TOL
+    s.set_x0(5.0 * prob.x0)
+    u = s.mpc_step(prob.x0[:, None])               # brings its own x0
+    o.solve()
+    assert rel_err(u[:, 0], o.solution()[1][:, 0]) < TOL
+    assert rel_err(s.get_solution()["controls"], o.solution()[1]) < TOL
+    s.reset_workspace()                            # cold start: solution and statistics read as zero again
+    assert not s.get_solution()["states"].any() and s.get_stats()["iter"] == 0
+    s.reset()

@@ -110,7 +110,15 @@ struct tinympc_solver {
     std::vector<int> Acx, qcx, Acu, qcu;
     std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
     double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
-    double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch
+    double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch (and x0 of single-instance handles)
+    // Single-instance handles (batch == 1, what the MEX shim creates): set_x0 only fills the pinned h_x0, the next
+    // launch reads it from there (and mirrors it into dx0), and the kernels also write solution + statistics into the
+    // pinned h_sol -- the reference's per-tick sequence set_x0 / solve / get_solution then costs ONE launch and ONE
+    // synchronisation instead of three synchronous copies around the launch.
+    double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status]
+    bool x0_on_host = false;           // h_x0 is newer than dx0
+    int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
+    bool host_path() const { return batch == 1 && h_sol != nullptr; }
     bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
     double *dscratch_state = nullptr;
     bool fam_dirty = true;
@@ -314,6 +322,17 @@ int launch(tinympc_solver *s, bool timed) {
         p.x0_mirror = s->dx0;
         p.u0_host = s->h_u0;
     }
+    if (s->host_path()) {
+        if (s->x0_on_host) {
+            p.x0 = s->h_x0;
+            p.x0_mirror = s->dx0;
+            s->x0_on_host = false;  // the kernel mirrors it into dx0
+        }
+        if (s->st.max_iter > 0) {   // (a 0-iteration solve writes nothing anywhere)
+            p.host_sol = s->h_sol;
+            s->host_sol_state = 1;
+        }
+    }
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -349,6 +368,7 @@ void destroy(tinympc_solver *s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
+    if (s->h_sol) (void)hipHostFree(s->h_sol);
     if (s->h_x0) (void)hipHostFree(s->h_x0);
     if (s->h_u0) (void)hipHostFree(s->h_u0);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -521,6 +541,12 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     HIP_TRY_S(hipMemsetAsync(s->distats, 0, sizeof(int) * batch * 2, s->stream));
     HIP_TRY_S(hipMemsetAsync(s->ddstats, 0, sizeof(double) * batch * 4, s->stream));
 
+    if (batch == 1) {
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_sol, sizeof(double) * (X + U + 6), hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx, hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu, hipHostMallocDefault));
+        std::memset(s->h_sol, 0, sizeof(double) * (X + U + 6));
+    }
     TRY(run_precompute(s));  // tiny_api.cpp:113
     HIP_TRY_S(hipStreamSynchronize(s->stream));
 #undef TRY
@@ -547,6 +573,12 @@ int tinympc_set_x0(tinympc_solver *s, const double *x0, int len, int verbose) {
     // The reference only perror()s on a wrong length and still assigns (tiny_api.cpp:238-241); an
     // Eigen column assignment of the wrong length is undefined behaviour, so the C ABI rejects it.
     if (len != s->nx) return fail(TINYMPC_ERR_INVALID_INPUT, "set_x0: x0 has %d entries, expected %d", len, s->nx);
+    if (s->host_path()) {  // no device call at all: the next launch picks x0 up from pinned host memory
+        std::memcpy(s->h_x0, x0, sizeof(double) * s->nx);
+        s->x0_on_host = true;
+        if (verbose) printf("Initial state set\n");
+        return TINYMPC_OK;
+    }
     if ((rc = bind_device(s))) return rc;
     rc = upload(s, s->dx0, x0, s->nx);
     if (!rc && verbose) printf("Initial state set\n");
@@ -614,6 +646,7 @@ int tinympc_synchronize(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->host_sol_state == 1) s->host_sol_state = 2;
     return TINYMPC_OK;
 }
 
@@ -637,6 +670,7 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms) {
     if ((rc = refresh_derived(s))) return rc;  // keep table rebuilds out of the timed region
     if ((rc = launch(s, true))) return rc;
     HIP_TRY(hipEventSynchronize(s->ev1));
+    if (s->host_sol_state == 1) s->host_sol_state = 2;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     if (kernel_ms) *kernel_ms = ms;
@@ -649,6 +683,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     if (!x0s || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "mpc_step: x0s and u0_out are required");
     if ((rc = bind_device(s))) return rc;
     const size_t nx0 = (size_t)s->batch * s->nx, nu0 = (size_t)s->batch * s->nu;
+    s->x0_on_host = false;  // this call brings its own x0
     if (!s->h_x0) {  // pinned staging, so that the small copies are true async DMA and need no extra sync
         HIP_TRY(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx0, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
@@ -679,6 +714,12 @@ int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, 
     if (rc) return rc;
     if (first < 0 || count < 0 || first + count > s->batch)
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if (s->host_path() && count == 1 && s->host_sol_state != 0) {
+        if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
+        if (x_out) std::memcpy(x_out, s->h_sol, sizeof(double) * s->X());
+        if (u_out) std::memcpy(u_out, s->h_sol + s->X(), sizeof(double) * s->U());
+        return TINYMPC_OK;
+    }
     if ((rc = bind_device(s))) return rc;
     if (x_out && (rc = download(s, x_out, s->dsolx + (size_t)first * s->X(), sizeof(double) * s->X() * count))) return rc;
     if (u_out && (rc = download(s, u_out, s->dsolu + (size_t)first * s->U(), sizeof(double) * s->U() * count))) return rc;
@@ -709,6 +750,14 @@ int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *
     if (rc) return rc;
     if (first < 0 || count < 0 || first + count > s->batch)
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
+    if (s->host_path() && count == 1 && s->host_sol_state != 0) {
+        if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
+        const double *hs = s->h_sol + s->X() + s->U();
+        if (iters) iters[0] = (int)hs[4];
+        if (status) status[0] = (int)hs[5];
+        if (residuals) std::memcpy(residuals, hs, sizeof(double) * 4);
+        return TINYMPC_OK;
+    }
     if ((rc = bind_device(s))) return rc;
     if (iters || status) {
         std::vector<int> is((size_t)count * 2);
@@ -1017,6 +1066,7 @@ int tinympc_set_x0_batch(tinympc_solver *s, const double *x0s, int first, int co
     if (first < 0 || count < 0 || first + count > s->batch)
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
     if ((rc = bind_device(s))) return rc;
+    s->x0_on_host = false;
     return upload(s, s->dx0 + (size_t)first * s->nx, x0s, (size_t)count * s->nx);
 }
 
@@ -1027,6 +1077,7 @@ int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int firs
     if (first < 0 || count < 0 || first + count > s->batch)
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
     if ((rc = bind_device(s))) return rc;
+    s->x0_on_host = false;
     HIP_TRY(hipMemcpyAsync(s->dx0 + (size_t)first * s->nx, d_x0s, sizeof(double) * count * s->nx, hipMemcpyDeviceToDevice, s->stream));
     return TINYMPC_OK;
 }
@@ -1049,6 +1100,7 @@ int tinympc_reset_workspace(tinympc_solver *s) {
     HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));
     HIP_TRY(hipMemsetAsync(s->ddstats, 0, sizeof(double) * s->batch * 4, s->stream));
     HIP_TRY(launch_fill(s->drho_inst, (size_t)s->batch, s->rho, s->stream));  // adapted rho back to the setup value
+    s->host_sol_state = 0;  // the device solution / statistics were just zeroed: read them from there
     return TINYMPC_OK;
 }
 

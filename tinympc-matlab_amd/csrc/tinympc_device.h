@@ -123,6 +123,10 @@ struct SolveParams {
     // mirrored into the device copy; the first controls are also written straight into pinned host memory.
     double *x0_mirror;    // [batch][nx] or NULL
     double *u0_host;      // [batch][nu] or NULL
+    // Single-instance handles (the MEX use): solution and statistics are also written into pinned host memory, laid
+    // out [nx*N | nu*(N-1) | pri_x, dua_x, pri_u, dua_u | iter, status (as doubles)], so that get_solution / get_stats
+    // after a synchronous solve are host copies. NULL otherwise.
+    double *host_sol;
 };
 
 struct ChunkTableParams {

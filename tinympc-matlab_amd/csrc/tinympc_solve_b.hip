@@ -362,6 +362,10 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
             if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = sol;
             if (is_u && kn < N - 1) p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = sol;
             if (is_u && kn == 0 && p.u0_host) p.u0_host[(size_t)inst * nu + (r - nx)] = sol;  // first controls straight to the host
+            if (p.host_sol) {  // single-instance handle: the solution also goes straight into pinned host memory
+                if (is_x) p.host_sol[(size_t)kn * nx + r] = sol;
+                if (is_u && kn < N - 1) p.host_sol[(size_t)N * nx + (size_t)kn * nu + (r - nx)] = sol;
+            }
         }
         if (is_u)
             for (int i = 0; i < N - 1; ++i) gD[i * dstride + dIdx] = sD[i * dstride + dIdx];
@@ -369,6 +373,12 @@ __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) 
     if (inst_ok && r == 0) {
         p.istats[inst * 2 + 0] = it_done;
         p.istats[inst * 2 + 1] = status;
+        if (p.host_sol) {
+            double *hs = p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu;
+            hs[4] = (double)it_done;
+            hs[5] = (double)status;
+            if (res_valid) { hs[0] = res_px; hs[1] = res_dx; hs[2] = res_pu; hs[3] = res_du; }
+        }
         if (res_valid) {
             p.dstats[inst * 4 + 0] = res_px;
             p.dstats[inst * 4 + 1] = res_dx;

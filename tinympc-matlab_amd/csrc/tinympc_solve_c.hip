@@ -459,10 +459,15 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 const int k = c * S + i, kn = k + koff;
                 gG[(size_t)kn * 64] = g[i];
                 gV[(size_t)kn * 64] = converged ? vprev[i] : v[i];  // converged: the reference returns before v <- vnew
-                if (is_x) p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
-                else {
+                if (is_x) {
+                    p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
+                } else {
                     p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
                     if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * nu + (r - nx)] = v[i];  // first controls straight to the host
+                }
+                if (p.host_sol) {  // single-instance handle: the solution also goes straight into pinned host memory
+                    if (is_x) p.host_sol[(size_t)kn * nx + r] = v[i];
+                    else p.host_sol[(size_t)N * nx + (size_t)kn * nu + (r - nx)] = v[i];
                 }
                 if (FAM) {
                     gGC[(size_t)kn * 64] = gc[i];
@@ -475,6 +480,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             gG[0] = g0;
             gV[0] = converged ? v0prev : v0;
             p.sol_x[(size_t)inst * N * nx + r] = v0;
+            if (p.host_sol) p.host_sol[r] = v0;
             if (FAM) {
                 gGC[0] = gc0;
                 gGL[0] = gl0;
@@ -484,6 +490,12 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     if (tid == 0) {
         p.istats[inst * 2 + 0] = it_done;
         p.istats[inst * 2 + 1] = status;
+        if (p.host_sol) {
+            double *hs = p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu;
+            hs[4] = (double)it_done;
+            hs[5] = (double)status;
+            if (res_valid) { hs[0] = res_px; hs[1] = res_dx; hs[2] = res_pu; hs[3] = res_du; }
+        }
         if (res_valid) {
             p.dstats[inst * 4 + 0] = res_px;
             p.dstats[inst * 4 + 1] = res_dx;

@@ -26,3 +26,27 @@ for name, prob in (("cartpole N=10", P.cartpole(10, True)), ("quadrotor N=20", P
             x = prob.A @ x + prob.B @ u0
         print(f"{name:16s} B={B:5d}: fused mpc_step {1e6*t_fused/n:7.1f} us | 3-verb tick {1e6*(t_set+t_solve+t_get)/n:8.1f} us  (set_x0 {1e6*t_set/n:6.1f}, solve {1e6*t_solve/n:7.1f}, get_u0 {1e6*t_get/n:6.1f}; max iters/tick {iters/n:.1f})")
         s.reset()
+
+# The reference's own per-tick sequence (examples/cartpole_example_mpc.m:36-44): set_x0 -> solve -> get_solution on a
+# single-instance handle, i.e. what the MEX shim issues. Timed around the three C-ABI calls.
+import ctypes as C
+L = pkg.load_library()
+for name, prob in (("cartpole N=10", P.cartpole(10, True)), ("quadrotor N=50", P.quadrotor(50))):
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    x = prob.x0.copy()
+    X = np.zeros((prob.nx, prob.N), order="F"); U = np.zeros((prob.nu, prob.N - 1), order="F")
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    t = [0.0, 0.0, 0.0]; n = 200
+    for k in range(n + 20):
+        xx = np.ascontiguousarray(x)
+        t0 = time.perf_counter(); L.tinympc_set_x0(s._h, dp(xx), prob.nx, 0)
+        t1 = time.perf_counter(); L.tinympc_solve(s._h, 0)
+        t2 = time.perf_counter(); L.tinympc_get_solution(s._h, dp(X), dp(U), 0)
+        t3 = time.perf_counter()
+        if k >= 20:
+            t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2
+        x = prob.A @ x + prob.B @ U[:, 0]
+    print(f"{name:16s} single-instance verbs: set_x0 {1e6*t[0]/n:5.1f} + solve {1e6*t[1]/n:5.1f} + get_solution {1e6*t[2]/n:5.1f} = {1e6*sum(t)/n:6.1f} us per tick")
+    s.reset()
