@@ -237,9 +237,12 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
 /* One closed-loop control tick for every instance of the handle (the loop of
  * examples/cartpole_example_mpc.m:36-44 / rocket_landing_constraints.m:86-121 as ONE call): upload the
  * measured states x0s (nx x batch), run the warm-started solve, download the first control of each
- * instance into u0_out (nu x batch). One stream submission (H2D, kernel, D2H through pinned staging
- * buffers) and one synchronisation instead of three synchronous verbs; results are identical to
- * tinympc_set_x0_batch + tinympc_solve + tinympc_get_first_controls_batch. */
+ * instance into u0_out (nu x batch). One stream submission and one synchronisation instead of three
+ * synchronous verbs: up to 256 instances the kernel reads x0 from and writes the first controls to pinned
+ * host memory itself (no copy engine involved), larger batches go through two async copies. Results are
+ * identical to tinympc_set_x0_batch + tinympc_solve + tinympc_get_first_controls_batch.
+ * (Single-instance handles get the same treatment for the plain verbs: tinympc_set_x0 only fills a pinned
+ * buffer the next launch reads, and tinympc_get_solution / tinympc_get_stats after a solve are host copies.) */
 int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out);
 
 /* Launch geometry of the solve kernel, for reports: lanes per instance, instances per wavefront,
@@ -248,8 +251,10 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
 int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave,
                             int *workgroups, int *lds_bytes, int *tables_in_lds);
 
-/* Which solve kernel the handle uses: 'A' (all ADMM state in LDS, one wavefront per workgroup) or 'B'
- * (V as an L2-resident HBM ping-pong pair, four wavefronts per workgroup). 0 for a NULL handle. */
+/* Which solve kernel the handle uses for box-constrained solves: 'A' (all ADMM state in LDS, one wavefront per
+ * workgroup), 'B' (V L2-resident in HBM, four wavefronts per workgroup; large batches) or 'C' (one instance per
+ * workgroup, horizon swept in 16 concurrent chunks; batches up to 1,024 and every single solve). The
+ * environment variable TINYMPC_LAYOUT=A|B|C overrides the choice at setup. 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
 
 /* The HIP stream of the handle as an opaque pointer (hipStream_t). */
