@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
     int it_done = 0;
     int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
     bool res_valid = false;
-    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    double snap_pri = 0.0, snap_dua = 0.0;  // this lane's residual maxima at its instance's last termination check
 
     for (int it = 0; it < p.max_iter; ++it) {  // admm.cpp:129
         if (__ballot(active) == 0ull) break;
@@ -187,16 +187,17 @@ __global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
-        // ---------------- R1: inf-norm residuals (admm.cpp:93-101), one butterfly per iteration
+        // ---------------- R1: termination test (admm.cpp:93-101)
         if (check) {
-            const double px = group_max<W>(is_x ? pri : 0.0);
-            const double pu = group_max<W>(is_u ? pri : 0.0);
-            const double dx = group_max<W>(is_x ? dua : 0.0) * rho;
-            const double du = group_max<W>(is_u ? dua : 0.0) * rho;
+            // decided element-wise with one ballot (max_i a_i < tol iff every a_i < tol; rho > 0): see tinympc_solve_b.hip
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+            const bool conv = ((__ballot(below) >> (j * W)) & ones) == ones;
             if (active) {
-                res_px = px; res_dx = dx; res_pu = pu; res_du = du;
+                snap_pri = pri;
+                snap_dua = dua;
                 res_valid = true;
-                if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
+                if (conv) {
                     status = 1;  // TINY_SOLVED: stop this instance before the backward pass (admm.cpp:181-192)
                     active = false;
                 }
@@ -234,6 +235,10 @@ __global__ void __launch_bounds__(64) k_admm_solve(const SolveParams p) {
     }
 
     // ---- write-back: state for the next (warm-started) solve, solution, stats
+    // the four norms of the last check (for get_stats), reduced once
+    const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
+
     if (p.max_iter > 0 && inst_ok) {
         for (int kn = 0; kn < N; ++kn) {
             const int e = (kn + 1) * 64 + lane;

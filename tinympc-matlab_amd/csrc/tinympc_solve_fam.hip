@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     int it_done = 0;
     int status = 11;
     bool res_valid = false;
-    double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
+    double snap_pri = 0.0, snap_dua = 0.0;  // this lane's residual maxima at its instance's last termination check
 
     for (int it = 0; it < p.max_iter; ++it) {
         if (__ballot(active) == 0ull) break;
@@ -222,14 +222,15 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
 
         // ---------------- residuals (box family only, as upstream)
         if (check) {
-            const double px = group_max<W>(is_x ? pri : 0.0);
-            const double pu = group_max<W>(is_u ? pri : 0.0);
-            const double dx = group_max<W>(is_x ? dua : 0.0) * rho;
-            const double du = group_max<W>(is_u ? dua : 0.0) * rho;
+            // decided element-wise with one ballot (max_i a_i < tol iff every a_i < tol; rho > 0): see tinympc_solve_b.hip
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+            const bool conv = ((__ballot(below) >> (j * W)) & ones) == ones;
             if (active) {
-                res_px = px; res_dx = dx; res_pu = pu; res_du = du;
+                snap_pri = pri;
+                snap_dua = dua;
                 res_valid = true;
-                if (px < p.abs_pri_tol && pu < p.abs_pri_tol && dx < p.abs_dua_tol && du < p.abs_dua_tol) {
+                if (conv) {
                     status = 1;
                     active = false;
                 }
@@ -266,6 +267,10 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             if (i == 0) bstep(A, B);
         }
     }
+
+    // the four norms of the last check (for get_stats), reduced once
+    const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
 
     if (p.max_iter > 0 && inst_ok) {
         for (int kn = 0; kn < N; ++kn) {
