@@ -21,12 +21,14 @@ assert TOL < TOL_BAR
 SINGLE = ["cartpole_unconstrained", "cartpole_box_tol", "cartpole_box_200", "quadrotor_box_200", "quadrotor_box_tol"]
 
 
-@pytest.fixture(autouse=True, params=["A", "B", "C"])
+@pytest.fixture(autouse=True, params=["A", "B", "C", "D"])
 def kernel_layout(request, monkeypatch):
-    """Every test runs against all three solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip),
-    layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip) and layout C (one instance per
-    workgroup, horizon swept in 16 concurrent chunks, tinympc_solve_c.hip). The layout is chosen at setup time;
-    where B does not apply (W > 16 or N < 8) or C does not (W > 16 or N > 129) the library falls back."""
+    """Every test runs against all four solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip),
+    layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip), layout C (one instance per
+    workgroup, horizon swept in 16 concurrent chunks, tinympc_solve_c.hip) and layout D (horizon unrolled at compile
+    time, state in registers, two waves per SIMD, tinympc_solve_d.hip). The layout is chosen at setup time;
+    where B does not apply (W > 16 or N < 8), C does not (W > 16 or N > 129) or D does not (shape not compiled in,
+    time-varying bounds / references) the library falls back."""
     monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
     return request.param
 
@@ -68,7 +70,11 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     s.reset()
     s = make_solver(pkg, P.quadrotor(50), {}, batch=2048)
     info = s.launch_info()
-    assert info["layout"] == "B" and info["workgroups"] == 128 and info["lds_bytes"] <= 160 * 1024  # large batch: B where it fits
+    assert info["layout"] == "D" and info["workgroups"] == 64  # large batch of a compiled-in shape: two waves per SIMD
+    s.reset()
+    s = make_solver(pkg, P.quadrotor(40), {}, batch=2048)
+    info = s.launch_info()
+    assert info["layout"] == "B" and info["workgroups"] == 128 and info["lds_bytes"] <= 160 * 1024  # other horizons: B where it fits
     s.reset()
     monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})

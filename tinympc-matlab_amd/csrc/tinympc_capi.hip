@@ -95,6 +95,10 @@ struct tinympc_solver {
     bool tables_in_lds = false;
     bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
     bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
+    // Horizon unrolled at compile time, state in registers, two waves per SIMD (tinympc_solve_d.hip). Wanted for large
+    // batches of a shape that is compiled in; each launch still checks that bounds / references are time-invariant and
+    // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
+    bool layout_d = false;
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
     bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
@@ -118,13 +122,16 @@ struct tinympc_solver {
     double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status]
     bool x0_on_host = false;           // h_x0 is newer than dx0
     int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
-    bool host_path() const { return batch == 1 && h_sol != nullptr; }
+    bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d; }  // (layout D writes to device memory only)
     bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
     double *dscratch_state = nullptr;
     bool fam_dirty = true;
     size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
     bool tables_in_lds_a = false;
 
+    bool use_layout_d() const {
+        return layout_d && tables_const() && !families_active() && !st.adaptive_rho;
+    }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
@@ -317,7 +324,7 @@ int launch(tinympc_solver *s, bool timed) {
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     p.const_tables = s->tables_const() ? 1 : 0;
-    if (s->zero_copy_tick) {  // set by tinympc_mpc_step_batch for the duration of one launch
+    if (s->zero_copy_tick && !s->use_layout_d()) {  // set by tinympc_mpc_step_batch for the duration of one launch
         p.x0 = s->h_x0;
         p.x0_mirror = s->dx0;
         p.u0_host = s->h_u0;
@@ -350,6 +357,8 @@ int launch(tinympc_solver *s, bool timed) {
         // handle can switch between them from one solve to the next.
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (s->use_layout_d()) {
+        HIP_TRY(launch_solve_d(p, s->stream));
     } else if (s->layout_c) {
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
@@ -481,14 +490,21 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         bool want_c = c_possible && batch <= kLayoutCBatchMax;
         if (const char *env = getenv("TINYMPC_LAYOUT")) {
             if (env[0] == 'C' || env[0] == 'c') want_c = c_possible;
-            else if (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b') want_c = false;
+            else if (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b' || env[0] == 'D' || env[0] == 'd') want_c = false;
         }
         s->layout_c = want_c;
+        // Layout D: default above the latency kernel's range for the shapes compiled in; TINYMPC_LAYOUT=D forces it at
+        // any batch size (tests), =A / =B / =C exclude it.
+        const bool d_possible = (W == 16) && solve_d_supported(nx, nu, N, true);
+        bool want_d = d_possible && !want_c;
+        if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = d_possible && (env[0] == 'D' || env[0] == 'd');
+        s->layout_d = want_d;
+        if (want_d) s->layout_c = false;
         // The families: k_admm_solve_fam keeps the whole ADMM state in LDS (layout A), so a long horizon leaves it
         // one wavefront = 4 instances per CU; the latency kernel then wins at EVERY batch size (rocket N=100:
         // 30 vs 15.6 M iterations/s at 4096 instances, profiles/r01d_rocket_sweep.txt). Otherwise as for the box path.
         bool c_excluded = false;
-        if (const char *env = getenv("TINYMPC_LAYOUT")) c_excluded = (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b');
+        if (const char *env = getenv("TINYMPC_LAYOUT")) c_excluded = (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b' || env[0] == 'D' || env[0] == 'd');
         const size_t fam_a_waves_per_cu = s->state_in_global ? 1 : kLdsMax / (s->lds_bytes_a ? s->lds_bytes_a : kLdsMax);
         s->fam_c = c_possible && !c_excluded && (want_c || fam_a_waves_per_cu <= 1);
         s->c_tables = s->layout_c || s->fam_c;
@@ -689,7 +705,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
-    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0) {
+    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d()) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
@@ -1127,13 +1143,13 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->use_layout_d() ? solve_d_workgroups(s->groups) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)(s->layout_c ? s->lds_bytes_c : s->lds_bytes);
     if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
     return TINYMPC_OK;
 }
 
-int tinympc_get_layout(tinympc_solver *s) { return s ? (s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
+int tinympc_get_layout(tinympc_solver *s) { return s ? (s->use_layout_d() ? 'D' : s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
 
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 

@@ -177,6 +177,11 @@ hipError_t launch_solve(const SolveParams &p, int W, int KT, size_t lds_bytes, h
 hipError_t launch_solve_b(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 size_t solve_b_lds_bytes(int nx, int nu, int N, int W);
 constexpr int WAVES_PER_GROUP_B = 4;
+// Layout D: horizon unrolled at compile time, duals in registers, slack split between registers and LDS, two waves
+// per SIMD. Only for the (nx, nu, N) shapes compiled into the library and time-invariant bounds / references.
+bool solve_d_supported(int nx, int nu, int N, bool const_tables);
+hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream);
+int solve_d_workgroups(int groups);
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 // Layout C: one instance per 256-thread workgroup, the horizon swept in 16 concurrent chunks (latency kernel

@@ -1,0 +1,454 @@
+// tinympc_solve_d.hip -- k_admm_solve_d: the solve kernel in "layout D" (register-resident throughput layout), gfx950 FP64.
+//
+// Same algorithm and lane layout as the other solve kernels (tinympc_solve.hip has the reference citations:
+// M1 solve admm.cpp:109-207 = F1 :25-35, S1 :43-59, D1 :65-69, L1 :75-83, R1 :89-107, C1 :196-197, B1 :13-20).
+// What changes is where the ADMM state lives and, with it, how many wavefronts a SIMD runs:
+//
+//   layout B   G + D in LDS (33 KB per wave), V in HBM/L2        -> LDS caps a CU at 4 waves = ONE per SIMD; a lone wave
+//              issues one VALU instruction per ~8 cycles on the dependent FP64 chain; 104 of 512 VGPRs in use.
+//   layout D   the horizon is a COMPILE-TIME constant and both sweeps are fully unrolled, so every knot's dual g|y
+//              has its own register pair (2*(N-1)+2 VGPRs) and the slack v|z is split between registers and LDS; LDS
+//              holds only the feed-forward d (compact), part of v|z and one copy of the sweep operators per workgroup.
+//              <= 256 VGPRs and <= 20 KB of LDS per wave -> 8 waves per CU = TWO per SIMD, whose FP64 chains
+//              interleave. HBM is touched at entry and exit only (plus the conditional stale copy, below).
+//
+// Per sweep step the instruction stream is one asm block (tinympc_solve_d_chain.h): mov + (nx+nu) fused DPP FMAs +
+// the 8-instruction row-local block going forward, (nx+nu) FMAs + 3 going backward; no address arithmetic (LDS
+// immediate offsets), no selects:
+//   * the chain's columns k < nx read the state operand register, columns k >= nx the input-row operand register
+//     (two different DPP sources), so [x_i; d_i] / [p_{i+1}; r_i] are never merged into one register;
+//   * going backward every lane uses the SAME slot: slot s holds knot s+1 on state lanes and knot s on input lanes,
+//     q_s is folded into the accumulator's start value (state lanes) instead of being added after the mat-vec;
+//   * a converged instance is frozen by EXEC (its 16 lanes are one DPP row, so row_newbcast never crosses the mask),
+//     not by redirecting stores.
+// The sweep operators' rows (16 doubles per lane each) are re-read from LDS at the start of every sweep: holding both
+// for the whole solve would cost 32 more VGPRs than the budget has.
+//
+// Reference semantics that need care are those of layout B (tinympc_solve_b.hip): per-instance termination,
+// `iter % check_termination` with iter already incremented, the solution is vnew/znew, and a converged solve leaves
+// the PREVIOUS iterate in v/z (admm.cpp:181-197) -- the stale copy goes to p.V2, written only in sweeps that can
+// still end converged (decided every D_GROUP steps, exact because the residual maxima only grow).
+#include <type_traits>
+
+#include "tinympc_device.h"
+#include "tinympc_sweep.h"
+
+namespace tinympc {
+template <int NX, int NU>
+struct DStep;  // specialised per (nx, nu) by tinympc_solve_d_chain.h
+}  // namespace tinympc
+
+// The (nx, nu) pairs compiled into the library: quadrotor, cartpole, rocket landing (BASELINE.json configs 2-5).
+#define D_NX 12
+#define D_NU 4
+#include "tinympc_solve_d_chain.h"
+#define D_NX 4
+#define D_NU 1
+#include "tinympc_solve_d_chain.h"
+
+namespace tinympc {
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// ---- LDS plan per workgroup, in doubles: operators [2][16 k][16 r] | tables (!CT) | per wave: V[VL][64], D[(N-1)*4*nu]
+constexpr int D_OPS_DOUBLES = 2 * 16 * 16;
+constexpr int D_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
+constexpr int D_VREG_MAX = 24;    // slack knots kept in registers (the rest goes to LDS)
+constexpr int D_LDS_PER_CU = 160 * 1024;
+__host__ __device__ constexpr int d_d_doubles(int nu, int N) { return ((N - 1) * 4 * nu + 1) & ~1; }
+__host__ __device__ constexpr int d_tab_doubles(int N) { return 3 * (N + 2) * 16 + 16; }
+// number of slack slots in LDS; -1 if the shape does not fit the plan (8 waves per CU)
+__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg) {
+    const int ns = N - 1;
+    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / 8 - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N));
+    const int wave_doubles = wg_doubles / wpg - d_d_doubles(nu, N);
+    if (wave_doubles < 0) return -1;
+    const int vlmax = wave_doubles / 64;
+    const int want = ns > D_VREG_MAX ? ns - D_VREG_MAX : 0;
+    return want <= vlmax ? want : -1;
+}
+__host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg, int vl) {
+    return sizeof(double) * ((size_t)D_OPS_DOUBLES + (ct ? 0 : d_tab_doubles(N)) + (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
+}
+
+// LDS traffic of the sweeps goes through asm volatile so that WHERE a read is issued is this file's decision, not the
+// scheduler's (see tinympc_solve_d_chain.h): reads are issued one block ahead and retired by the block's own s_waitcnt.
+typedef __attribute__((address_space(3))) double lds_double_t;
+__device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double_t *)p; }
+template <int OFF>
+__device__ __forceinline__ double lds_read_async(unsigned addr) {  // the value is valid after the next s_waitcnt lgkmcnt(0)
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_async(unsigned addr, double v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the lanes that
+// are still iterating. True if some live instance (16-lane row) has no bad lane.
+__device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsigned long long live) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long b = (bad >> (j * 16)) & 0xffffull, l = (live >> (j * 16)) & 0xffffull;
+        any = any || (l != 0ull && b == 0ull);
+    }
+    return any;
+}
+
+template <int NX, int NU, int N, bool CT, int WPG, int VL>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
+    constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
+    constexpr int TOFF = (N + 2) * W;
+    static_assert(NS >= 3 && VL >= 0 && VL <= NS, "layout D: N >= 4");
+    using Step = DStep<NX, NU>;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane >> 4, r = lane & 15;
+    const long grp = (long)blockIdx.x * WPG + wv;
+    const bool grp_ok = grp < p.groups;
+    const long inst = grp * IPW + j;
+    const bool is_x = r < NX;
+    const bool is_u = (r >= NX) && (r < NXU);
+    const bool inst_ok = grp_ok && inst < p.batch;
+    const int koff = is_x ? 1 : 0;  // slot s = knot s+1 on state lanes, knot s on input lanes
+
+    double *sOps = smem;
+    double *sT = smem + D_OPS_DOUBLES;
+    double *sV = sT + (CT ? 0 : d_tab_doubles(N)) + (size_t)wv * (VL * 64 + d_d_doubles(NU, N));
+    double *sD = sV + VL * 64;
+
+    // ---- workgroup-shared: the two sweep operators, transposed to [k][r] (conflict-free row reads), and the tables
+    for (int i = threadIdx.x; i < D_OPS_DOUBLES; i += 64 * WPG) {
+        const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
+        sOps[i] = (k < KT) ? p.ops[(size_t)which * W * KT + (size_t)rr * KT + k] : 0.0;
+    }
+    if constexpr (!CT)
+        for (int i = threadIdx.x; i < d_tab_doubles(N); i += 64 * WPG) sT[i] = p.tables[i];
+
+    const size_t g0 = grp_ok ? (size_t)grp : 0;
+    double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
+    double *const gD = p.D + g0 * (size_t)(NS * DS);
+    double *const gV0 = p.V + (g0 * v_rows(N) + V_PAD) * 64 + lane;    // canonical v|z, knot 0
+    double *const gV1u = p.V2 + (g0 * v_rows(N) + V_PAD) * 64;         // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset)
+    const unsigned voff = (unsigned)(lane + koff * 64);
+    double *const sVl = sV + lane;
+    if (grp_ok) {
+        for (int i = lane; i < NS * DS; i += 64) sD[i] = gD[i];
+        static_for<0, VL>([&](auto S) { sVl[S.value * 64] = gV0[(S.value + koff) * 64]; });
+    }
+    __syncthreads();  // the only workgroup-wide barrier: from here on the waves are independent
+    if (!grp_ok) return;
+
+    // ---- register-resident state
+    double G[NS], G0, Vr[NVR > 0 ? NVR : 1], V0;
+    static_for<0, NS>([&](auto S) { G[S.value] = gG[(S.value + koff) * 64]; });
+    static_for<0, NVR>([&](auto S) { Vr[S.value] = gV0[(VL + S.value + koff) * 64]; });
+    G0 = gG[0];
+    V0 = gV0[0];
+
+    const double cf = p.ops[(size_t)2 * W * KT + r];
+    const double cb = p.ops[(size_t)2 * W * KT + W + r];
+    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    const double rho = p.rho, nrho = -p.rho;
+    const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
+    const double rhom = is_x ? nrho : 0.0;
+    const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+    const int dIdx = j * NU + (is_u ? r - NX : 0);
+    const double *const sDr = sD + dIdx;
+    double *const sDw = sD + dIdx;
+    const double *const sTl = sT + koff * W + r;  // (!CT) row of slot s: sTl[(s + 1) * W]
+    const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
+    const unsigned aV = lds_addr(sVl), aD = lds_addr(sDr);
+    const int ct = p.check_termination;
+
+    // Control: an instance that converges stops being `active` but its lanes keep iterating as a zombie (the sweeps are
+    // unconditional for all 64 lanes -- no EXEC-masked region around the unrolled body). Its state is written back at
+    // the top of the next round, before the next forward sweep touches G and V; the backward sweep in between leaves
+    // G and V alone and skips a zombie's d. Instances that hit max_iter are written back by the same code in round
+    // `max_iter`, which does nothing else.
+    bool active = inst_ok;
+    bool pending = false;  // converged in the previous round: state not yet written back
+    int it_done = 0;
+    int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
+    bool res_valid = false;
+    double snap_pri = 0.0, snap_dua = 0.0;
+
+    auto load_ops = [&](const double *src, double (&m)[16]) {
+        static_for<0, 16>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * 16]; });
+    };
+    auto vget = [&](auto S) -> double {
+        if constexpr (decltype(S)::value >= VL) return Vr[decltype(S)::value - VL];
+        else return sVl[decltype(S)::value * 64];
+    };
+
+    const int max_iter = p.max_iter;
+    for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129
+        // (readfirstlane: keeps the loop counter and everything derived from it in SGPRs, so that the branches below
+        // are scalar branches and not EXEC-masked regions)
+        const int it0 = __builtin_amdgcn_readfirstlane(it);
+        const bool final_round = it0 >= max_iter;
+        // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
+        // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
+        const bool wb = pending || (final_round && active);
+        if (__ballot(wb) != 0ull) {
+            // Rare path (once per instance and solve), kept small in registers rather than fast: addresses are rebuilt
+            // here from the kernel arguments (the opaque copy of `lane` keeps the compiler from hoisting them out of
+            // the iteration loop, where they would occupy registers the unrolled sweeps need).
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int r_o = lane_o & 15, j_o = lane_o >> 4;
+            const bool x_o = r_o < NX;
+            if (wb && r_o < NXU) {
+                const int ko = x_o ? 1 : 0;
+                const size_t inst_o = (size_t)grp * IPW + j_o;
+                double *const wG = p.G + (size_t)grp * (N + 1) * 64 + lane_o + ko * 64;                // slot 0
+                double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;   // slot 0
+                double *const wS = x_o ? p.sol_x + (inst_o * N + 1) * NX + r_o : p.sol_u + inst_o * NS * NU + (r_o - NX);  // slot 0
+                const int sst = x_o ? NX : NU;
+                if (x_o) {  // knot 0
+                    wG[-64] = G0;
+                    wV[-64] = V0;
+                    wS[-NX] = V0;
+                }
+                static_for<0, NS>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    const double vn = vget(S);
+                    wG[s * 64] = G[s];
+                    wV[s * 64] = vn;
+                    wS[s * sst] = vn;
+                });
+                if (!x_o) {
+                    double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
+                    for (int i = 0; i < NS; ++i) wD[i * DS] = sDw[i * DS];
+                }
+            }
+            pending = false;
+        }
+        if (final_round || __ballot(active) == 0ull) break;
+        const int it1 = it0 + 1;
+        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91 (iter already incremented, :143)
+
+        double pri = 0.0, dua = 0.0;
+        bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
+        double m[16];
+        load_ops(sMf, m);
+        // ---------------- knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
+        {
+            const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
+            if (may && is_x) gV1u[(unsigned)lane] = V0;
+            const double s = x0v + G0;
+            const double snew = fmin(hi0, fmax(lo0, s));
+            G0 = s - snew;
+            pri = is_x ? fabs(x0v - snew) : 0.0;
+            dua = is_x ? fabs(V0 - snew) : 0.0;
+            V0 = snew;
+        }
+        // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
+        // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
+        // PREVIOUS step's block and retired by that block's trailing s_waitcnt.
+        double xcur = x0v;
+        double dcur = lds_read_async<0>(aD), vcur = 0.0;
+        if constexpr (VL > 0) vcur = lds_read_async<0>(aV);
+        lds_wait();
+        auto fstep = [&](auto S) {
+            constexpr int q = decltype(S)::value;
+            double dn = 0.0, vn = 0.0;
+            if constexpr (q + 1 < NS) dn = lds_read_async<(q + 1) * DS * 8>(aD);
+            if constexpr (q + 1 < VL) vn = lds_read_async<(q + 1) * 512>(aV);
+            static_assert(CT, "time-varying tables: not in this build");
+            if constexpr (q >= VL) {
+                xcur = Step::fwd_reg(xcur, dcur, m, cf, lo_c, hi_c, G[q], Vr[q - VL], pri, dua);
+            } else {
+                double vnew;
+                xcur = Step::fwd_lds(xcur, dcur, m, cf, lo_c, hi_c, G[q], vcur, vnew, pri, dua);
+                lds_write_async<q * 512>(aV, vnew);
+            }
+            dcur = dn;
+            vcur = vn;
+        };
+        constexpr int NG = (NS + D_GROUP - 1) / D_GROUP;
+        static_for<0, NG>([&](auto Gi) {
+            constexpr int s0 = Gi.value * D_GROUP, s1 = (s0 + D_GROUP < NS) ? s0 + D_GROUP : NS;
+            if (may) {
+                // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
+                // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does
+                // not keep one pointer per slot alive across the iteration loop.
+                if constexpr (s0 > 0) {
+                    const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                    may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+                }
+                if (may) {
+                    unsigned vo = voff;
+                    double *base = gV1u;
+                    asm volatile("" : "+v"(vo), "+s"(base));
+                    static_for<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
+                }
+            }
+            static_for<s0, s1>([&](auto S) { fstep(S); });
+        });
+        if (active) it_done = it1;  // admm.cpp:143
+
+        // ---------------- R1: termination (admm.cpp:93-101), decided element-wise: one ballot, no reductions
+        if (check) {
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            const bool conv = ((__ballot(below) >> (j * W)) & 0xffffull) == 0xffffull;
+            if (active) {
+                snap_pri = pri;
+                snap_dua = dua;
+                res_valid = true;
+                if (conv) {
+                    status = 1;  // TINY_SOLVED: this instance stops before the backward pass (admm.cpp:181-192)
+                    active = false;
+                    pending = true;
+                }
+            }
+        }
+
+        // ---------------- backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G
+        {
+            const bool wr_d = is_u && active;  // a zombie keeps the d of its last real iteration
+            load_ops(sMb, m);
+            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type)
+                if constexpr (CT) return lr_c;
+                else return sTl[2 * TOFF + (S.value + 1) * W];
+            };
+            double px, rcur, rnext, acc;
+            {   // p_{N-1} (state lanes, admm.cpp:81-82) | r_{N-2} (input lanes) share slot NS-1; then slot NS-2
+                const double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
+                const double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
+                const double lrmc2 = is_x ? lr2 + cb : cb;
+                const double v1 = vget(std::integral_constant<int, NS - 1>{}), v2 = vget(std::integral_constant<int, NS - 2>{});
+                double t;
+                asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
+                    "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
+                    "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                    "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
+                    "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
+                    : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
+                    : [v1] "v"(v1), [g1] "v"(G[NS - 1]), [v2] "v"(v2), [g2] "v"(G[NS - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
+                      [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                rcur = px;
+            }
+            // slack operand of a block's tail: a register, or an LDS read issued one block ahead
+            auto vreq = [&](auto S) -> double {
+                if constexpr (decltype(S)::value >= VL) return Vr[decltype(S)::value - VL];
+                else return lds_read_async<decltype(S)::value * 512>(aV);
+            };
+            double v2cur = vreq(std::integral_constant<int, (NS >= 3 ? NS - 3 : 0)>{});
+            lds_wait();
+            static_for<0, NS - 1>([&](auto I) {
+                constexpr int s = NS - 1 - I.value;           // NS-1 .. 1
+                constexpr int s2 = s >= 2 ? s - 2 : 0;        // slot feeding the tail (s = 1: any finite t will do)
+                constexpr int s3 = s >= 3 ? s - 3 : 0;        // ... of the next block
+                // (an asynchronous read MUST be consumed after its wait: the destination of a dead one would be handed to
+                // the block's outputs while the read is still in flight)
+                double v2n = 0.0;
+                if constexpr (s >= 2) v2n = vreq(std::integral_constant<int, s3>{});
+                const double lr2 = lr_of(std::integral_constant<int, s2>{});
+                const double lrmc2 = is_x ? lr2 + cb : cb;
+                double a = acc, an, rn;
+                Step::bwd(a, px, rcur, m, v2cur, G[s2], rhom, lrmc2, nrho, lr2, an, rn);
+                if (wr_d) lds_write_async<s * DS * 8>(aD, a);  // d_s
+                px = a;
+                rcur = rnext;
+                rnext = rn;
+                acc = an;
+                v2cur = v2n;
+            });
+            {
+                double a = acc;
+                Step::bwd_last(a, px, rcur, m);
+                if (wr_d) lds_write_async<0>(aD, a);  // d_0
+            }
+        }
+    }
+    lds_wait();
+
+    // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
+    // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
+    if (inst_ok && status == 1 && r < NXU) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const int rows = is_x ? N : NS;
+        double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane;
+        const double *const wV2 = p.V2 + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane;
+        for (int kn = 0; kn < rows; ++kn) wV[kn * 64] = wV2[kn * 64];
+    }
+
+    const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
+
+    if (inst_ok && r == 0) {
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            p.dstats[inst * 4 + 0] = res_px;
+            p.dstats[inst * 4 + 1] = res_dx;
+            p.dstats[inst * 4 + 2] = res_pu;
+            p.dstats[inst * 4 + 3] = res_du;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Host side: the instantiation table. A shape runs on layout D only if it was compiled in.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int D_WPG = 8;
+
+template <int NX, int NU, int N, bool CT>
+static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
+    constexpr int VL = d_vl(NU, N, CT, D_WPG);
+    if constexpr (VL < 0) {
+        return hipErrorInvalidValue;
+    } else {
+        constexpr size_t lds = d_lds_bytes(NU, N, CT, D_WPG, VL);
+        static size_t lds_set[16] = {0};
+        auto fn = &k_admm_solve_d<NX, NU, N, CT, D_WPG, VL>;
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
+        if (e != hipSuccess) return e;
+        const int wgs = (p.groups + D_WPG - 1) / D_WPG;
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * D_WPG), lds, stream, p);
+        return hipGetLastError();
+    }
+}
+
+#define TINY_D_SHAPES(X) \
+    X(12, 4, 50)         \
+    X(4, 1, 20)          \
+    X(4, 1, 10)
+
+bool solve_d_supported(int nx, int nu, int N, bool const_tables) {
+    if (!const_tables) return false;
+#define X(NX_, NU_, N_) \
+    if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, true, D_WPG) >= 0;
+    TINY_D_SHAPES(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
+    if (!p.const_tables) return hipErrorInvalidValue;
+#define X(NX_, NU_, N_) \
+    if (p.nx == NX_ && p.nu == NU_ && p.N == N_) return launch_d_one<NX_, NU_, N_, true>(p, stream);
+    TINY_D_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+int solve_d_workgroups(int groups) { return (groups + D_WPG - 1) / D_WPG; }
+
+}  // namespace tinympc

@@ -1,0 +1,227 @@
+// tinympc_solve_d_chain.h -- X-macro body: the sweep-step asm blocks of layout D for ONE (nx, nu) pair.
+//
+// Include with D_NX and D_NU defined (tinympc_solve_d.hip does, once per supported pair). Defines the explicit
+// specialisation DStep<D_NX, D_NU>. The split of the fused DPP mat-vec chain into "columns fed by the state
+// operand" (k < nx) and "columns fed by the input-row operand" (nx <= k < nx+nu) has to be spelled in the asm
+// text itself, hence the preprocessor: column k reads %[x] or %[d] and columns >= nx+nu are not emitted at all
+// (rocket landing, nx+nu = 9: 9 FMAs per step where the run-time-nx kernels issue 12).
+//
+// What bounds a wavefront (tools/microbench_fp64_occupancy.hip, gpurun_out/mb_occ_r02.txt): in straight-line code a
+// DEPENDENT chain of v_fmac_f64_dpp issues every 4.1 cycles from a single wave -- the FP64 pipe's own rate (16 lanes
+// per clock), so the mat-vec needs neither partial sums nor interleaving. What does stall a wave is waiting for LDS:
+// hipcc sinks ds_reads next to their use and waits lgkmcnt(0) right behind them, exposing ~100+ cycles per step.
+// Hence every block is `asm volatile` and ends with its own s_waitcnt: the caller issues the NEXT step's LDS reads
+// (asm volatile, tinympc_solve_d.hip) right before a block, they complete in the shadow of the block's ~25 FP64
+// instructions, and the block's trailing wait makes them architecturally visible before any later code can touch them.
+//
+// DPP hazard (a VGPR written by VALU must not be read through DPP within 2 wait states; nothing guards it inside
+// inline asm): `x` is the `a` the previous block's chain wrote; forward blocks end with >= 8 non-DPP instructions
+// after that write, backward blocks with 3. tests/test_isa_hazards.py checks the generated code.
+#if !defined(D_NX) || !defined(D_NU)
+#error "define D_NX and D_NU before including tinympc_solve_d_chain.h"
+#endif
+#if D_NX < 1 || D_NU < 1 || D_NX + D_NU > 16
+#error "layout D: 1 <= nx, 1 <= nu, nx + nu <= 16"
+#endif
+
+#define D_FM_(src, i) "v_fmac_f64_dpp %[a], " src ", %[m" #i "] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
+// column i of the chain: state operand, input operand, or nothing.
+// (The preprocessor cannot index, so each column is resolved by its own #if ladder.)
+#if 0 < D_NX
+#define D_C0 D_FM_("%[x]", 0)
+#else
+#define D_C0 D_FM_("%[d]", 0)
+#endif
+#if 1 < D_NX
+#define D_C1 D_FM_("%[x]", 1)
+#elif 1 < D_NX + D_NU
+#define D_C1 D_FM_("%[d]", 1)
+#else
+#define D_C1 ""
+#endif
+#if 2 < D_NX
+#define D_C2 D_FM_("%[x]", 2)
+#elif 2 < D_NX + D_NU
+#define D_C2 D_FM_("%[d]", 2)
+#else
+#define D_C2 ""
+#endif
+#if 3 < D_NX
+#define D_C3 D_FM_("%[x]", 3)
+#elif 3 < D_NX + D_NU
+#define D_C3 D_FM_("%[d]", 3)
+#else
+#define D_C3 ""
+#endif
+#if 4 < D_NX
+#define D_C4 D_FM_("%[x]", 4)
+#elif 4 < D_NX + D_NU
+#define D_C4 D_FM_("%[d]", 4)
+#else
+#define D_C4 ""
+#endif
+#if 5 < D_NX
+#define D_C5 D_FM_("%[x]", 5)
+#elif 5 < D_NX + D_NU
+#define D_C5 D_FM_("%[d]", 5)
+#else
+#define D_C5 ""
+#endif
+#if 6 < D_NX
+#define D_C6 D_FM_("%[x]", 6)
+#elif 6 < D_NX + D_NU
+#define D_C6 D_FM_("%[d]", 6)
+#else
+#define D_C6 ""
+#endif
+#if 7 < D_NX
+#define D_C7 D_FM_("%[x]", 7)
+#elif 7 < D_NX + D_NU
+#define D_C7 D_FM_("%[d]", 7)
+#else
+#define D_C7 ""
+#endif
+#if 8 < D_NX
+#define D_C8 D_FM_("%[x]", 8)
+#elif 8 < D_NX + D_NU
+#define D_C8 D_FM_("%[d]", 8)
+#else
+#define D_C8 ""
+#endif
+#if 9 < D_NX
+#define D_C9 D_FM_("%[x]", 9)
+#elif 9 < D_NX + D_NU
+#define D_C9 D_FM_("%[d]", 9)
+#else
+#define D_C9 ""
+#endif
+#if 10 < D_NX
+#define D_C10 D_FM_("%[x]", 10)
+#elif 10 < D_NX + D_NU
+#define D_C10 D_FM_("%[d]", 10)
+#else
+#define D_C10 ""
+#endif
+#if 11 < D_NX
+#define D_C11 D_FM_("%[x]", 11)
+#elif 11 < D_NX + D_NU
+#define D_C11 D_FM_("%[d]", 11)
+#else
+#define D_C11 ""
+#endif
+#if 12 < D_NX
+#define D_C12 D_FM_("%[x]", 12)
+#elif 12 < D_NX + D_NU
+#define D_C12 D_FM_("%[d]", 12)
+#else
+#define D_C12 ""
+#endif
+#if 13 < D_NX
+#define D_C13 D_FM_("%[x]", 13)
+#elif 13 < D_NX + D_NU
+#define D_C13 D_FM_("%[d]", 13)
+#else
+#define D_C13 ""
+#endif
+#if 14 < D_NX
+#define D_C14 D_FM_("%[x]", 14)
+#elif 14 < D_NX + D_NU
+#define D_C14 D_FM_("%[d]", 14)
+#else
+#define D_C14 ""
+#endif
+#if 15 < D_NX
+#define D_C15 D_FM_("%[x]", 15)
+#elif 15 < D_NX + D_NU
+#define D_C15 D_FM_("%[d]", 15)
+#else
+#define D_C15 ""
+#endif
+
+#define D_CHAIN D_C0 D_C1 D_C2 D_C3 D_C4 D_C5 D_C6 D_C7 D_C8 D_C9 D_C10 D_C11 D_C12 D_C13 D_C14 D_C15
+#define D_MOPS                                                                                                      \
+    [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]), [m6] "v"(m[6]), \
+        [m7] "v"(m[7]), [m8] "v"(m[8]), [m9] "v"(m[9]), [m10] "v"(m[10]), [m11] "v"(m[11]), [m12] "v"(m[12]),       \
+        [m13] "v"(m[13]), [m14] "v"(m[14]), [m15] "v"(m[15])
+
+// S1 + D1 + R1 for the element the chain just produced (admm.cpp:45-58, 67-68, 93-96); g is updated in place.
+#define D_PROJECT                                  \
+    "v_add_f64 %[s], %[a], %[g]\n\t"               \
+    "v_max_f64 %[sn], %[lo], %[s]\n\t"             \
+    "v_min_f64 %[sn], %[hi], %[sn]\n\t"            \
+    "v_add_f64 %[g], %[s], -%[sn]\n\t"             \
+    "v_add_f64 %[t], %[a], -%[sn]\n\t"             \
+    "v_max_f64 %[pri], %[pri], |%[t]|\n\t"         \
+    "v_add_f64 %[t], %[v], -%[sn]\n\t"             \
+    "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
+#define D_WAIT "s_waitcnt lgkmcnt(0)"
+
+namespace tinympc {
+
+template <>
+struct DStep<D_NX, D_NU> {
+    // Forward step, slack kept in a REGISTER: a = cf + Mf * [x; d], then the row-local block; v (vold in, vnew out)
+    // and g are updated in place so that no register rotates across the iteration loop's back edge.
+    static __device__ __forceinline__ double fwd_reg(double x, double d, const double (&m)[16], double cf, double lo, double hi,
+                                                     double &g, double &v, double &pri, double &dua) {
+        double a, s, t, sn;
+        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_CHAIN D_PROJECT "v_mov_b64 %[v], %[sn]\n\t" D_WAIT
+                     : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
+                     : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), D_MOPS);
+        return a;
+    }
+    // Forward step, slack kept in LDS: vold comes in, vnew goes out (the caller loads / stores them).
+    static __device__ __forceinline__ double fwd_lds(double x, double d, const double (&m)[16], double cf, double lo, double hi,
+                                                     double &g, double v, double &vnew, double &pri, double &dua) {
+        double a, s, t;
+        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_CHAIN D_PROJECT D_WAIT
+                     : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
+                     : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), D_MOPS);
+        return a;
+    }
+    // Backward step for slot s: a (in: accumulator start = q_s + cb on state lanes, cb on input lanes; out: p_s | d_s)
+    // += Mb * [x; d] with x = p_{s+1} (state lanes) and d = r_s (input lanes). The tail prepares, from slot s-2's
+    // (v2, g2), the accumulator start of step s-1 (`an`) and the input-row operand of step s-2 (`rn`)   (L1, admm.cpp:77-80):
+    //     t = v2 - g2 ;  an = rhom * t + lrmc ;  rn = nrho * t + lr
+    // with rhom = -rho / 0 and lrmc = lr + cb / cb on state / input lanes.
+    static __device__ __forceinline__ void bwd(double &a, double x, double d, const double (&m)[16], double v2, double g2,
+                                               double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
+        double t;
+        asm volatile(D_CHAIN
+                     "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                     "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
+                     : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
+                     : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
+    }
+    // Last backward step (slot 0): nothing left to prepare.
+    static __device__ __forceinline__ void bwd_last(double &a, double x, double d, const double (&m)[16]) {
+        asm volatile(D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
+    }
+};
+
+}  // namespace tinympc
+
+#undef D_FM_
+#undef D_C0
+#undef D_C1
+#undef D_C2
+#undef D_C3
+#undef D_C4
+#undef D_C5
+#undef D_C6
+#undef D_C7
+#undef D_C8
+#undef D_C9
+#undef D_C10
+#undef D_C11
+#undef D_C12
+#undef D_C13
+#undef D_C14
+#undef D_C15
+#undef D_CHAIN
+#undef D_MOPS
+#undef D_PROJECT
+#undef D_WAIT
+#undef D_NX
+#undef D_NU

@@ -1,4 +1,4 @@
-"""Kernel time of the three solve layouts over batch sizes (quadrotor N=50, 200 forced iterations).
+"""Kernel time of the solve layouts over batch sizes (quadrotor N=50, 200 forced iterations).
 Usage (GPU box): python tools/layout_sweep.py [--horizon 50] > gpurun_out/layout_sweep.txt"""
 import argparse
 import os
@@ -12,6 +12,7 @@ import __graft_entry__ as g  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--horizon", type=int, default=50)
 ap.add_argument("--iters", type=int, default=200)
+ap.add_argument("--layouts", type=str, default="A,B,C,D")
 ap.add_argument("--batches", type=str, default="1,4,16,64,128,256,512,1024,2048,4096,8192")
 args = ap.parse_args()
 pkg = g.load_package()
@@ -20,7 +21,7 @@ prob = P.quadrotor(args.horizon)
 print(f"# quadrotor N={args.horizon}, {args.iters} iterations per solve; kernel ms (HIP events), us/iter, M instance-iters/s")
 for batch in [int(b) for b in args.batches.split(",")]:
     row = [f"{batch:6d}"]
-    for layout in ("A", "B", "C"):
+    for layout in args.layouts.split(","):
         os.environ["TINYMPC_LAYOUT"] = layout
         s = pkg.TinyMPC()
         s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, max_iter=args.iters, abs_pri_tol=0.0, abs_dua_tol=0.0)
