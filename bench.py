@@ -14,9 +14,14 @@ instances are independent, so there is no data-path collective -- only a summary
 timed region.
 
 Prints ONE JSON line on rank 0 (see the keys below). `value` is the whole-job aggregate
-instance-iterations per second; `roofline` prices the solve kernel's ALGORITHMIC bytes
-(8*(11U+9X) per instance-iteration) against the 8 TB/s HBM peak using the kernel duration
-measured live with HIP events on the kernel's stream; `cpu_baseline` times the reference's own compiled
+instance-iterations per second; `roofline` prices the solve kernel against the roof that BINDS it -- FP64 vector
+issue: algorithmic flops (SURVEY.md section 8a's formula, 60,848 per instance-iteration) / the kernel duration measured
+live with HIP events on the kernel's stream / 78.6 TFLOP/s. The ADMM state stays on chip for the whole solve, so the
+streaming-bytes figure of SURVEY.md section 8d (8*(11U+9X) per instance-iteration against 8 TB/s) exceeds 1 and is
+kept only as the secondary block `roofline.hbm_algorithmic`; `roofline.traffic` is the PMC-measured HBM bytes per
+launch, reported only when profiles/traffic_latest.json was collected with the library that is running now.
+`parity_check` compares instances 0..63 of the timed workload with tests/golden/quadrotor_batch64.npz (the reference
+core's own output) after the timed region and fails the run beyond 1e-6. `cpu_baseline` times the reference's own compiled
 core (oracle/_ref, kind "reference") -- or this repo's C restatement (kind "port") where that binary is
 absent -- on the host cores, on a bounded sample of the same workload.
 """
@@ -47,6 +52,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 65,536-instance single-GPU leg")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--worker-index", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-rocket", action="store_true", help=argparse.SUPPRESS)
@@ -103,6 +109,42 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
     return 0
 
 
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None where the file does not say."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def library_hash() -> str:
+    """sha256 over the sources of the HIP library (csrc/ + the C-ABI header): stamps PMC traffic figures to the kernels
+    they were measured on (the built .so is not tracked, its sources are)."""
+    import hashlib
+    csrc = os.path.join(ROOT, "tinympc-matlab_amd", "csrc")
+    paths = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
+    paths.append(os.path.join(ROOT, "include", "tinympc_hip.h"))
+    h = hashlib.sha256()
+    for path in paths:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host
     cores: one PROCESS per logical CPU (Eigen's per-operation malloc makes threads of one process contend),
@@ -137,10 +179,12 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     except OSError:
         pass
     value = sum(rates)
+    physical = physical_cores()
     rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.split()
     rocket_us = 1e6 * float(rocket[-1]) / int(rocket[-2]) if len(rocket) >= 2 and int(rocket[-2]) > 0 else None
-    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates), "kind": kind,
+    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates), "cores_logical": cores,
+            "cores_physical": physical, "kind": kind,
             "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={horizon} solves, {len(rates)} single-threaded "
                       f"processes x {seconds:.0f} s each ({wall:.1f} s wall; seeded x0, same settings as the GPU run)",
             "single_process_iters_per_s": single, "us_per_iter_single_process": 1e6 / single if single == single else None,
@@ -232,21 +276,44 @@ def main() -> int:
     flops_iter = prob.flops_per_iteration()
     kernel_s = kernel_ms_avg * 1e-3
     alg_bytes_per_launch = count * args.iters * bytes_iter
+    alg_flops_per_launch = count * args.iters * flops_iter
     achieved_gbs = alg_bytes_per_launch / kernel_s / 1e9
+    achieved_tflops = alg_flops_per_launch / kernel_s / 1e12
+
+    # Parity of the timed workload itself: instances 0..63 of rank 0 are the x0 of tests/golden/quadrotor_batch64.npz
+    # (200 forced iterations of the reference's own core). The last timed step's solutions are still on the device.
+    parity = None
+    gpath = os.path.join(ROOT, "tests", "golden", "quadrotor_batch64.npz")
+    if rank == 0 and os.path.exists(gpath) and args.iters == 200 and args.horizon == 50 and count >= 64:
+        g = np.load(gpath)
+        if np.array_equal(g["x0s"], x0_host[:, :64]):
+            sol = solver.get_solution_batch(0, 64)
+            ex = float(np.max(np.abs(sol["states"] - g["sol_x"])) / np.max(np.abs(g["sol_x"])))
+            eu = float(np.max(np.abs(sol["controls"] - g["sol_u"])) / np.max(np.abs(g["sol_u"])))
+            its = solver.get_stats_batch(0, 64)["iter"]
+            parity = {"against": "tests/golden/quadrotor_batch64.npz (reference core, 64 instances x 200 iterations)",
+                      "max_rel_err_states": ex, "max_rel_err_controls": eu, "tolerance": 1e-6,
+                      "iterations_match": bool(np.array_equal(np.asarray(its), g["iters"])),
+                      "ok": bool(ex < 1e-6 and eu < 1e-6 and np.array_equal(np.asarray(its), g["iters"]))}
 
     out = None
     if rank == 0:
         info = solver.launch_info()
-        traffic = None
+        traffic, traffic_note = None, "no PMC collection for this workload"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("batch_per_gpu") == B and tj.get("iters") == args.iters and tj.get("horizon") == args.horizon:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("library_hash") == library_hash():
+                        traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "PMC, " + str(tj.get("source"))
+                    else:
+                        traffic_note = "dropped: %s was collected on other kernel sources (%s, now %s)" % (
+                            tj.get("source"), tj.get("library_hash"), library_hash())
             except (OSError, ValueError):
                 traffic = None
+        kname = {"A": "k_admm_solve", "B": "k_admm_solve_b", "C": "k_admm_solve_c", "D": "k_admm_solve_d"}.get(info.get("layout"), "k_admm_solve")
         out = {
             "metric": "ADMM iterations/s, batched quadrotor nx=12 nu=4 N=%d (instance-iterations/s, whole job)" % prob.N,
             "value": value, "unit": "ADMM iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -258,19 +325,50 @@ def main() -> int:
                        "batch_per_gpu": B, "global_batch": total_instances, "iters_per_solve": args.iters,
                        "parallelism": "independent instances sharded x%d, no data-path collective" % world},
             "solves_per_s": value / args.iters,
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                         "kernel": {"A": "k_admm_solve", "B": "k_admm_solve_b", "C": "k_admm_solve_c"}.get(info.get("layout"), "k_admm_solve")
-                                   + "<%d lanes/instance>" % info["lanes_per_instance"], "kernel_ms_avg": kernel_ms_avg,
-                         "algorithmic_bytes_per_instance_iteration": bytes_iter,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "note": "ADMM state stays on chip for the whole solve (LDS + L2), so measured HBM traffic is far below "
-                                 "the algorithmic (streaming) bytes and frac may exceed 1; the kernel is FP64-issue bound",
-                         "fp64_tflops": count * args.iters * flops_iter / kernel_s / 1e12,
-                         "fp64_frac_of_vector_peak": count * args.iters * flops_iter / kernel_s / 1e12 / PEAK_FP64_TFLOPS},
+            "roofline": {"bound": "fp64_vector", "achieved": achieved_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": kname + "<%d lanes/instance>" % info["lanes_per_instance"], "kernel_ms_avg": kernel_ms_avg,
+                         "algorithmic_flops_per_instance_iteration": flops_iter,
+                         "algorithmic_flops_per_launch": alg_flops_per_launch,
+                         "note": "binding roof = FP64 vector issue (MI355X: 78.6 TFLOP/s; FP64 MFMA has the same peak and needs "
+                                 "16 instances per wavefront whose state does not fit on chip). The ADMM state is register/LDS "
+                                 "resident for the whole solve, so HBM is touched at entry and exit only",
+                         "hbm_algorithmic": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                             "frac": achieved_gbs / PEAK_HBM_GBS,
+                                             "bytes_per_instance_iteration": bytes_iter, "bytes_per_launch": alg_bytes_per_launch,
+                                             "note": "SURVEY.md section 8d streaming model; > 1 means the state never streams "
+                                                     "from HBM (on-chip), so this roof does not bind"},
+                         "hbm_measured_frac_of_peak": (traffic / kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None},
+            "parity_check": parity,
             "launch": info,
             "summary": summary,
         }
+        if world == 1 and not args.no_config5:
+            # BASELINE config 5 on ONE GPU: all 65,536 instances in one launch (8 waves per CU x 8 rounds)
+            nb = 65536
+            big = pkg.TinyMPC()
+            big.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=local_rank, rho=prob.rho,
+                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
+            big.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            big.set_x0_batch(torch.from_numpy(np.ascontiguousarray(P.quadrotor_batch_x0(nb).T)).to(dev))
+            big.synchronize()
+            big.reset_workspace()
+            big.solve_timed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            kms = []
+            for _ in range(3):
+                big.reset_workspace()
+                kms.append(big.solve_timed())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            u_first = big.get_solution_batch(0, 64)["controls"]
+            out["config5_single_gpu"] = {"workload": "65,536 quadrotor N=%d instances x %d forced iterations on ONE GPU, 3 cold-started steps" % (prob.N, args.iters),
+                                         "value": 3 * nb * args.iters / dt, "unit": "ADMM iters/s", "ms_per_step": 1e3 * dt / 3,
+                                         "kernel_ms_avg": sum(kms) / 3, "layout": big.launch_info()["layout"],
+                                         "fp64_frac": nb * args.iters * flops_iter / (sum(kms) / 3 * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                         "prefix_matches_8192_run": (bool(np.array_equal(u_first, sol["controls"])) if parity else None)}
+            big.reset()
         if not args.no_single:
             one = pkg.TinyMPC()
             one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho,
@@ -315,10 +413,15 @@ def main() -> int:
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
     solver.reset()
+    if parity is not None and not parity["ok"]:
+        print("bench.py: parity_check FAILED: %s" % json.dumps(parity), file=sys.stderr)
+        rc_final = 3
+    else:
+        rc_final = 0
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc_final
 
 
 if __name__ == "__main__":

@@ -93,6 +93,20 @@ __device__ __forceinline__ void lds_write_async(unsigned addr, double v) {
     static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+// Store for the lanes of `mask` only, without a branch: EXEC is narrowed around the one instruction by two scalar
+// instructions (a branch around the store would put a label between two sweep blocks -- one more taken-or-not decision per
+// step, and a branch target the ISA lint could not see through).
+template <int OFF>
+__device__ __forceinline__ void lds_write_masked(unsigned addr, double v, unsigned long long mask) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "ds_write_b64 %[a], %[v] offset:%[o]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved)
+                 : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
+                 : "memory", "scc");
+}
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the lanes that
@@ -321,7 +335,7 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 
         // ---------------- backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G
         {
-            const bool wr_d = is_u && active;  // a zombie keeps the d of its last real iteration
+            const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
             load_ops(sMb, m);
             auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type)
                 if constexpr (CT) return lr_c;
@@ -363,7 +377,7 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 double a = acc, an, rn;
                 Step::bwd(a, px, rcur, m, v2cur, G[s2], rhom, lrmc2, nrho, lr2, an, rn);
-                if (wr_d) lds_write_async<s * DS * 8>(aD, a);  // d_s
+                lds_write_masked<s * DS * 8>(aD, a, wr_d);  // d_s
                 px = a;
                 rcur = rnext;
                 rnext = rn;
@@ -373,7 +387,7 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
             {
                 double a = acc;
                 Step::bwd_last(a, px, rcur, m);
-                if (wr_d) lds_write_async<0>(aD, a);  // d_0
+                lds_write_masked<0>(aD, a, wr_d);  // d_0
             }
         }
     }

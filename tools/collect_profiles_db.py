@@ -16,8 +16,12 @@ import os
 import sqlite3
 import statistics as st
 
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADLINE = "k_admm_solve_b"
+sys.path.insert(0, ROOT)
+from bench import library_hash  # noqa: E402  (stamps the traffic figure with the kernel sources it was measured on)
+HEADLINE = "k_admm_solve_d"  # the kernel bench.py times at 8,192 quadrotor instances (layout D)
 
 
 def counter_means(db, counter):
@@ -36,6 +40,7 @@ def main():
     ap.add_argument("--trace")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--sq", help="directory with one sub-directory per SQ counter pass (tools/gpu_profile.sh <tag> sq)")
     a = ap.parse_args()
     P = os.path.join(ROOT, "profiles")
     os.makedirs(P, exist_ok=True)
@@ -74,9 +79,31 @@ def main():
             pmc["hbm_bytes_per_launch"] = read_b + write_b
             pmc["note"] = "read side = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md); per launch of 8,192 instances x 200 iterations"
             json.dump({"batch_per_gpu": 8192, "iters": 200, "horizon": 50, "hbm_bytes_per_launch": read_b + write_b,
-                       "source": f"profiles/{a.tag}_pmc.json"},
+                       "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
+                       "library_hash": library_hash(), "source": f"profiles/{a.tag}_pmc.json"},
                       open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
         json.dump(pmc, open(os.path.join(P, f"{a.tag}_pmc.json"), "w"), indent=1)
+    if a.sq:
+        import glob
+        sq = {}
+        for db in sorted(glob.glob(os.path.join(a.sq, "*", "*_results.db"))):
+            con = sqlite3.connect(db)
+            for name, cn, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
+                if HEADLINE in name:
+                    sq.setdefault(cn, []).append(float(v))
+        c = {k: {"launches": len(v), "mean": st.mean(v)} for k, v in sq.items()}
+        out = {"kernel": HEADLINE, "workload": "8,192 quadrotor N=50 instances x 200 iterations per launch", "counters": c}
+        if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
+            waves = c["SQ_WAVES"]["mean"]
+            d = {"waves": waves, "valu_per_wave_iteration": c["SQ_INSTS_VALU"]["mean"] / waves / 200}
+            for k, key in (("SQ_INSTS_LDS", "lds_per_wave_iteration"), ("SQ_INSTS_SALU", "salu_per_wave_iteration")):
+                if k in c:
+                    d[key] = c[k]["mean"] / waves / 200
+            if "SQ_WAVE_CYCLES" in c:  # quad-cycles (MI355X_MICROARCH.md, PMC units)
+                d["cycles_per_wave_iteration"] = 4 * c["SQ_WAVE_CYCLES"]["mean"] / waves / 200
+                d["cycles_per_valu_per_simd_at_2_waves"] = d["cycles_per_wave_iteration"] / 2 / d["valu_per_wave_iteration"]
+            out["derived"] = d
+        json.dump(out, open(os.path.join(P, f"{a.tag}_pmc_sq.json"), "w"), indent=1)
     print("wrote profiles/%s_*" % a.tag)
 
 
