@@ -203,8 +203,10 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
 
 /* x0s is nx x count (column b = instance first+b), host memory. */
 int tinympc_set_x0_batch(tinympc_solver *s, const double *x0s, int first, int count);
-/* Same, from device memory on the handle's GPU (e.g. a torch tensor's data_ptr); asynchronous on
- * the handle's stream. */
+/* Same, from device memory on the handle's GPU (e.g. a torch tensor's data_ptr). Contract: whatever
+ * PRODUCED d_x0s on another stream must have completed before the call (the copy runs on the handle's own
+ * non-blocking stream, which is ordered against no other stream); the copy itself has completed when the
+ * call returns, so the caller may free or overwrite d_x0s right away. */
 int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int first, int count);
 
 /* Zero the persistent ADMM state (cold start) of every instance and put every instance's rho back to
@@ -227,7 +229,10 @@ int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *
  * tinympc_reset; lets a caller consume results without a D2H copy. */
 int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u);
 
-/* Launch the solve without waiting (same kernel as tinympc_solve); pair with tinympc_synchronize. */
+/* Launch the solve without waiting (same kernel as tinympc_solve); pair with tinympc_synchronize. Every verb
+ * that changes an input of the launch in flight (set_x0, mpc_step, ... -- on single-instance handles x0 lives in
+ * pinned host memory that the kernel reads directly) waits for the launch first, so the sequence solve_async ->
+ * set_x0 (next tick) -> synchronize is safe for every batch size. */
 int tinympc_solve_async(tinympc_solver *s);
 int tinympc_synchronize(tinympc_solver *s);
 /* Synchronous solve that also reports the kernel's duration measured with HIP events recorded on

@@ -104,6 +104,17 @@ def test_argument_count_errors(mex):
     assert mex.call("reset", 0.0)[0] is None                                  # resetting nothing is fine (:539)
 
 
+def test_setup_rejects_arrays_that_do_not_match_nx_nu(mex, pkg):
+    """The C ABI reads nx*nx, nx*nu ... doubles behind the raw pointers; the shim must not forward arrays of another
+    shape (the reference gets that from its Eigen conversions + tiny_setup's checks, bindings.cpp:60-85)."""
+    p = pkg.problems.cartpole()
+    ok = [p.A, p.B, np.zeros((4, 1)), p.Q, p.R, 1.0, 4.0, 1.0, 20.0, 0.0]
+    for idx, bad in ((0, np.eye(3)), (1, np.zeros((4, 2))), (2, np.zeros((3, 1))), (3, np.eye(5)), (4, np.eye(2))):
+        args = list(ok)
+        args[idx] = bad
+        assert mex.call("setup", *args, nlhs=1)[0] == "TinyMPC:InvalidInput", idx
+
+
 def test_setup_without_gpu_raises_setup_failed(mex, pkg):
     if pkg.device_count() > 0:
         pytest.skip("a HIP device is visible")

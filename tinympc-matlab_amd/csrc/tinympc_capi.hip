@@ -590,6 +590,8 @@ int tinympc_set_x0(tinympc_solver *s, const double *x0, int len, int verbose) {
     // Eigen column assignment of the wrong length is undefined behaviour, so the C ABI rejects it.
     if (len != s->nx) return fail(TINYMPC_ERR_INVALID_INPUT, "set_x0: x0 has %d entries, expected %d", len, s->nx);
     if (s->host_path()) {  // no device call at all: the next launch picks x0 up from pinned host memory
+        // (a launch of tinympc_solve_async may still be reading the buffer: wait for it first)
+        if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
         std::memcpy(s->h_x0, x0, sizeof(double) * s->nx);
         s->x0_on_host = true;
         if (verbose) printf("Initial state set\n");
@@ -703,6 +705,10 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     if (!s->h_x0) {  // pinned staging, so that the small copies are true async DMA and need no extra sync
         HIP_TRY(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx0, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
+    }
+    if (s->host_sol_state == 1) {  // a launch of tinympc_solve_async may still be reading h_x0
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->host_sol_state = 2;
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
     if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d()) {
@@ -1095,6 +1101,10 @@ int tinympc_set_x0_batch_device(tinympc_solver *s, const double *d_x0s, int firs
     if ((rc = bind_device(s))) return rc;
     s->x0_on_host = false;
     HIP_TRY(hipMemcpyAsync(s->dx0 + (size_t)first * s->nx, d_x0s, sizeof(double) * count * s->nx, hipMemcpyDeviceToDevice, s->stream));
+    // The copy runs on the handle's own (non-blocking) stream: wait for it here, so that the caller may free or reuse
+    // d_x0s as soon as the call returns -- the same ownership rule as every host-pointer verb. (Work that PRODUCES
+    // d_x0s on another stream must have completed before the call; see the header.)
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return TINYMPC_OK;
 }
 

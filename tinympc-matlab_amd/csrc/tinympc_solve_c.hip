@@ -395,11 +395,14 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             res_valid = true;
             const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
             const bool wave_ok = __ballot(!below) == 0ull;
-            if ((tid & 63) == 0) reinterpret_cast<int *>(sR)[tid >> 6] = wave_ok ? 1 : 0;
+            // (flag slots alternate with the iteration's parity: with no carry-scan level -- N == 2 -- this barrier is
+            // the only one of an iteration, and a fast wavefront would otherwise overwrite its flag for iteration it+1
+            // before a slow one has read the flags of iteration it)
+            if ((tid & 63) == 0) reinterpret_cast<int *>(sR)[(it & 1) * 4 + (tid >> 6)] = wave_ok ? 1 : 0;
         }
         __syncthreads();
         if (check) {
-            const int *flags = reinterpret_cast<const int *>(sR);
+            const int *flags = reinterpret_cast<const int *>(sR) + (it & 1) * 4;
             if ((flags[0] & flags[1] & flags[2] & flags[3]) != 0) {
                 status = 1;  // uniform over the workgroup: one instance
                 converged = true;

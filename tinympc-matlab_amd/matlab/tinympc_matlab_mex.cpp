@@ -75,10 +75,22 @@ mxArray *matrix_out(int rows, int cols) { return mxCreateDoubleMatrix((mwSize)ro
 void verb_setup(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {  // A,B,fdyn,Q,R,rho,nx,nu,N,verbose
     if (nrhs != 10)
         mexErrMsgIdAndTxt("TinyMPC:InvalidInput", "setup requires 10 input arguments: A, B, fdyn, Q, R, rho, nx, nu, N, verbose");
-    const double *A = real_doubles(prhs[0]), *B = real_doubles(prhs[1]), *f = real_doubles(prhs[2]);
+    const double *A = real_doubles(prhs[0]), *B = real_doubles(prhs[1]), *f = real_doubles(prhs[2]);  // (f: NULL when empty, below)
     const double *Q = real_doubles(prhs[3]), *R = real_doubles(prhs[4]);
     const double rho = mxGetScalar(prhs[5]);
     const int nx = as_int(prhs[6]), nu = as_int(prhs[7]), N = as_int(prhs[8]), verbose = as_int(prhs[9]);
+    // The C ABI reads nx*nx, nx*nu, ... doubles behind these pointers: the arrays must really have that shape
+    // (the reference gets the same guarantee from its Eigen conversions and tiny_setup's dimension checks).
+    const struct { const mxArray *a; int rows, cols; const char *name; } shapes[] = {
+        {prhs[0], nx, nx, "A"}, {prhs[1], nx, nu, "B"}, {prhs[3], nx, nx, "Q"}, {prhs[4], nu, nu, "R"}};
+    for (const auto &sh : shapes)
+        if ((int)mxGetM(sh.a) != sh.rows || (int)mxGetN(sh.a) != sh.cols)
+            mexErrMsgIdAndTxt("TinyMPC:InvalidInput", "setup: %s is %dx%d, expected %dx%d", sh.name, (int)mxGetM(sh.a),
+                              (int)mxGetN(sh.a), sh.rows, sh.cols);
+    const size_t nf = mxGetM(prhs[2]) * mxGetN(prhs[2]);
+    if (nf != 0 && nf != (size_t)nx)
+        mexErrMsgIdAndTxt("TinyMPC:InvalidInput", "setup: fdyn has %d entries, expected 0 or %d", (int)nf, nx);
+    if (nf == 0) f = nullptr;
     if (g_handle) tinympc_reset(&g_handle, 0);  // setup replaces the global solver (bindings.cpp:92)
     check(tinympc_setup(&g_handle, A, B, f, Q, R, rho, nx, nu, N, verbose), "TinyMPC:SetupFailed");
     g_nx = nx; g_nu = nu; g_N = N;
@@ -228,6 +240,9 @@ void verb_set_cone_constraints(int, mxArray *[], int nrhs, const mxArray *prhs[]
     const std::vector<int> Acx = index_vector(prhs[0]), qcx = index_vector(prhs[1]);
     const std::vector<int> Acu = index_vector(prhs[3]), qcu = index_vector(prhs[4]);
     const int ncx = (int)Acx.size(), ncu = (int)Acu.size();
+    if (qcx.size() != Acx.size() || mxGetM(prhs[2]) * mxGetN(prhs[2]) != Acx.size() || qcu.size() != Acu.size() ||
+        mxGetM(prhs[5]) * mxGetN(prhs[5]) != Acu.size())
+        mexErrMsgIdAndTxt("TinyMPC:InvalidInput", "set_cone_constraints: Ac, qc and c of one side must have the same length");
     check(tinympc_set_cone_constraints(g_handle, Acx.data(), qcx.data(), ncx ? real_doubles(prhs[2]) : nullptr, ncx, Acu.data(),
                                        qcu.data(), ncu ? real_doubles(prhs[5]) : nullptr, ncu),
           "TinyMPC:SetConeConstraintsFailed");

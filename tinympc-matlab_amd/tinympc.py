@@ -303,6 +303,10 @@ class TinyMPC:
         if hasattr(x0s, "data_ptr") and getattr(x0s, "is_cuda", False):
             assert x0s.dtype.itemsize == 8 and x0s.is_contiguous() and x0s.numel() % self.nx == 0
             count = x0s.numel() // self.nx
+            # the C ABI's contract: the producer of the tensor has finished (the handle's stream is ordered against no
+            # torch stream); the copy itself completes inside the call
+            import torch
+            torch.cuda.current_stream(x0s.device).synchronize()
             _lib.check(self._L.tinympc_set_x0_batch_device(self._h, C.c_void_p(x0s.data_ptr()), first, count))
             return
         a = _f(x0s)
