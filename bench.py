@@ -340,6 +340,7 @@ def main() -> int:
                                                      "from HBM (on-chip), so this roof does not bind"},
                          "hbm_measured_frac_of_peak": (traffic / kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None},
             "parity_check": parity,
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if use_dist else None),
             "launch": info,
             "summary": summary,
         }

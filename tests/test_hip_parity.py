@@ -351,6 +351,116 @@ def test_full_size_batch_properties(pkg):
     s.reset()
 
 
+def test_bench_size_solve_matches_golden_and_oracle(pkg, kernel_layout):
+    """The configuration bench.py times -- 8,192 quadrotor N=50 instances, cold start, 200 forced iterations -- checked
+    at that size (not only through properties): instances 0..63 against the reference core's own output
+    (tests/golden/quadrotor_batch64.npz), a seeded sample of 64 instances from the whole batch against the oracle, and
+    all iteration counts. Layout C handles one instance per workgroup and is far off its range at 8,192 x 200, so it
+    runs the same check on 1,024 instances."""
+    P = pkg.problems
+    g = golden("quadrotor_batch64")
+    prob = P.quadrotor(50)
+    settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200, check_termination=1)
+    B = 1024 if kernel_layout == "C" else 8192
+    x0s = P.quadrotor_batch_x0(B)
+    np.testing.assert_array_equal(x0s[:, :64], g["x0s"])  # the bench's seeded x0 ARE the fixture's
+    s = make_solver(pkg, prob, settings, batch=B)
+    assert s.launch_info()["layout"] == kernel_layout
+    s.set_x0_batch(x0s)
+    s.solve()
+    st = s.get_stats_batch()
+    assert np.all(st["iter"] == 200) and np.all(st["status"] == 11)
+    head = s.get_solution_batch(0, 64)
+    assert rel_err(head["states"], g["sol_x"]) < TOL
+    assert rel_err(head["controls"], g["sol_u"]) < TOL
+    assert rel_err(st["residuals"][:, :64], g["residuals"]) < 1e-6
+    sample = np.sort(np.random.default_rng(7).choice(np.arange(64, B), size=64, replace=False))
+    sol = s.get_solution_batch()
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, oit, _, ores = orc.solve_batch(x0s[:, sample])
+    assert rel_err(sol["states"][:, :, sample], ox) < TOL
+    assert rel_err(sol["controls"][:, :, sample], ou) < TOL
+    assert rel_err(st["residuals"][:, sample], ores) < 1e-6
+    s.reset()
+
+
+def test_config5_on_one_gpu_properties(pkg, kernel_layout):
+    """BASELINE config 5 in one launch: all 65,536 quadrotor instances on ONE GPU (8 rounds of 8 waves per CU).
+    The first 8,192 instances must equal, bit for bit, what the 8,192-instance shard produces (an instance's
+    result does not depend on the batch it is solved in or on the wave slot it lands in); the last 64 are checked against
+    the oracle; feasibility everywhere."""
+    if kernel_layout != "D":
+        pytest.skip("one throughput layout is enough for the 65,536-instance case")
+    P = pkg.problems
+    prob = P.quadrotor(50)
+    settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
+    B = 65536
+    x0s = P.quadrotor_batch_x0(B)
+    big = make_solver(pkg, prob, settings, batch=B)
+    big.set_x0_batch(x0s)
+    big.solve()
+    st = big.get_stats_batch()
+    assert np.all(st["iter"] == 60) and np.all(st["status"] == 11)
+    small = make_solver(pkg, prob, settings, batch=8192)
+    small.set_x0_batch(x0s[:, :8192])
+    small.solve()
+    a, b = big.get_solution_batch(0, 8192), small.get_solution_batch()
+    np.testing.assert_array_equal(a["controls"], b["controls"])
+    np.testing.assert_array_equal(a["states"], b["states"])
+    tail = big.get_solution_batch(B - 64, 64)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, _, _, _ = orc.solve_batch(x0s[:, B - 64:])
+    assert rel_err(tail["states"], ox) < TOL and rel_err(tail["controls"], ou) < TOL
+    u = big.get_first_controls_batch()
+    assert np.all(np.abs(u) <= 0.5 + 1e-15)
+    big.reset()
+    small.reset()
+
+
+def test_per_tick_references_stay_one_launch_and_match_the_device_path(pkg):
+    """The reference's tracking loops re-send the references every tick (rocket_landing_constraints.m:86-121,
+    cartpole_example_mpc_reference_constrained.m:47-55). On a single-instance handle set_x_ref / set_u_ref only fill
+    pinned host memory and the solve kernel rebuilds the reference-dependent table rows itself; a batched handle
+    uploads them and runs k_build_tables. Both must agree bit for bit, tick by tick, and with the oracle."""
+    P = pkg.problems
+    prob = P.quadrotor(20)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=80)
+    one = make_solver(pkg, prob, settings, batch=1)
+    two = make_solver(pkg, prob, settings, batch=2)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    goal = np.array([1.0, -0.5, 0.8, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    x = prob.x0.copy()
+    total = 40
+    for k in range(10):
+        x_ref = np.stack([prob.x0 + (goal - prob.x0) * min(i + k, total - 1) / (total - 1) for i in range(prob.N)], axis=1)
+        u_ref = np.full((prob.nu, prob.N - 1), 0.01 * k)
+        for h in (one, two, orc):
+            h.set_x_ref(x_ref)
+            h.set_u_ref(u_ref)
+        one.set_x0(x)
+        two.set_x0_batch(np.stack([x, x], axis=1))
+        orc.set_x0(x)
+        one.solve()
+        two.solve()
+        orc.solve()
+        a, b = one.get_solution(), two.get_solution_batch()
+        np.testing.assert_array_equal(a["controls"], b["controls"][:, :, 0])
+        np.testing.assert_array_equal(a["states"], b["states"][:, :, 1])
+        assert one.get_stats()["iter"] == two.get_stats_batch()["iter"][0] == orc.stats()["iter"]
+        assert rel_err(a["controls"], orc.solution()[1]) < TOL and rel_err(a["states"], orc.solution()[0]) < TOL
+        x = prob.A @ x + prob.B @ a["controls"][:, 0]
+    # a reference set while the pinned copy is pending must survive a bounds change (k_build_tables runs first)
+    one.set_x_ref(np.tile(goal[:, None], (1, prob.N)))
+    one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min * 0.9, prob.u_max * 0.9)
+    two.set_x_ref(np.tile(goal[:, None], (1, prob.N)))
+    two.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min * 0.9, prob.u_max * 0.9)
+    one.solve()
+    two.solve()
+    np.testing.assert_array_equal(one.get_solution()["controls"], two.get_solution_batch()["controls"][:, :, 0])
+    one.reset()
+    two.reset()
+
+
 @pytest.mark.parametrize("batch", [1, 6, 300])
 def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a

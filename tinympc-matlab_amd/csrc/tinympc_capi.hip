@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -119,7 +120,14 @@ struct tinympc_solver {
     // launch reads it from there (and mirrors it into dx0), and the kernels also write solution + statistics into the
     // pinned h_sol -- the reference's per-tick sequence set_x0 / solve / get_solution then costs ONE launch and ONE
     // synchronisation instead of three synchronous copies around the launch.
-    double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status]
+    double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
+    unsigned long long launch_seq = 0; // sequence number of the last launch that raises the completion flag (0: none pending)
+    bool flag_pending = false;
+    // ... and set_x_ref / set_u_ref only fill these pinned copies; the next launch's workgroup rebuilds the
+    // reference-dependent table rows from them (refresh_reference_tables): a tick with per-tick references
+    // (rocket_landing_constraints.m:86-121) is still one launch and one synchronisation.
+    double *h_xref = nullptr, *h_uref = nullptr;
+    bool refs_on_host = false;         // the pinned references are newer than dXref / dUref and the tables
     bool x0_on_host = false;           // h_x0 is newer than dx0
     int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
     bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d; }  // (layout D writes to device memory only)
@@ -201,6 +209,16 @@ int run_precompute(tinympc_solver *s) {
     p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
     HIP_TRY(launch_precompute(p, s->stream));
     s->ops_dirty = true;
+    s->tables_dirty = true;
+    return TINYMPC_OK;
+}
+
+// References left in pinned host memory by set_x_ref / set_u_ref -> device copies, the ordinary way.
+int flush_host_refs(tinympc_solver *s) {
+    int rc;
+    if ((rc = upload(s, s->dXref, s->h_xref, s->X()))) return rc;
+    if (s->U() && (rc = upload(s, s->dUref, s->h_uref, s->U()))) return rc;
+    s->refs_on_host = false;
     s->tables_dirty = true;
     return TINYMPC_OK;
 }
@@ -297,11 +315,25 @@ int refresh_families(tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+// Single-instance launches of the latency kernel end by writing a sequence number behind the solution in pinned host
+// memory; tinympc_synchronize polls it (a few hundred nanoseconds after the kernel's last store) instead of sleeping in
+// hipStreamSynchronize (whose wake-up costs several microseconds of a ~25 us tick).
+void arm_completion_flag(tinympc_solver *s, SolveParams &p) {
+    if (!p.host_sol) return;
+    s->launch_seq += 1;
+    p.host_seq = (double)s->launch_seq;
+    s->flag_pending = true;
+}
+
 int launch(tinympc_solver *s, bool timed) {
-    int rc = refresh_derived(s);
-    if (rc) return rc;
+    int rc;
+    s->flag_pending = false;
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
+    if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts
+        if ((rc = flush_host_refs(s))) return rc;
+    }
+    if ((rc = refresh_derived(s))) return rc;
     if (adaptive && fam)
         return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
     if (adaptive) {  // tiny tables from the current cache, sensitivities and Xref; rebuilt per launch (a few microseconds)
@@ -340,6 +372,11 @@ int launch(tinympc_solver *s, bool timed) {
             s->host_sol_state = 1;
         }
     }
+    if (s->refs_on_host) {  // (host_path() handles only: batch == 1, one workgroup)
+        p.href_x = s->h_xref; p.href_u = s->h_uref;
+        p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;
+        s->refs_on_host = false;  // the kernel brings the tables and the device copies up to date
+    }
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
@@ -351,6 +388,7 @@ int launch(tinympc_solver *s, bool timed) {
         // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         p.families = 1;
+        arm_completion_flag(s, p);
         HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
     } else if (fam) {
         // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
@@ -361,6 +399,7 @@ int launch(tinympc_solver *s, bool timed) {
         HIP_TRY(launch_solve_d(p, s->stream));
     } else if (s->layout_c) {
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
+        arm_completion_flag(s, p);
         HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
     } else if (s->layout_b) {
         HIP_TRY(launch_solve_b(p, s->W, s->KT, s->lds_bytes, s->stream));
@@ -378,6 +417,8 @@ void destroy(tinympc_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
     if (s->h_sol) (void)hipHostFree(s->h_sol);
+    if (s->h_xref) (void)hipHostFree(s->h_xref);
+    if (s->h_uref) (void)hipHostFree(s->h_uref);
     if (s->h_x0) (void)hipHostFree(s->h_x0);
     if (s->h_u0) (void)hipHostFree(s->h_u0);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -459,7 +500,9 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     // Two workgroups per CU need <= 80 KB each; prefer LDS tables whenever they do not cost a workgroup slot.
     const size_t slots_without = s->state_in_global ? 0 : kLdsMax / without;
     const size_t slots_with = kLdsMax / with_tables;
-    s->tables_in_lds = !s->state_in_global && (with_tables <= kLdsMax) && (slots_with >= (slots_without > 2 ? 2 : slots_without));
+    // (up to four: one wavefront per SIMD. Wide systems -- 2 or 1 instances per wavefront -- have short state arrays and
+    // long tables; keeping the tables in L2 doubles their wavefronts per CU, profiles/r02_wide_sweep.txt)
+    s->tables_in_lds = !s->state_in_global && (with_tables <= kLdsMax) && (slots_with >= (slots_without > 4 ? 4 : slots_without));
     s->lds_bytes = s->state_in_global ? 0 : (s->tables_in_lds ? with_tables : without);
     s->lds_bytes_a = s->lds_bytes;
     s->tables_in_lds_a = s->tables_in_lds;
@@ -558,10 +601,14 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     HIP_TRY_S(hipMemsetAsync(s->ddstats, 0, sizeof(double) * batch * 4, s->stream));
 
     if (batch == 1) {
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_sol, sizeof(double) * (X + U + 6), hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_sol, sizeof(double) * (X + U + 8), hipHostMallocDefault));
         HIP_TRY_S(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx, hipHostMallocDefault));
         HIP_TRY_S(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu, hipHostMallocDefault));
-        std::memset(s->h_sol, 0, sizeof(double) * (X + U + 6));
+        std::memset(s->h_sol, 0, sizeof(double) * (X + U + 8));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_xref, sizeof(double) * X, hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_uref, sizeof(double) * (U ? U : 1), hipHostMallocDefault));
+        std::memset(s->h_xref, 0, sizeof(double) * X);  // tiny_setup zeroes the references (tiny_api.cpp:83-84)
+        std::memset(s->h_uref, 0, sizeof(double) * (U ? U : 1));
     }
     TRY(run_precompute(s));  // tiny_api.cpp:113
     HIP_TRY_S(hipStreamSynchronize(s->stream));
@@ -611,9 +658,16 @@ int tinympc_set_x_ref(tinympc_solver *s, const double *Xref, int rows, int cols,
     // the workspace shape under the solver; rejected here.
     if (rows != s->nx || cols != s->N)
         return fail(TINYMPC_ERR_INVALID_INPUT, "State reference trajectory (x_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nx, s->N);
+    s->xref_const = rows_constant(Xref, s->nx, s->N);
+    if (s->host_path()) {  // no device call: the next launch reads the pinned copy and rebuilds the table rows itself
+        if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;  // a launch in flight may be reading it
+        std::memcpy(s->h_xref, Xref, sizeof(double) * s->X());
+        s->refs_on_host = true;
+        if (verbose) printf("State reference set\n");
+        return TINYMPC_OK;
+    }
     if ((rc = bind_device(s))) return rc;
     rc = upload(s, s->dXref, Xref, s->X());
-    s->xref_const = rows_constant(Xref, s->nx, s->N);
     s->tables_dirty = true;
     if (!rc && verbose) printf("State reference set\n");
     return rc;
@@ -625,9 +679,16 @@ int tinympc_set_u_ref(tinympc_solver *s, const double *Uref, int rows, int cols,
     if (!Uref) return fail(TINYMPC_ERR_INVALID_INPUT, "set_u_ref: Uref is NULL");
     if (rows != s->nu || cols != s->N - 1)
         return fail(TINYMPC_ERR_INVALID_INPUT, "Control/input reference trajectory (u_ref) is %d x %d. Expected %d x %d.", rows, cols, s->nu, s->N - 1);
+    s->uref_const = rows_constant(Uref, s->nu, s->N - 1);
+    if (s->host_path()) {
+        if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
+        std::memcpy(s->h_uref, Uref, sizeof(double) * s->U());
+        s->refs_on_host = true;
+        if (verbose) printf("Input reference set\n");
+        return TINYMPC_OK;
+    }
     if ((rc = bind_device(s))) return rc;
     rc = upload(s, s->dUref, Uref, s->U());
-    s->uref_const = rows_constant(Uref, s->nu, s->N - 1);
     s->tables_dirty = true;
     if (!rc && verbose) printf("Input reference set\n");
     return rc;
@@ -663,7 +724,23 @@ int tinympc_solve_async(tinympc_solver *s) {
 int tinympc_synchronize(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if (s->flag_pending && s->host_sol_state == 1) {
+        // The launch in flight raises a flag in pinned memory after its last store: poll it. Bounded: a kernel that takes
+        // longer than the polling budget (long solves) is waited for the ordinary way.
+        const volatile double *flag = s->h_sol + s->X() + s->U() + 6;
+        const double want = (double)s->launch_seq;
+        for (int spin = 0; spin < 400000; ++spin) {
+            if (*flag == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                s->flag_pending = false;
+                s->host_sol_state = 2;
+                return TINYMPC_OK;
+            }
+            __builtin_ia32_pause();
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->flag_pending = false;
     if (s->host_sol_state == 1) s->host_sol_state = 2;
     return TINYMPC_OK;
 }
@@ -719,7 +796,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         rc = launch(s, false);
         s->zero_copy_tick = false;
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        if ((rc = tinympc_synchronize(s))) return rc;  // (single instance: polls the completion flag in pinned memory)
     } else {
         HIP_TRY(hipMemcpyAsync(s->dx0, s->h_x0, sizeof(double) * nx0, hipMemcpyHostToDevice, s->stream));
         if ((rc = launch(s, false))) return rc;

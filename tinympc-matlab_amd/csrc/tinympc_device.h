@@ -127,6 +127,17 @@ struct SolveParams {
     // out [nx*N | nu*(N-1) | pri_x, dua_x, pri_u, dua_u | iter, status (as doubles)], so that get_solution / get_stats
     // after a synchronous solve are host copies. NULL otherwise.
     double *host_sol;
+    // Completion flag of a single-instance launch (layout C): after its last store to host_sol the workgroup writes this
+    // (non-zero) sequence number behind it, at host_sol[nx*N + nu*(N-1) + 6]; the host can then poll pinned memory instead
+    // of paying the wake-up latency of hipStreamSynchronize. 0 = no flag.
+    double host_seq;
+    // Single-instance handles, references left in pinned host memory by set_x_ref / set_u_ref (the closed-loop tick
+    // with per-tick references, rocket_landing_constraints.m:86-121): the launch's one workgroup rebuilds the
+    // reference-dependent table rows itself before anything reads them (refresh_reference_tables, tinympc_sweep.h),
+    // so the tick stays ONE launch. NULL otherwise.
+    const double *href_x, *href_u;  // nx x N, nu x (N-1), column-major, pinned host
+    double *dXref, *dUref;          // their device copies (kept current for the other kernels)
+    const double *Pinf;             // for pNref (admm.cpp:81)
 };
 
 struct ChunkTableParams {

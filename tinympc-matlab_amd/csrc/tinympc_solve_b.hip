@@ -66,6 +66,7 @@ struct BwdLds { double bg, blr; };
 template <int W, int KT, int R4, bool CT>
 __global__ void __launch_bounds__(64 * WPG) k_admm_solve_b(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    refresh_reference_tables(p, W, KT);  // references handed over in pinned host memory (single-instance handles)
     constexpr int IPW = 64 / W;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

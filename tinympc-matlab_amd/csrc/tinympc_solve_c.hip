@@ -157,6 +157,21 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     const size_t vrow0 = ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;  // knot 0 in the V-shaped arrays
     double *gGC = p.GC + (FAM ? vrow0 : 0), *gGL = p.GL + (FAM ? vrow0 : 0);
 
+    // Single-instance handles hand the references over in pinned host memory (SolveParams::href_x): every lane
+    // derives its own linear-cost entries straight from there -- the PCIe reads are in flight together with the
+    // rest of this prologue's loads, nothing waits on a table rebuild -- and mirrors them into the device copies
+    // (references, table rows) that the other kernels and k_build_tables use.
+    const bool href = p.href_x != nullptr;
+    const double dg_r = href ? p.ops[2 * M + 2 * CW + r] : 0.0;
+    double href_val[SMAX];
+    double xr_last[CW], pinf_row[CW];  // operands of pNref (admm.cpp:81), requested first so that ONE PCIe round trip covers all
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+        const bool in = href && (r < nx) && (q < nx);
+        xr_last[q] = in ? p.href_x[q + (size_t)(N - 1) * nx] : 0.0;
+        pinf_row[q] = in ? p.Pinf[q + (size_t)r * nx] : 0.0;
+    }
+    const double x0ref = (href && c == 0 && r < nx) ? p.href_x[r] : 0.0;  // knot 0 of the state rows: only mirrored
     // ---- this lane's elements: slot i <-> step k = c*S + i; state lanes own knot k+1, input lanes knot k
     double g[SMAX], v[SMAX], lo[SMAX], hi[SMAX], lr[SMAX], dd[SMAX];
     double gc[SMAX], gl[SMAX], lx[SMAX];  // FAM only
@@ -174,7 +189,13 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         dd[i] = (step[i] && is_u) ? gD[(size_t)k * dstride] : 0.0;
         lo[i] = ok[i] ? p.tables[(size_t)(kn + 1) * CW + r] : 0.0;
         hi[i] = ok[i] ? p.tables[(size_t)TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
-        lr[i] = ok[i] ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
+        if (href) {  // -(Xref .* Q) / -(Uref .* R), admm.cpp:77-79: the expression of k_build_tables, on the pinned copy
+            const double ref = ok[i] ? (is_x ? p.href_x[r + (size_t)kn * nx] : p.href_u[(r - nx) + (size_t)kn * nu]) : 0.0;
+            href_val[i] = ref;
+            lr[i] = ok[i] ? -(ref * dg_r) : 0.0;
+        } else {
+            lr[i] = ok[i] ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
+        }
         gc[i] = (FAM && ok[i]) ? gGC[(size_t)kn * 64] : 0.0;
         gl[i] = (FAM && ok[i]) ? gGL[(size_t)kn * 64] : 0.0;
         lx[i] = 0.0;
@@ -272,7 +293,34 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         }
         return lxv;
     };
-    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    double pnref = p.tables[(size_t)3 * TOFF + r];
+    if (href) {
+        // pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81): the sum of k_build_tables, term by term in the same order
+        double acc = 0.0;
+        if (is_x) {
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if (q < nx) acc += xr_last[q] * pinf_row[q];
+            acc = -acc;
+        }
+        pnref = acc;
+        // mirrors (stores nobody in this launch waits for)
+        double *tab = const_cast<double *>(p.tables);
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) {
+            const int kn = c * S + i + koff;
+            if (ok[i]) {
+                if (is_x) p.dXref[r + (size_t)kn * nx] = href_val[i];
+                else p.dUref[(r - nx) + (size_t)kn * nu] = href_val[i];
+                tab[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] = lr[i];
+            }
+        }
+        if (k0) {
+            p.dXref[r] = x0ref;
+            tab[(size_t)2 * TOFF + (size_t)CW + r] = -(x0ref * dg_r);
+        }
+        if (c == 0) tab[(size_t)3 * TOFF + r] = pnref;
+    }
     const double rho = p.rho;
     const int ct = p.check_termination;
     const int i_last = (T - 1) - (C - 1) * S;  // slot of the last step, in group C-1
@@ -505,6 +553,11 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             p.dstats[inst * 4 + 2] = res_pu;
             p.dstats[inst * 4 + 3] = res_du;
         }
+    }
+    if (p.host_sol && p.host_seq != 0.0) {  // (kernel arguments: uniform) everything above is in pinned memory: raise the flag
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) p.host_sol[(size_t)N * nx + (size_t)(N - 1) * nu + 6] = p.host_seq;
     }
 }
 

@@ -31,6 +31,7 @@ struct FamBwd { double bg, bv, blr, lx; };
 template <int W, int KT, bool TLDS, bool GMEM = false>
 __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    refresh_reference_tables(p, W, KT);  // references handed over in pinned host memory (single-instance handles)
     constexpr int IPW = 64 / W;
     const int lane = threadIdx.x;
     const int j = lane / W, r = lane % W;

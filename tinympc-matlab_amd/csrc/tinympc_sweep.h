@@ -4,11 +4,122 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "tinympc_device.h"
+
 namespace tinympc {
 
 // ------------------------------------------------------------------------------------------------
-// Generic-width helpers (W = 32, 64): broadcast lane K of every W-lane group to the whole group.
+// References handed over in pinned host memory (single-instance handles; SolveParams::href_x). The ONE workgroup of
+// the launch recomputes what k_build_tables derives from them -- the linref rows -(Xref .* Q), -(Uref .* R)
+// (admm.cpp:77, 79) and pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81), same expressions, same order of operations, so the
+// tables are bit-identical to a k_build_tables launch -- and mirrors the references into their device copies. Must be
+// called by all threads of the workgroup before anything reads p.tables; ends with a barrier.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void refresh_reference_tables(const SolveParams &p, int W, int KT) {
+    if (!p.href_x) return;  // kernel argument: uniform
+    const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu, nthreads = (int)blockDim.x;
+    // Phase 1: pinned host -> device copies, every thread's reads in flight at once (a host read is a PCIe round trip
+    // of a microsecond or two; anything that waits for them one after the other -- the pNref dot products did, in a
+    // first version -- costs that per element).
+    const int X = nx * N, U = nu * (N - 1);
+    for (int i = threadIdx.x; i < X; i += nthreads) p.dXref[i] = p.href_x[i];
+    for (int i = threadIdx.x; i < U; i += nthreads) p.dUref[i] = p.href_u[i];
+    __threadfence_block();
+    __syncthreads();
+    // Phase 2: the table rows, from the device copies (L2)
+    const size_t TR = (size_t)(N + 2) * W;
+    double *tab = const_cast<double *>(p.tables);
+    double *lr = tab + 2 * TR, *pn = lr + TR;
+    const double *dg = p.ops + (size_t)2 * W * KT + 2 * W;
+    const double *Xr = p.dXref, *Ur = p.dUref;
+    for (int idx = threadIdx.x; idx < N * W; idx += nthreads) {
+        const int kn = idx / W, r = idx % W;
+        double ref = 0.0;
+        if (r < nx) ref = -(Xr[r + (size_t)kn * nx] * dg[r]);
+        else if (r < nxu && kn < N - 1) ref = -(Ur[(r - nx) + (size_t)kn * nu] * dg[r]);
+        lr[(size_t)(kn + 1) * W + r] = ref;
+    }
+    for (int c = threadIdx.x; c < W; c += nthreads) {
+        double acc = 0.0;
+        if (c < nx) {
+            // same sum, same order as k_build_tables; the operands are fetched eight at a time so that the loop does
+            // not pay one L2 round trip per term (products beyond nx are exact zeros)
+            for (int k0 = 0; k0 < nx; k0 += 8) {
+                double a[8], b[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool in = k0 + q < nx;
+                    a[q] = in ? Xr[(k0 + q) + (size_t)(N - 1) * nx] : 0.0;
+                    b[q] = in ? p.Pinf[(k0 + q) + (size_t)c * nx] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k0 + q < nx) acc += a[q] * b[q];
+            }
+            acc = -acc;
+        }
+        pn[c] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide systems (16 < nx+nu <= 64): an instance spans 2 (W = 32) or 4 (W = 64) DPP rows of 16 lanes. The operand
+// vector of a sweep step is spread over those rows; `row_newbcast` only reaches inside a row, so the operand is first
+// replicated ACROSS the rows of the instance with the gfx950 cross-row swaps -- v_permlane16_swap (odd rows of the
+// first operand <-> even rows of the second) and v_permlane32_swap (upper half of the first <-> lower half of the
+// second), applied to two copies of the same register (tools/microbench_mfma_f64.hip prints their lane maps):
+//   W = 32   permlane16_swap(w, w)              -> E = [r0 r0 r2 r2], O = [r1 r1 r3 r3]
+//   W = 64   permlane32_swap(w, w)              -> P = [r0 r1 r0 r1], Q = [r2 r3 r2 r3]
+//            permlane16_swap(P, P), (Q, Q)      -> R0 .. R3 = [rj rj rj rj]
+// after which the mat-vec is the same fused chain as for W = 16, 16 columns per replicated operand:
+// acc += m[16 j + k] * Rj(row_newbcast:k). Per step: 2 (6) swap instructions on 32-bit halves + a few copies + KT FMAs,
+// where the first version of this path issued, per column, two ds_bpermute (W = 32) or two v_readlane (W = 64) in
+// front of the FMA -- on the serial x_i -> x_{i+1} chain.
+// Hazards: the swaps write VGPRs that the chain reads through DPP (2 wait states, `s_nop 1` opens every operand's
+// first block; checked by tools/isa_lint.py, which knows that the swaps write both of their operands).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned tiny_uint2 __attribute__((ext_vector_type(2)));
+
+template <int MODE16>
+__device__ __forceinline__ void cross_row_pair(double w, double &lo_rows, double &hi_rows) {
+    const unsigned l = (unsigned)__double2loint(w), h = (unsigned)__double2hiint(w);
+    tiny_uint2 a, b;
+    if constexpr (MODE16) {
+        a = __builtin_amdgcn_permlane16_swap(l, l, false, false);
+        b = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+    } else {
+        a = __builtin_amdgcn_permlane32_swap(l, l, false, false);
+        b = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+    }
+    lo_rows = __hiloint2double((int)b[0], (int)a[0]);
+    hi_rows = __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// acc += sum_{k<16} m[k] * (lane k of the DPP row of `w`), as four schedulable blocks of four fused DPP FMAs
+#define TINY_FMQ(i) "v_fmac_f64_dpp %[a], %[w], %[m" #i "] row_newbcast:%[b" #i "] row_mask:0xf bank_mask:0xf\n\t"
+template <int B0>
+__device__ __forceinline__ void dpp_block4(double &a, double w, const double *m4, bool first) {
+    if (first)
+        asm("s_nop 1\n\t" TINY_FMQ(0) TINY_FMQ(1) TINY_FMQ(2) TINY_FMQ(3)
+            : [a] "+v"(a)
+            : [w] "v"(w), [m0] "v"(m4[0]), [m1] "v"(m4[1]), [m2] "v"(m4[2]), [m3] "v"(m4[3]), [b0] "n"(B0), [b1] "n"(B0 + 1), [b2] "n"(B0 + 2), [b3] "n"(B0 + 3));
+    else
+        asm(TINY_FMQ(0) TINY_FMQ(1) TINY_FMQ(2) TINY_FMQ(3)
+            : [a] "+v"(a)
+            : [w] "v"(w), [m0] "v"(m4[0]), [m1] "v"(m4[1]), [m2] "v"(m4[2]), [m3] "v"(m4[3]), [b0] "n"(B0), [b1] "n"(B0 + 1), [b2] "n"(B0 + 2), [b3] "n"(B0 + 3));
+}
+template <int NCOLS>
+__device__ __forceinline__ void dpp_row16(double &a, double w, const double *m16) {
+    static_assert(NCOLS % 4 == 0 && NCOLS >= 4 && NCOLS <= 16, "columns per replicated operand: 4, 8, 12 or 16");
+    dpp_block4<0>(a, w, m16, true);
+    if constexpr (NCOLS > 4) dpp_block4<4>(a, w, m16 + 4, false);
+    if constexpr (NCOLS > 8) dpp_block4<8>(a, w, m16 + 8, false);
+    if constexpr (NCOLS > 12) dpp_block4<12>(a, w, m16 + 12, false);
+}
+
+#ifdef TINYMPC_WIDE_SHFL  // dev switch (tools/build_variants.sh): the first version of the wide path, for A/B runs
 template <int W, int K>
 __device__ __forceinline__ double group_bcast(double w) {
     if constexpr (W == 64) {
@@ -27,6 +138,7 @@ __device__ __forceinline__ void matvec_accumulate(const double (&m)[KT], double 
         matvec_accumulate<W, KT, K + 1>(m, w, acc);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // W = 16: the mat-vec as ONE chain of fused VOP2+DPP instructions, acc += m_k * (w of lane k of the
@@ -65,9 +177,31 @@ __device__ __forceinline__ double group_matvec(const double (&m)[KT], double w, 
         if constexpr (KT == 16) asm(TINY_FM(12) TINY_FM(13) TINY_FM(14) TINY_FM(15) : [a] "+v"(a) : [w] "v"(w), TINY_M16);
         return a;
     } else {
+#ifdef TINYMPC_WIDE_SHFL
         double acc[2] = {c, 0.0};
         matvec_accumulate<W, KT>(m, w, acc);
         return acc[0] + acc[1];
+#else
+        double a = c;
+        if constexpr (W == 32) {
+            static_assert(KT > 16 && KT <= 32 && KT % 4 == 0, "W=32: 16 < KT <= 32, a multiple of 4");
+            double e, o;
+            cross_row_pair<1>(w, e, o);
+            dpp_row16<16>(a, e, m);
+            dpp_row16<KT - 16>(a, o, m + 16);
+        } else {
+            static_assert(W == 64 && KT > 32 && KT <= 64 && KT % 4 == 0, "W=64: 32 < KT <= 64, a multiple of 4");
+            double pq0, pq1, r0, r1, r2, r3;
+            cross_row_pair<0>(w, pq0, pq1);
+            cross_row_pair<1>(pq0, r0, r1);
+            cross_row_pair<1>(pq1, r2, r3);
+            dpp_row16<16>(a, r0, m);
+            dpp_row16<16>(a, r1, m + 16);
+            dpp_row16<(KT - 32 > 16 ? 16 : KT - 32)>(a, r2, m + 32);
+            if constexpr (KT > 48) dpp_row16<KT - 48>(a, r3, m + 48);
+        }
+        return a;
+#endif
     }
 }
 

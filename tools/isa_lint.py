@@ -53,6 +53,8 @@ def lint(asm_text: str):
                     break
                 waited += ws
         dest = _regs(toks[0].split()[0]) if mnem.startswith("v_") and toks and toks[0] else set()
+        if mnem.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap_b")) and len(toks) > 1:
+            dest |= _regs(toks[1].split()[0])  # the swaps write both of their operands
         ws = 1
         if mnem == "s_nop":
             ws = int(toks[0]) + 1

@@ -50,3 +50,37 @@ for name, prob in (("cartpole N=10", P.cartpole(10, True)), ("quadrotor N=50", P
         x = prob.A @ x + prob.B @ U[:, 0]
     print(f"{name:16s} single-instance verbs: set_x0 {1e6*t[0]/n:5.1f} + solve {1e6*t[1]/n:5.1f} + get_solution {1e6*t[2]/n:5.1f} = {1e6*sum(t)/n:6.1f} us per tick")
     s.reset()
+
+# The tracking loops of the reference re-send the references every tick (rocket_landing_constraints.m:86-121):
+# set_x0 -> set_x_ref -> set_u_ref -> solve -> get_solution on a single-instance handle. References go through pinned
+# host memory; the solve kernel rebuilds the table rows they determine, so the tick is still one launch.
+for name, prob in (("quadrotor N=50", P.quadrotor(50)), ("rocket N=10", P.rocket(10)), ("rocket N=100", P.rocket(100))):
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, fdyn=prob.fdyn, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if getattr(prob, "cones", None):
+        s.set_cone_constraints(**prob.cones)
+    if getattr(prob, "linear", None):
+        s.set_linear_constraints(**prob.linear)
+    x = prob.x0.copy()
+    goal = np.zeros(prob.nx)
+    X = np.zeros((prob.nx, prob.N), order="F"); U = np.zeros((prob.nu, prob.N - 1), order="F")
+    uref = np.asfortranarray(prob.u_ref if prob.u_ref is not None else np.zeros((prob.nu, prob.N - 1)))
+    t = [0.0] * 5; n = 200; total = n + 20 + prob.N
+    iters = 0
+    for k in range(n + 20):
+        xx = np.ascontiguousarray(x)
+        xref = np.asfortranarray(np.stack([prob.x0 + (goal - prob.x0) * (i + k) / (total - 1) for i in range(prob.N)], axis=1))
+        t0 = time.perf_counter(); L.tinympc_set_x0(s._h, dp(xx), prob.nx, 0)
+        t1 = time.perf_counter(); L.tinympc_set_x_ref(s._h, dp(xref), prob.nx, prob.N, 0)
+        t2 = time.perf_counter(); L.tinympc_set_u_ref(s._h, dp(uref), prob.nu, prob.N - 1, 0)
+        t3 = time.perf_counter(); L.tinympc_solve(s._h, 0)
+        t4 = time.perf_counter(); L.tinympc_get_solution(s._h, dp(X), dp(U), 0)
+        t5 = time.perf_counter()
+        if k >= 20:
+            for q, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))): t[q] += b - a
+            iters += s.get_stats()["iter"]
+        x = prob.A @ x + prob.B @ U[:, 0] + (prob.fdyn if prob.fdyn is not None else 0.0)
+    print(f"{name:16s} tick with per-tick references: set_x0 {1e6*t[0]/n:4.1f} + set_x_ref {1e6*t[1]/n:4.1f} + set_u_ref {1e6*t[2]/n:4.1f} + solve {1e6*t[3]/n:5.1f} "
+          f"+ get_solution {1e6*t[4]/n:4.1f} = {1e6*sum(t)/n:6.1f} us per tick ({iters/n:.1f} iterations/tick)")
+    s.reset()
