@@ -229,6 +229,22 @@ int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *
  * tinympc_reset; lets a caller consume results without a D2H copy. */
 int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u);
 
+/* Closed-loop SESSION (single-instance handles): the reference's control loops call set_x0 -> solve -> get_solution
+ * once per tick (examples/cartpole_example_mpc.m:36-44); every such tick pays a kernel launch and a stream
+ * synchronisation (~20 us of a ~25 us tick). In a session the solve kernel is launched ONCE and stays resident: it polls
+ * a mailbox in pinned host memory for the next x0, runs the warm-started solve with the ADMM state kept in registers, and
+ * writes the solution + a completion stamp back into pinned memory, where tinympc_session_step polls for it.
+ *   tinympc_session_begin   settings, bounds, cache are frozen for the session; references may change between ticks
+ *                           (tinympc_set_x_ref / _set_u_ref: picked up by the next step)
+ *   tinympc_session_step    x0 in (nx), first controls out (nu); tinympc_get_solution / _get_stats work as usual
+ *   tinympc_session_end     stops the kernel; the handle continues with ordinary solves from the same ADMM state.
+ * Any other verb that needs the device ends the session implicitly. The resident kernel leaves on its own after 2 s
+ * without a command (a crashed host does not leave it spinning); the next step restarts it transparently. Results are
+ * identical, bit for bit, to the same ticks issued as tinympc_mpc_step_batch calls. */
+int tinympc_session_begin(tinympc_solver *s);
+int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out);
+int tinympc_session_end(tinympc_solver *s);
+
 /* Launch the solve without waiting (same kernel as tinympc_solve); pair with tinympc_synchronize. Every verb
  * that changes an input of the launch in flight (set_x0, mpc_step, ... -- on single-instance handles x0 lives in
  * pinned host memory that the kernel reads directly) waits for the launch first, so the sequence solve_async ->

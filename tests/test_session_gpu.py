@@ -1,0 +1,108 @@
+"""Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks from
+a mailbox in pinned host memory. A session's ticks must equal, bit for bit, the same ticks issued as ordinary launches
+(tinympc_mpc_step_batch) -- same warm-start state, same stale-v semantics after converged solves (admm.cpp:181-197),
+same per-tick references -- and the handle must continue with ordinary solves afterwards."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import pytest
+from conftest import rel_err
+
+import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(pkg, prob, settings, families=False):
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, fdyn=prob.fdyn, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if prob.x_ref is not None:
+        s.set_x_ref(prob.x_ref)
+    if prob.u_ref is not None:
+        s.set_u_ref(prob.u_ref)
+    if families:
+        s.set_cone_constraints(**prob.cones)
+        s.set_linear_constraints(**prob.linear)
+    return s
+
+
+@pytest.mark.parametrize("name", ["cartpole", "quadrotor"])
+def test_session_ticks_equal_launched_ticks(pkg, name):
+    P = pkg.problems
+    prob = P.cartpole(10, True) if name == "cartpole" else P.quadrotor(50)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=80)
+    a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    a.session_begin()
+    xa, xb = prob.x0.copy(), prob.x0.copy()
+    for k in range(25):
+        ua = a.session_step(xa)
+        ub = b.mpc_step(xb)[:, 0]
+        orc.set_x0(xa)
+        orc.solve()
+        np.testing.assert_array_equal(ua, ub)
+        assert a.get_stats()["iter"] == b.get_stats()["iter"] == orc.stats()["iter"], k
+        np.testing.assert_array_equal(a.get_solution()["states"], b.get_solution()["states"])
+        assert rel_err(a.get_solution()["controls"], orc.solution()[1]) < 1e-9
+        xa = prob.A @ xa + prob.B @ ua
+        xb = prob.A @ xb + prob.B @ ub
+    a.session_end()
+    # the handle goes on with ordinary launches from the session's ADMM state
+    ua, ub = a.mpc_step(xa)[:, 0], b.mpc_step(xb)[:, 0]
+    np.testing.assert_array_equal(ua, ub)
+    assert a.get_stats()["iter"] == b.get_stats()["iter"]
+    a.reset()
+    b.reset()
+
+
+def test_session_with_per_tick_references_and_families(pkg):
+    """rocket_landing_constraints.m:86-121 inside a session: references re-sent every tick, cones + linear row + fdyn."""
+    P = pkg.problems
+    prob = P.rocket(20)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
+    a, b = _solver(pkg, prob, settings, True), _solver(pkg, prob, settings, True)
+    a.session_begin()
+    x = prob.x0.copy()
+    goal = np.zeros(prob.nx)
+    for k in range(12):
+        x_ref = np.stack([prob.x0 + (goal - prob.x0) * min(i + k, 99) / 99 for i in range(prob.N)], axis=1)
+        for h in (a, b):
+            h.set_x_ref(x_ref)
+            h.set_u_ref(prob.u_ref)
+        ua = a.session_step(x)
+        ub = b.mpc_step(x)[:, 0]
+        np.testing.assert_array_equal(ua, ub)
+        assert a.get_stats()["iter"] == b.get_stats()["iter"], k
+        x = prob.A @ x + prob.B @ ua + prob.fdyn
+    a.session_end()
+    a.reset()
+    b.reset()
+
+
+def test_session_is_ended_by_other_verbs_and_survives_idling(pkg):
+    P = pkg.problems
+    prob = P.quadrotor(20)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=40)
+    a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
+    x = prob.x0.copy()
+    a.session_begin()
+    np.testing.assert_array_equal(a.session_step(x), b.mpc_step(x)[:, 0])
+    # a verb that needs the device ends the session implicitly; the handle keeps working
+    a.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min * 0.8, prob.u_max * 0.8)
+    b.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min * 0.8, prob.u_max * 0.8)
+    with pytest.raises(pkg.TinyMPCError):
+        a.session_step(x)
+    np.testing.assert_array_equal(a.mpc_step(x)[:, 0], b.mpc_step(x)[:, 0])
+    # idle longer than the resident kernel's time-out (2 s): the next step restarts it transparently
+    a.session_begin()
+    np.testing.assert_array_equal(a.session_step(x), b.mpc_step(x)[:, 0])
+    time.sleep(2.6)
+    x2 = 0.9 * x
+    np.testing.assert_array_equal(a.session_step(x2), b.mpc_step(x2)[:, 0])
+    a.session_end()
+    a.session_end()  # ending twice is harmless
+    a.reset()
+    b.reset()

@@ -86,6 +86,9 @@ SIGNATURES = {
     "tinympc_synchronize": (C.c_int, [Handle]),
     "tinympc_solve_timed": (C.c_int, [Handle, C.POINTER(C.c_float)]),
     "tinympc_mpc_step_batch": (C.c_int, [Handle, c_double_p, c_double_p]),
+    "tinympc_session_begin": (C.c_int, [Handle]),
+    "tinympc_session_step": (C.c_int, [Handle, c_double_p, c_double_p]),
+    "tinympc_session_end": (C.c_int, [Handle]),
     "tinympc_get_launch_info": (C.c_int, [Handle, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "tinympc_get_layout": (C.c_int, [Handle]),
     "tinympc_get_stream": (C.c_void_p, [Handle]),

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -61,6 +62,9 @@ struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings
 };
 
 constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
+// Every pinned buffer the kernels and the host exchange data through WHILE a kernel runs (completion flags, the session
+// mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
+// GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
 constexpr int kLayoutCBatchMax = 1024;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
 
@@ -121,7 +125,13 @@ struct tinympc_solver {
     // pinned h_sol -- the reference's per-tick sequence set_x0 / solve / get_solution then costs ONE launch and ONE
     // synchronisation instead of three synchronous copies around the launch.
     double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
-    unsigned long long launch_seq = 0; // sequence number of the last launch that raises the completion flag (0: none pending)
+    // Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks
+    // from this mailbox in pinned memory (layout: SolveParams::mail).
+    double *h_mail = nullptr;          // [32]
+    bool session_active = false;
+    // ONE counter stamps session commands and flag-raising launches alike (both complete by writing their stamp into the
+    // same slot of h_sol: a launch after a session must not find its number already there)
+    unsigned long long session_seq = 0;  // stamp of the last session command / flag-raising launch
     bool flag_pending = false;
     // ... and set_x_ref / set_u_ref only fill these pinned copies; the next launch's workgroup rebuilds the
     // reference-dependent table rows from them (refresh_reference_tables): a tick with per-tick references
@@ -165,8 +175,13 @@ int dalloc(tinympc_solver *s, T **p, size_t count) {
     return TINYMPC_OK;
 }
 
+int end_session(tinympc_solver *s);
+
+// Every verb that touches the device passes through here first: a resident session kernel would make it wait forever
+// on the handle's stream, so the session is ended (its state is in HBM after every tick) before anything else happens.
 int bind_device(tinympc_solver *s) {
     HIP_TRY(hipSetDevice(s->device));
+    if (s->session_active) return end_session(s);
     return TINYMPC_OK;
 }
 
@@ -320,8 +335,8 @@ int refresh_families(tinympc_solver *s) {
 // hipStreamSynchronize (whose wake-up costs several microseconds of a ~25 us tick).
 void arm_completion_flag(tinympc_solver *s, SolveParams &p) {
     if (!p.host_sol) return;
-    s->launch_seq += 1;
-    p.host_seq = (double)s->launch_seq;
+    s->session_seq += 1;
+    p.host_seq = (double)s->session_seq;
     s->flag_pending = true;
 }
 
@@ -410,13 +425,67 @@ int launch(tinympc_solver *s, bool timed) {
     return TINYMPC_OK;
 }
 
+// ---- closed-loop session ------------------------------------------------------------------------------------
+constexpr double kSessionIdleSeconds = 2.0;  // the resident kernel leaves on its own after this long without a command
+
+void write_command(tinympc_solver *s, int flags, const double *x0) {
+    // payload 0 = flags, payloads 1.. = x0; line l = [7 payload | stamp]. Payload before stamp, line by line (x86 keeps
+    // the order of stores; the compiler is kept from reordering by the fences).
+    volatile double *m = s->h_mail;
+    const double stamp = (double)(++s->session_seq);
+    const int npay = 1 + s->nx, nlines = (npay + 6) / 7;
+    for (int l = 0; l < nlines; ++l) {
+        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = (q == 0) ? (double)flags : (x0 ? x0[q - 1] : 0.0);
+        std::atomic_thread_fence(std::memory_order_release);
+        m[8 * l + 7] = stamp;
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+int launch_session_kernel(tinympc_solver *s) {
+    int rc = refresh_derived(s);
+    if (rc) return rc;
+    const bool fam = s->families_active();
+    if (fam && (rc = refresh_families(s))) return rc;
+    SolveParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = 1;
+    p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
+    p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
+    p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0; p.x0_mirror = s->dx0;
+    p.groups = s->groups;
+    p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
+    p.istats = s->distats; p.dstats = s->ddstats;
+    p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
+    p.const_tables = s->tables_const() ? 1 : 0;
+    p.host_sol = s->h_sol;
+    p.href_x = s->h_xref; p.href_u = s->h_uref; p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;  // (re-read on request)
+    s->refs_on_host = false;  // the prologue stages them
+    p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
+    p.families = fam ? 1 : 0;
+    p.mail = s->h_mail;
+    p.session_expect = (double)(s->session_seq + 1);
+    p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
+    HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
+    return TINYMPC_OK;
+}
+
+int end_session(tinympc_solver *s) {
+    if (!s->session_active) return TINYMPC_OK;
+    write_command(s, 1, nullptr);  // stop
+    s->session_active = false;     // (before anything that could come back here)
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
 void destroy(tinympc_solver *s) {
     if (!s) return;
     // teardown is best effort: errors here have nowhere useful to go
     (void)hipSetDevice(s->device);
+    if (s->session_active) (void)end_session(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
     if (s->h_sol) (void)hipHostFree(s->h_sol);
+    if (s->h_mail) (void)hipHostFree(s->h_mail);
     if (s->h_xref) (void)hipHostFree(s->h_xref);
     if (s->h_uref) (void)hipHostFree(s->h_uref);
     if (s->h_x0) (void)hipHostFree(s->h_x0);
@@ -528,7 +597,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         // 2-3x shorter iteration for one instance, lower throughput once the batch fills the chip's wave slots.
         // Default for small batches; TINYMPC_LAYOUT=C forces it, =A / =B exclude it.
         chunk_plan(N, &s->chunk_len, &s->chunk_count, &s->chunk_levels);
-        s->lds_bytes_c = solve_c_lds_bytes(nx, s->chunk_levels);
+        // (single-instance handles stage their references in LDS, see k_admm_solve_c's prologue)
+        s->lds_bytes_c = batch == 1 ? solve_c_lds_bytes_refs(nx, nu, N, s->chunk_levels) : solve_c_lds_bytes(nx, s->chunk_levels);
         const bool c_possible = (W == 16) && (s->chunk_len <= 8) && (s->lds_bytes_c <= kLdsMax);
         bool want_c = c_possible && batch <= kLayoutCBatchMax;
         if (const char *env = getenv("TINYMPC_LAYOUT")) {
@@ -601,12 +671,12 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     HIP_TRY_S(hipMemsetAsync(s->ddstats, 0, sizeof(double) * batch * 4, s->stream));
 
     if (batch == 1) {
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_sol, sizeof(double) * (X + U + 8), hipHostMallocDefault));
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx, hipHostMallocDefault));
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu, hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_sol, sizeof(double) * (X + U + 8), hipHostMallocCoherent));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx, hipHostMallocCoherent));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu, hipHostMallocCoherent));
         std::memset(s->h_sol, 0, sizeof(double) * (X + U + 8));
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_xref, sizeof(double) * X, hipHostMallocDefault));
-        HIP_TRY_S(hipHostMalloc((void **)&s->h_uref, sizeof(double) * (U ? U : 1), hipHostMallocDefault));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_xref, sizeof(double) * X, hipHostMallocCoherent));
+        HIP_TRY_S(hipHostMalloc((void **)&s->h_uref, sizeof(double) * (U ? U : 1), hipHostMallocCoherent));
         std::memset(s->h_xref, 0, sizeof(double) * X);  // tiny_setup zeroes the references (tiny_api.cpp:83-84)
         std::memset(s->h_uref, 0, sizeof(double) * (U ? U : 1));
     }
@@ -724,11 +794,12 @@ int tinympc_solve_async(tinympc_solver *s) {
 int tinympc_synchronize(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if (s->session_active) return TINYMPC_OK;  // session steps are synchronous; the resident kernel never "finishes"
     if (s->flag_pending && s->host_sol_state == 1) {
         // The launch in flight raises a flag in pinned memory after its last store: poll it. Bounded: a kernel that takes
         // longer than the polling budget (long solves) is waited for the ordinary way.
         const volatile double *flag = s->h_sol + s->X() + s->U() + 6;
-        const double want = (double)s->launch_seq;
+        const double want = (double)s->session_seq;
         for (int spin = 0; spin < 400000; ++spin) {
             if (*flag == want) {
                 std::atomic_thread_fence(std::memory_order_acquire);
@@ -780,8 +851,8 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     const size_t nx0 = (size_t)s->batch * s->nx, nu0 = (size_t)s->batch * s->nu;
     s->x0_on_host = false;  // this call brings its own x0
     if (!s->h_x0) {  // pinned staging, so that the small copies are true async DMA and need no extra sync
-        HIP_TRY(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx0, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s->h_x0, sizeof(double) * nx0, hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void **)&s->h_u0, sizeof(double) * nu0, hipHostMallocCoherent));
     }
     if (s->host_sol_state == 1) {  // a launch of tinympc_solve_async may still be reading h_x0
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -806,6 +877,71 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     }
     std::memcpy(u0_out, s->h_u0, sizeof(double) * nu0);
     return TINYMPC_OK;
+}
+
+int tinympc_session_begin(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;  // (ends a session that is still open)
+    if (!s->host_path() || !(s->layout_c || (s->families_active() && s->fam_c)))
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles on the latency kernel only (batch 1, nx+nu <= 16, N <= 129)");
+    if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
+    if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
+    if (!s->h_mail) {
+        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 32, hipHostMallocCoherent));
+        std::memset(s->h_mail, 0, sizeof(double) * 32);
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = launch_session_kernel(s))) return rc;
+    s->session_active = true;
+    s->flag_pending = false;
+    return TINYMPC_OK;
+}
+
+int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
+    if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
+    const int flags = s->refs_on_host ? 2 : 0;
+    s->refs_on_host = false;
+    write_command(s, flags, x0);
+    const volatile double *done = s->h_sol + s->X() + s->U() + 6;
+    const double want = (double)s->session_seq;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        if (*done == want) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0xffff) {
+            // Nothing for a while: has the kernel left (idle time-out)? Then start it again; it waits for exactly the
+            // command that is pending. A stream error or 30 s without an answer end the session with an error.
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) {
+                s->session_seq -= 1;  // (launch_session_kernel waits for session_seq + 1)
+                rc = launch_session_kernel(s);
+                s->session_seq += 1;
+                if (rc) { s->session_active = false; return rc; }
+            } else if (q != hipErrorNotReady) {
+                s->session_active = false;
+                return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
+            }
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
+                (void)end_session(s);
+                return fail(TINYMPC_ERR_HIP, "session_step: no answer from the resident kernel within 30 s");
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->host_sol_state = 2;
+    std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
+    return TINYMPC_OK;
+}
+
+int tinympc_session_end(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    return end_session(s);
 }
 
 int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count) {

@@ -131,6 +131,14 @@ struct SolveParams {
     // (non-zero) sequence number behind it, at host_sol[nx*N + nu*(N-1) + 6]; the host can then poll pinned memory instead
     // of paying the wake-up latency of hipStreamSynchronize. 0 = no flag.
     double host_seq;
+    // Closed-loop SESSION (tinympc_session_begin / _step / _end; layout C, single instance): the kernel stays resident
+    // and polls a mailbox in pinned host memory for the next tick's command instead of being launched per tick. The
+    // mailbox is an array of 64-byte lines [7 payload doubles | stamp]; payload 0 = flags (1: stop, 2: references changed),
+    // payloads 1.. = x0. The host writes a line's payload before its stamp, so a line whose stamp equals the expected
+    // sequence number is complete. NULL = an ordinary one-shot launch.
+    const double *mail;
+    double session_expect;             // stamp of the first command to wait for
+    unsigned long long session_idle;   // exit after this many 100 MHz ticks without a command (the exit every wave reaches)
     // Single-instance handles, references left in pinned host memory by set_x_ref / set_u_ref (the closed-loop tick
     // with per-tick references, rocket_landing_constraints.m:86-121): the launch's one workgroup rebuilds the
     // reference-dependent table rows itself before anything reads them (refresh_reference_tables, tinympc_sweep.h),
@@ -201,6 +209,7 @@ hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes,
 hipError_t launch_build_chunk_tables(const ChunkTableParams &p, hipStream_t stream);
 void chunk_plan(int N, int *S, int *C, int *Lc);
 size_t solve_c_lds_bytes(int nx, int Lc);
+size_t solve_c_lds_bytes_refs(int nx, int nu, int N, int Lc);
 size_t chunk_table_doubles(int nx, int Lc);
 int chunk_ks(int nx);
 // Layout A plus adaptive rho (per-instance rho, Taylor-updated operators).

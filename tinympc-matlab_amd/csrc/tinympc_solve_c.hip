@@ -8,8 +8,12 @@
 //     backward  [p_k;    d_k] = Mb [p_{k+1}; r_k] + [q_k;0] + cb     (admm.cpp:13-20,  Psi = AmBKt)
 //   pass 1  every chunk c (S consecutive steps, one 16-lane group) runs its S steps from a ZERO incoming state
 //           (chunk 0: from x_0; the last chunk of the backward sweep: from p_{N-1}) -- only the end value is kept;
-//   carry   the true state after chunk c is  X_c = end_c + Phi^S X_{c-1}: a Hillis-Steele scan over the C <= 16
-//           chunks with the precomputed powers Phi^(S*2^l) -- log2(C) mat-vecs, values exchanged through LDS;
+//   carry   the true state after chunk c is  X_c = end_c + Phi^S X_{c-1}: a two-level scan over the C <= 16 chunks with
+//           the precomputed powers Phi^S .. Phi^(4S). Inside a wavefront (4 chunks = its 4 DPP rows) the prefix is
+//           formed with cross-row swaps -- no LDS, no barrier; the four wavefronts' totals cross through LDS behind ONE
+//           barrier; a last mat-vec brings the incoming carry to every row. 5 mat-vecs and 1 barrier per sweep (the
+//           first version: a 4-level Hillis-Steele scan over all 16 chunks, 4 mat-vecs but 4 barriers + 4 LDS exchanges
+//           on the dependent path -- half of the iteration);
 //   pass 2  the chunk is swept again from its true incoming state X_{c-1}: these are the sweep's real values.
 // Depth per sweep: 2*S + log2(C) mat-vecs instead of N-1 (quadrotor N=50: 12 instead of 49). Passes 1 and 2 use
 // the lane's rows of Mf / Mb, resident in registers; only the carry matrices come from LDS. (A variant that
@@ -22,6 +26,10 @@
 // of the carries (~1e-14 relative); iteration counts match the reference in every test.
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
+
+#ifndef TINY_EXP
+#define TINY_EXP 0
+#endif
 
 namespace tinympc {
 
@@ -61,11 +69,11 @@ __device__ __forceinline__ double row_max(double v) {
 __host__ __device__ inline int chunk_ks_impl(int nx) { return nx <= 8 ? 8 : nx <= 12 ? 12 : 16; }
 int chunk_ks(int nx) { return chunk_ks_impl(nx); }
 
-// ---- carry matrices PhiS_l = Phi^(S 2^l) | PsiS_l = Psi^(S 2^l)  (l < Lc), each [16][KS] row-major (KS = nx rounded
+// ---- carry matrices PhiS_l = Phi^(S (l+1)) | PsiS_l = Psi^(S (l+1))  (l < Lc = 4), each [16][KS] row-major (KS = nx rounded
 //      up to 8 / 12 / 16: their operand is a state vector), zero outside the nx x nx state block; Phi, Psi are the
 //      state blocks of the fused operators of k_build_operators
 __global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTableParams p) {
-    __shared__ double Base[256], Cur[256], Tmp[256];
+    __shared__ double Base[256], Cur[256], Tmp[256], Pw[256];
     const int nx = p.nx, KT = p.KT, KS = chunk_ks_impl(nx), S = p.S, Lc = p.Lc, tid = threadIdx.x;
     const int r = tid / 16, k = tid % 16;  // 16 x 16 working matrices
     const size_t M = (size_t)CW * KT, MS = (size_t)CW * KS;
@@ -90,9 +98,11 @@ __global__ void __launch_bounds__(256) k_build_chunk_tables(const ChunkTablePara
             Cur[tid] = Tmp[tid];
             __syncthreads();
         }
-        for (int l = 0; l < Lc; ++l) {  // Base^(S 2^l)
+        Pw[tid] = Cur[tid];  // Base^S
+        __syncthreads();
+        for (int l = 0; l < Lc; ++l) {  // Base^(S (l+1))
             if (in) dst[(size_t)l * MS + r * KS + k] = Cur[tid];
-            mul(Tmp, Cur, Cur);
+            mul(Tmp, Pw, Cur);
             Cur[tid] = Tmp[tid];
             __syncthreads();
         }
@@ -108,16 +118,18 @@ void chunk_plan(int N, int *S, int *C, int *Lc) {
     const int T = N - 1;
     *S = (T + CGROUPS - 1) / CGROUPS;
     *C = (T + *S - 1) / *S;
-    int l = 0;
-    while ((1 << l) < *C) ++l;
-    *Lc = l;
+    *Lc = 4;  // carry matrices: powers S, 2S, 3S, 4S
 }
 
 size_t chunk_table_doubles(int nx, int Lc) { return (size_t)2 * Lc * CW * chunk_ks(nx); }
 
 size_t solve_c_lds_bytes(int nx, int Lc) {
-    // carry matrices + carry ping-pong Y[2][256] + boundary q Q[256] + residual partials R[16][4]
-    return sizeof(double) * ((size_t)2 * Lc * CW * (chunk_ks(nx) + 2) + 2 * 256 + 256 + 64);
+    // carry matrices + wave totals ping-pong Y[2][256] (64 used each) + boundary q Q[256] + residual partials R[16][4]
+    return sizeof(double) * ((size_t)2 * Lc * CW * (chunk_ks(nx) + 2) + 2 * 256 + 256 + 64 + 32 + 3 * MAX_LIN_ROWS * CW);
+}
+// ... + the staged references (nx x N | nu x (N-1)) of a single-instance handle, see the kernel's prologue
+size_t solve_c_lds_bytes_refs(int nx, int nu, int N, int Lc) {
+    return solve_c_lds_bytes(nx, Lc) + sizeof(double) * ((size_t)nx * N + (size_t)nu * (N - 1));
 }
 
 // FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there)
@@ -140,6 +152,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     double *sY = sTab + (size_t)2 * Lc * ML;  // [2][256]
     double *sQ = sY + 512;                    // [256]
     double *sR = sQ + 256;                    // [16][4]
+    double *sMail = sR + 64;                  // [32] the session mailbox as last polled (+ the poller's time-out verdict)
+    double *sLin = sMail + 32;                // [MAX_LIN_ROWS][3][16]  a_k | b_k | 1/||a_k||^2 per lane row (FAM)
+    double *sRef = sLin + 3 * MAX_LIN_ROWS * CW;  // [nx*N | nu*(N-1)] references staged from pinned host memory (href only)
     const double *PH = sTab, *PS = PH + (size_t)Lc * ML;
     for (int i = tid; i < 2 * Lc * (int)MS; i += CTHREADS) {
         const int mat = i / (int)MS, rem = i % (int)MS;
@@ -157,21 +172,28 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     const size_t vrow0 = ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;  // knot 0 in the V-shaped arrays
     double *gGC = p.GC + (FAM ? vrow0 : 0), *gGL = p.GL + (FAM ? vrow0 : 0);
 
-    // Single-instance handles hand the references over in pinned host memory (SolveParams::href_x): every lane
-    // derives its own linear-cost entries straight from there -- the PCIe reads are in flight together with the
-    // rest of this prologue's loads, nothing waits on a table rebuild -- and mirrors them into the device copies
-    // (references, table rows) that the other kernels and k_build_tables use.
+    // Single-instance handles hand the references over in pinned host memory (SolveParams::href_x). A read of host
+    // memory is a PCIe round trip and the link keeps only a few dozen of them in flight, so the references are fetched
+    // ONCE, fully coalesced (about a hundred 64-byte requests for the quadrotor), into LDS -- and mirrored into their
+    // device copies on the way; every lane then derives its own linear-cost entries from LDS behind the prologue's
+    // barrier (a first version let every lane fetch its own entries from the host: ~6 us of a 25 us tick).
+    const bool session = p.mail != nullptr;
     const bool href = p.href_x != nullptr;
-    const double dg_r = href ? p.ops[2 * M + 2 * CW + r] : 0.0;
-    double href_val[SMAX];
-    double xr_last[CW], pinf_row[CW];  // operands of pNref (admm.cpp:81), requested first so that ONE PCIe round trip covers all
-#pragma unroll
-    for (int q = 0; q < CW; ++q) {
-        const bool in = href && (r < nx) && (q < nx);
-        xr_last[q] = in ? p.href_x[q + (size_t)(N - 1) * nx] : 0.0;
-        pinf_row[q] = in ? p.Pinf[q + (size_t)r * nx] : 0.0;
-    }
-    const double x0ref = (href && c == 0 && r < nx) ? p.href_x[r] : 0.0;  // knot 0 of the state rows: only mirrored
+    const double dg_r = (href || session) ? p.ops[2 * M + 2 * CW + r] : 0.0;
+    const int Xn = nx * N, Un = nu * T;
+    auto stage_refs = [&]() {  // pinned host -> LDS (+ device copies); callers put a barrier behind it
+        for (int i = tid; i < Xn; i += CTHREADS) {
+            const double x = p.href_x[i];
+            sRef[i] = x;
+            p.dXref[i] = x;
+        }
+        for (int i = tid; i < Un; i += CTHREADS) {
+            const double u = p.href_u[i];
+            sRef[Xn + i] = u;
+            p.dUref[i] = u;
+        }
+    };
+    if (href) stage_refs();
     // ---- this lane's elements: slot i <-> step k = c*S + i; state lanes own knot k+1, input lanes knot k
     double g[SMAX], v[SMAX], lo[SMAX], hi[SMAX], lr[SMAX], dd[SMAX];
     double gc[SMAX], gl[SMAX], lx[SMAX];  // FAM only
@@ -189,13 +211,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         dd[i] = (step[i] && is_u) ? gD[(size_t)k * dstride] : 0.0;
         lo[i] = ok[i] ? p.tables[(size_t)(kn + 1) * CW + r] : 0.0;
         hi[i] = ok[i] ? p.tables[(size_t)TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
-        if (href) {  // -(Xref .* Q) / -(Uref .* R), admm.cpp:77-79: the expression of k_build_tables, on the pinned copy
-            const double ref = ok[i] ? (is_x ? p.href_x[r + (size_t)kn * nx] : p.href_u[(r - nx) + (size_t)kn * nu]) : 0.0;
-            href_val[i] = ref;
-            lr[i] = ok[i] ? -(ref * dg_r) : 0.0;
-        } else {
-            lr[i] = ok[i] ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;
-        }
+        lr[i] = (ok[i] && !href) ? p.tables[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] : 0.0;  // (href: after the barrier)
         gc[i] = (FAM && ok[i]) ? gGC[(size_t)kn * 64] : 0.0;
         gl[i] = (FAM && ok[i]) ? gGL[(size_t)kn * 64] : 0.0;
         lx[i] = 0.0;
@@ -204,7 +220,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     const bool k0 = (c == 0) && is_x;
     double g0 = k0 ? gG[0] : 0.0, v0 = k0 ? gV[0] : 0.0;
     const double lo0 = k0 ? p.tables[CW + r] : 0.0, hi0 = k0 ? p.tables[(size_t)TOFF + CW + r] : 0.0;
-    const double x0v = k0 ? p.x0[inst * nx + r] : 0.0;
+    double x0v = k0 ? p.x0[inst * nx + r] : 0.0;
     if (p.x0_mirror && k0) p.x0_mirror[inst * nx + r] = x0v;  // zero-copy tick: x0 came from host memory
     double gc0 = (FAM && k0) ? gGC[0] : 0.0, gl0 = (FAM && k0) ? gGL[0] : 0.0;
 
@@ -221,9 +237,11 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     const double cb = p.ops[2 * M + CW + r];
     // ---- families: mask rows and coefficients (layout of fam_doubles(), built on the host from the verbs' data)
     double cn[KT], ct_[KT], ty[KT];
-    double ak[MAX_LIN_ROWS], bk[MAX_LIN_ROWS], nk[MAX_LIN_ROWS];
+    // (the linear rows' coefficients live in LDS and the rows are walked by a run-time loop: unrolled over MAX_LIN_ROWS
+    // with the coefficients in registers, every slot carried eight copies of the mat-vec behind scalar branches -- the
+    // iteration's code no longer fitted the instruction cache and 48 VGPRs were pinned for rows that mostly do not exist)
     int role = 0, nl = 0;
-    double mu = 0.0;
+    double mu = 0.0, inv_mu = 0.0;
     bool famc = false, faml = false, any_cone = false, any_lin = false;
     if (FAM) {
         const double *Cn = p.fam + 4 * CW + (size_t)r * KT, *Ct = Cn + M, *Ty = Ct + M;
@@ -235,16 +253,17 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         }
         role = (int)p.fam[r];
         mu = p.fam[CW + r];
+        inv_mu = (mu != 0.0) ? 1.0 / mu : 0.0;  // (mu = 0: row in no cone)
         famc = p.fam[2 * CW + r] != 0.0;
         faml = p.fam[3 * CW + r] != 0.0;
         const double *lin_rows = p.fam + 4 * CW + 3 * M;
         nl = (int)lin_rows[0];
-#pragma unroll
-        for (int k = 0; k < MAX_LIN_ROWS; ++k) {
-            ak[k] = lin_rows[1 + (size_t)(3 * k + 0) * CW + r];
-            bk[k] = lin_rows[1 + (size_t)(3 * k + 1) * CW + r];
-            nk[k] = lin_rows[1 + (size_t)(3 * k + 2) * CW + r];
-        }
+        if (c == 0)
+            for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+                sLin[(3 * k + 0) * CW + r] = lin_rows[1 + (size_t)(3 * k + 0) * CW + r];
+                sLin[(3 * k + 1) * CW + r] = lin_rows[1 + (size_t)(3 * k + 1) * CW + r];
+                sLin[(3 * k + 2) * CW + r] = 1.0 / lin_rows[1 + (size_t)(3 * k + 2) * CW + r];  // 1 / ||a_k||^2
+            }
         any_cone = __ballot(famc) != 0ull;  // the same in every wavefront: rows repeat per group
         any_lin = __ballot(faml) != 0ull;
     }
@@ -254,21 +273,22 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         double lxv = 0.0;
         gc_new = gc_old;
         gl_new = gl_old;
+#if TINY_EXP == 1  // timing experiments only (tools/build_variants.sh): no family work at all
+        return 0.0;
+#endif
         if (any_cone) {
             const double sv = val + gc_old;
+#if TINY_EXP == 2  // ... the cone's projection math without its two mat-vecs
+            const double a2 = sv * sv, t = sv;
+#else
             const double a2 = group_matvec<CW, KT>(cn, sv * sv, 0.0);
             const double t = group_matvec<CW, KT>(ct_, sv, 0.0);
-            const double u0 = t * mu;
-            const double a = sqrt(a2);
-            double vc = sv;
-            if (role != 0) {
-                if (a <= -u0) vc = 0.0;
-                else if (a <= u0) vc = sv;
-                else {
-                    const double scale = 0.5 * (1.0 + u0 / a);
-                    vc = (role == 1) ? scale * sv : scale * (a / mu);
-                }
-            }
+#endif
+#if TINY_EXP == 3  // ... the mat-vecs without the projection math
+            const double vc = a2 + t;
+#else
+            const double vc = soc_project_element(sv, a2, t, mu, inv_mu, role);
+#endif
             const double gcn = sv - vc;
             if (famc) {
                 gc_new = gcn;
@@ -278,12 +298,11 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         if (any_lin) {
             const double s0 = val + gl_old;
             double sv = s0;
-#pragma unroll
-            for (int k = 0; k < MAX_LIN_ROWS; ++k) {
-                if (k < nl) {
-                    const double dot = group_matvec<CW, KT>(ty, ak[k] * sv, 0.0);
-                    if (dot > bk[k]) sv -= ((dot - bk[k]) / nk[k]) * ak[k];
-                }
+#pragma unroll 1
+            for (int k = 0; k < nl; ++k) {  // (uniform trip count)
+                const double a_k = sLin[(3 * k + 0) * CW + r], b_k = sLin[(3 * k + 1) * CW + r], in_k = sLin[(3 * k + 2) * CW + r];
+                const double dot = group_matvec<CW, KT>(ty, a_k * sv, 0.0);
+                sv = halfspace_project_element(sv, dot, a_k, b_k, in_k);
             }
             const double gln = s0 - sv;
             if (faml) {
@@ -294,37 +313,35 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         return lxv;
     };
     double pnref = p.tables[(size_t)3 * TOFF + r];
-    if (href) {
-        // pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81): the sum of k_build_tables, term by term in the same order
-        double acc = 0.0;
-        if (is_x) {
-#pragma unroll
-            for (int q = 0; q < CW; ++q)
-                if (q < nx) acc += xr_last[q] * pinf_row[q];
-            acc = -acc;
-        }
-        pnref = acc;
-        // mirrors (stores nobody in this launch waits for)
+    const double rho = p.rho;
+    const int ct = p.check_termination;
+    const int i_last = (T - 1) - (C - 1) * S;  // slot of the last step, in group C-1
+    __syncthreads();
+    auto apply_refs = [&]() {  // behind the barrier that follows stage_refs()
+        // the expressions of k_build_tables, on the staged copy: -(Xref .* Q) / -(Uref .* R) (admm.cpp:77-79) and
+        // pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81), the sum term by term in the same order
         double *tab = const_cast<double *>(p.tables);
 #pragma unroll
         for (int i = 0; i < SMAX; ++i) {
             const int kn = c * S + i + koff;
             if (ok[i]) {
-                if (is_x) p.dXref[r + (size_t)kn * nx] = href_val[i];
-                else p.dUref[(r - nx) + (size_t)kn * nu] = href_val[i];
-                tab[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] = lr[i];
+                const double ref = is_x ? sRef[r + kn * nx] : sRef[Xn + (r - nx) + kn * nu];
+                lr[i] = -(ref * dg_r);
+                tab[(size_t)2 * TOFF + (size_t)(kn + 1) * CW + r] = lr[i];  // mirror: the table row the other kernels read
             }
         }
-        if (k0) {
-            p.dXref[r] = x0ref;
-            tab[(size_t)2 * TOFF + (size_t)CW + r] = -(x0ref * dg_r);
+        double acc = 0.0;
+        if (is_x) {
+#pragma unroll
+            for (int q = 0; q < CW; ++q)
+                if (q < nx) acc += sRef[q + (N - 1) * nx] * p.Pinf[q + (size_t)r * nx];
+            acc = -acc;
         }
+        pnref = acc;
+        if (k0) tab[(size_t)2 * TOFF + (size_t)CW + r] = -(sRef[r] * dg_r);
         if (c == 0) tab[(size_t)3 * TOFF + r] = pnref;
-    }
-    const double rho = p.rho;
-    const int ct = p.check_termination;
-    const int i_last = (T - 1) - (C - 1) * S;  // slot of the last step, in group C-1
-    __syncthreads();
+    };
+    if (href) apply_refs();
 
     int it_done = 0, status = 11;
     bool res_valid = false, converged = false;
@@ -334,29 +351,118 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     for (int i = 0; i < SMAX; ++i) vprev[i] = v[i];
     int cur = 0;  // carry ping-pong buffer
 
-    // Carry scan over the chunks (Hillis-Steele). In: the chunk's pass-1 end value. Out: the true value ENTERING
-    // the chunk from its neighbour n = c + dir,  I_c = sum_j Pm^(j) end_(n + j*dir)  -- the scan runs on the
-    // shifted sequence (level 0 reads the neighbour's and the next neighbour's end values in one exchange), so no
-    // extra exchange is needed afterwards to fetch the neighbour's result. The rows of a level are requested
-    // before its exchange; only the state lanes hold non-zero rows, so only they load (a quarter less LDS traffic).
-    auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
-        double acc = 0.0;
-        for (int l = 0; l < Lc; ++l) {
-            double m[KS];
-#pragma unroll
-            for (int k = 0; k < KS; ++k) m[k] = 0.0;
-            if (is_x) load_row<KS>(Pm + (size_t)l * ML, r, m);
-            const int n1 = c + dir, nb = c + dir * (l == 0 ? 2 : (1 << l));
-            sY[cur * 256 + tid] = (l == 0) ? end_val : acc;
-            __syncthreads();
-            if (l == 0) acc = (n1 >= 0 && n1 < CGROUPS && is_x) ? sY[cur * 256 + n1 * 16 + r] : 0.0;
-            const double o = (nb >= 0 && nb < CGROUPS && is_x) ? sY[cur * 256 + nb * 16 + r] : 0.0;
-            acc += group_matvec<CW, KS>(m, o, 0.0);
-            cur ^= 1;
+    // Carry scan over the chunks. In: the chunk's pass-1 end value (state lanes; 0 elsewhere and in idle groups). Out:
+    // the true value ENTERING the chunk from its neighbour c + dir,  I_c = sum_{j>=1} Pm^(j-1) end_(c + j*dir).
+    // Chunk c = 4 w + j is row j of wavefront w.
+    //   A  inside the wavefront, rows only (cross-row swaps):  t_j = e_j + P1 e_(j-1);  L_j = t_j + P2 t_(j-2)
+    //      -> L_j = the prefix over the wavefront's own rows up to j (P_n = Pm^(n S), "j-1" meaning the row towards -dir)
+    //   B  the wavefront's total L_last goes to LDS; ONE barrier; Horner over the three wavefronts before it:
+    //      Cin = T_(w-3);  Cin = T_(w-2) + P4 Cin;  Cin = T_(w-1) + P4 Cin   (absent wavefronts count as zero)
+    //   C  I_j = L_(j-1) + P_j Cin for the rows behind the first; the first row's incoming value is Cin itself.
+    // The matrix rows of all three stages are requested up front, so the LDS reads overlap stage A.
+    const int wv = tid >> 6, jrow = (tid >> 4) & 3;
+    auto rows_shift1 = [&](int dir, double x) -> double {  // row j <- row j + dir (the wavefront's edge row <- 0)
+        double e, o, lo2, hi2;
+        cross_row_pair<1>(x, e, o);  // e = [r0 r0 r2 r2], o = [r1 r1 r3 r3]
+        if (dir < 0) {               // [0 r0 r1 r2]
+            cross_row_pair<0>(o, lo2, hi2);  // lo2 = [r1 r1 r1 r1]
+            return jrow == 0 ? 0.0 : (jrow == 2 ? lo2 : e);
+        } else {                     // [r1 r2 r3 0]
+            cross_row_pair<0>(e, lo2, hi2);  // hi2 = [r2 r2 r2 r2]
+            return jrow == 3 ? 0.0 : (jrow == 1 ? hi2 : o);
         }
-        return acc;
+    };
+    auto rows_shift2 = [&](int dir, double x) -> double {  // row j <- row j + 2 dir
+        double lo2, hi2;
+        cross_row_pair<0>(x, lo2, hi2);  // lo2 = [r0 r1 r0 r1], hi2 = [r2 r3 r2 r3]
+        return dir < 0 ? (jrow >= 2 ? lo2 : 0.0) : (jrow < 2 ? hi2 : 0.0);
+    };
+    auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
+        const int jr = dir < 0 ? jrow : 3 - jrow;  // rows counted from the side the carry comes from
+        // (two matrix rows live at a time: the rows of stages B and C are requested after stage A's mat-vecs, still
+        // ahead of the barrier that hides their latency -- all four up front cost 48 VGPRs and a workgroup slot per CU)
+        double L;
+        {
+            double m1[KS], m2[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) m1[k] = m2[k] = 0.0;
+            if (is_x) {
+                load_row<KS>(Pm, r, m1);
+                load_row<KS>(Pm + ML, r, m2);
+            }
+            // A
+            const double t = end_val + group_matvec<CW, KS>(m1, rows_shift1(dir, end_val), 0.0);
+            L = t + group_matvec<CW, KS>(m2, rows_shift2(dir, t), 0.0);
+        }
+        double m4[KS], mj[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) m4[k] = mj[k] = 0.0;
+        if (is_x) {
+            load_row<KS>(Pm + 3 * ML, r, m4);
+            load_row<KS>(Pm + (size_t)(jr >= 1 ? jr - 1 : 0) * ML, r, mj);
+        }
+        // B
+        if (jr == 3 && is_x) sY[cur * 256 + wv * 16 + r] = L;
+        const double Lprev = rows_shift1(dir, L);
+        __syncthreads();
+        const int v1 = wv + dir, v2 = wv + 2 * dir, v3 = wv + 3 * dir;
+        const double T1 = (v1 >= 0 && v1 < 4 && is_x) ? sY[cur * 256 + v1 * 16 + r] : 0.0;
+        const double T2 = (v2 >= 0 && v2 < 4 && is_x) ? sY[cur * 256 + v2 * 16 + r] : 0.0;
+        const double T3 = (v3 >= 0 && v3 < 4 && is_x) ? sY[cur * 256 + v3 * 16 + r] : 0.0;
+        double cin = T2 + group_matvec<CW, KS>(m4, T3, 0.0);
+        cin = T1 + group_matvec<CW, KS>(m4, cin, 0.0);
+        // C
+        const double far = Lprev + group_matvec<CW, KS>(mj, cin, 0.0);
+        cur ^= 1;
+        return is_x ? (jr == 0 ? cin : far) : 0.0;
     };
 
+    // ---- SESSION: the kernel stays resident; every pass of this loop is one closed-loop tick (one pass otherwise).
+    double expect = p.session_expect;
+    for (;;) {
+    if (session) {
+        // Poll the mailbox: lanes 0..23 fetch its three lines in one load, everybody sees them through LDS and takes
+        // the same decision. A command is complete when the stamp of every line it uses equals `expect`. The poller's
+        // clock ends the session after p.session_idle ticks without a command -- the exit every wavefront reaches
+        // even if the host process is gone.
+        const unsigned long long t_idle0 = __builtin_amdgcn_s_memrealtime();
+        const int nlines = (1 + nx + 6) / 7;
+        bool go = false, quit = false;
+        while (!go && !quit) {
+            if (tid < 24) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) sMail[24] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+            __syncthreads();
+            go = true;
+            for (int l = 0; l < nlines; ++l) go = go && (sMail[8 * l + 7] == expect);
+            quit = !go && sMail[24] != 0.0;
+            __syncthreads();  // (the next poll overwrites sMail)
+        }
+
+        const int flags = go ? (int)sMail[0] : 1;
+        if (quit || (flags & 1)) break;  // stop requested, or nobody is talking to this kernel any more
+        if (k0) {
+            const int q = 1 + r;  // payload index of x0[r]
+            x0v = sMail[8 * (q / 7) + q % 7];
+            if (p.x0_mirror) p.x0_mirror[inst * nx + r] = x0v;
+        }
+        if (flags & 2) {  // the references changed: fetch them again (tinympc_set_x_ref / _u_ref filled the pinned copies)
+            // acquire: the stamp was observed, what the host wrote before it must be too -- without the fence these plain
+            // loads can be served from L2 lines that an earlier read of the same buffer (the prologue's) left there
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            stage_refs();
+            __syncthreads();
+            apply_refs();
+        }
+
+        __syncthreads();  // sMail has been read by everyone
+        it_done = 0;
+        status = 11;
+        res_valid = false;
+        converged = false;
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) vprev[i] = v[i];
+        v0prev = v0;
+    }
     for (int it = 0; it < p.max_iter; ++it) {
         const bool check = (ct > 0) && (((it + 1) % ct) == 0);
         // ================= forward sweep =================
@@ -488,6 +594,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         }
     }
 
+
     // ---- the four residual norms of the last check, for get_stats (two-stage max: rows, then groups through LDS)
     double res_px = 0.0, res_dx = 0.0, res_pu = 0.0, res_du = 0.0;
     if (res_valid) {
@@ -554,11 +661,27 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             p.dstats[inst * 4 + 3] = res_du;
         }
     }
-    if (p.host_sol && p.host_seq != 0.0) {  // (kernel arguments: uniform) everything above is in pinned memory: raise the flag
+
+    if (p.host_sol && (session || p.host_seq != 0.0)) {  // (uniform) everything above is in pinned memory: raise the flag
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) p.host_sol[(size_t)N * nx + (size_t)(N - 1) * nu + 6] = p.host_seq;
+        // (a system-scope atomic store: a plain store may sit in the L2 until the kernel ends -- which a resident session
+        // kernel does not do)
+        if (tid == 0)
+            __hip_atomic_store(p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu + 6, session ? expect : p.host_seq, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (!session) break;
+    // The next tick warm-starts from the registers. A converged solve returns before v <- vnew (admm.cpp:181-197): its
+    // canonical slack is the previous iterate -- what the write-back above stored, and what an ordinary launch would
+    // read back.
+    if (converged) {
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) v[i] = vprev[i];
+        v0 = v0prev;
+    }
+    expect += 1.0;
+    }  // ticks
 }
 
 template <int KT, int KS, int SMAX, bool FAM>

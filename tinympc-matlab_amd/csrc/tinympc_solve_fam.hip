@@ -84,15 +84,16 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     }
     const int role = (int)p.fam[r];
     const double mu = p.fam[W + r];
+    const double inv_mu = (mu != 0.0) ? 1.0 / mu : 0.0;  // (mu = 0: row in no cone)
     const bool famc = p.fam[2 * W + r] != 0.0, faml = p.fam[3 * W + r] != 0.0;
     const double *lin = p.fam + 4 * W + (size_t)3 * W * KT;
     const int nl = (int)lin[0];
-    double ak[MAX_LIN_ROWS], bk[MAX_LIN_ROWS], nk[MAX_LIN_ROWS];
+    double ak[MAX_LIN_ROWS], bk[MAX_LIN_ROWS], ink[MAX_LIN_ROWS];  // ink = 1 / ||a_k||^2
 #pragma unroll
     for (int k = 0; k < MAX_LIN_ROWS; ++k) {
         ak[k] = lin[1 + (size_t)(3 * k + 0) * W + r];
         bk[k] = lin[1 + (size_t)(3 * k + 1) * W + r];
-        nk[k] = lin[1 + (size_t)(3 * k + 2) * W + r];
+        ink[k] = 1.0 / lin[1 + (size_t)(3 * k + 2) * W + r];
     }
     // wave-uniform switches: is either family in use at all?
     const bool any_cone = __ballot(famc) != 0ull, any_lin = __ballot(faml) != 0ull;
@@ -118,19 +119,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             const double sv = val + gc_old;                              // vcnew = x + gc (all rows of an enabled side)
             const double a2 = group_matvec<W, KT>(cn, sv * sv, 0.0);     // ||w||^2 of the row's cone
             const double t = group_matvec<W, KT>(ct, sv, 0.0);           // last entry of the row's cone
-            const double u0 = t * mu;
-            const double a = sqrt(a2);
-            double vc = sv;
-            if (role != 0) {
-                if (a <= -u0) {
-                    vc = 0.0;                                            // below the cone: project to the apex
-                } else if (a <= u0) {
-                    vc = sv;                                             // inside
-                } else {
-                    const double scale = 0.5 * (1.0 + u0 / a);
-                    vc = (role == 1) ? scale * sv : scale * (a / mu);
-                }
-            }
+            const double vc = soc_project_element(sv, a2, t, mu, inv_mu, role);
             const double gcn = sv - vc;                                  // gc + x - vcnew
             if (famc) {
                 gc_new = gcn;
@@ -144,7 +133,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             for (int k = 0; k < MAX_LIN_ROWS; ++k) {
                 if (k < nl) {                                            // wave-uniform
                     const double dot = group_matvec<W, KT>(ty, ak[k] * sv, 0.0);
-                    if (dot > bk[k]) sv -= ((dot - bk[k]) / nk[k]) * ak[k];
+                    sv = halfspace_project_element(sv, dot, ak[k], bk[k], ink[k]);
                 }
             }
             const double gln = s0 - sv;

@@ -225,6 +225,45 @@ __device__ __forceinline__ void project_element(double val, double g, double lo,
         : [val] "v"(val), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [vold] "v"(vold));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-local math of the cone / linear-inequality families (PARITY UNPINNED upstream semantics: Euclidean projection onto
+// the second-order cone ||w|| <= mu t, and onto half-spaces one after another), written for issue slots, not for the
+// textbook: the second-order-cone
+// projection needs sqrt(a2) AND u0 / sqrt(a2) -- one v_rsq_f64 seed and two coupled Goldschmidt steps give both
+// (g -> sqrt(a2) with a final residual correction, 2h -> 1/sqrt(a2)), where sqrt() followed by a division costs two
+// such sequences plus the division's scaling / fix-up instructions (~70 -> ~20 instructions per element); divisions by
+// per-lane constants (the cone's slope, ||a_k||^2) are multiplications by reciprocals computed once per launch; the
+// three-way case distinction is selects, not branches. Results differ from the literal formulas by rounding
+// only (<= 2 ulp per element; the tests assert 1e-9 over whole solves).
+// ------------------------------------------------------------------------------------------------
+// role: 0 = row in no cone (returned unchanged), 1 = norm member, 2 = the cone's last ("t") row.
+// sv: the row's own entry; a2: sum of squares of the cone's norm members; t: the cone's last entry.
+__device__ __forceinline__ double soc_project_element(double sv, double a2, double t, double mu, double inv_mu, int role) {
+    const double u0 = t * mu;
+    const double a2c = fmax(a2, 1e-300);  // a2 = 0 -> the `inside` / `apex` cases below decide, never the quotient
+    double y = __builtin_amdgcn_rsq(a2c);
+    double g = a2c * y, h = 0.5 * y;
+    double rr = fma(-g, h, 0.5);
+    g = fma(g, rr, g);
+    h = fma(h, rr, h);
+    rr = fma(-g, h, 0.5);
+    g = fma(g, rr, g);
+    h = fma(h, rr, h);
+    const double d = fma(-g, g, a2c);
+    const double a = fma(d, h, g);        // sqrt(a2)
+    const double inv_a = h + h;           // 1 / sqrt(a2)
+    const double scale = 0.5 * (1.0 + u0 * inv_a);
+    const double proj = (role == 1) ? scale * sv : scale * (a * inv_mu);
+    const bool apex = a <= -u0, inside = a <= u0;
+    const double vc = apex ? 0.0 : (inside ? sv : proj);
+    return role != 0 ? vc : sv;
+}
+// One half-space a_k' s <= b_k: sv <- sv - ((dot - b_k) / ||a_k||^2) a_k  if violated. inv_nk = 1 / ||a_k||^2.
+__device__ __forceinline__ double halfspace_project_element(double sv, double dot, double ak, double bk, double inv_nk) {
+    const double dist = (dot - bk) * inv_nk;
+    return dot > bk ? fma(-dist, ak, sv) : sv;
+}
+
 template <int W>
 __device__ __forceinline__ double group_max(double v) {
 #pragma unroll

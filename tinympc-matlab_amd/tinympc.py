@@ -323,6 +323,26 @@ class TinyMPC:
         _lib.check(self._L.tinympc_mpc_step_batch(self._h, _p(a), _p(u0)))
         return u0
 
+    # ------------------------------------------------------------------ closed-loop session (resident kernel)
+    def session_begin(self):
+        """Launch the solve kernel once and keep it resident: `session_step` then costs no kernel launch and no stream
+        synchronisation per tick (include/tinympc_hip.h). Single-instance handles."""
+        self._check_setup()
+        _lib.check(self._L.tinympc_session_begin(self._h))
+
+    def session_step(self, x0) -> np.ndarray:
+        """One tick inside a session: measured state in, warm-started solve, first controls out."""
+        self._check_setup()
+        a = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1))
+        assert a.size == self.nx
+        u0 = np.zeros(self.nu)
+        _lib.check(self._L.tinympc_session_step(self._h, _p(a), _p(u0)))
+        return u0
+
+    def session_end(self):
+        self._check_setup()
+        _lib.check(self._L.tinympc_session_end(self._h))
+
     def reset_workspace(self):
         self._check_setup()
         _lib.check(self._L.tinympc_reset_workspace(self._h))

@@ -84,3 +84,29 @@ for name, prob in (("quadrotor N=50", P.quadrotor(50)), ("rocket N=10", P.rocket
     print(f"{name:16s} tick with per-tick references: set_x0 {1e6*t[0]/n:4.1f} + set_x_ref {1e6*t[1]/n:4.1f} + set_u_ref {1e6*t[2]/n:4.1f} + solve {1e6*t[3]/n:5.1f} "
           f"+ get_solution {1e6*t[4]/n:4.1f} = {1e6*sum(t)/n:6.1f} us per tick ({iters/n:.1f} iterations/tick)")
     s.reset()
+
+# Closed-loop SESSION: the kernel stays resident (no launch, no stream synchronisation per tick); x0 goes in and the
+# solution comes back through pinned host memory. Same loop as above, tick = tinympc_session_step (+ get_solution).
+for name, prob, refs in (("cartpole N=10", P.cartpole(10, True), False), ("quadrotor N=50", P.quadrotor(50), False), ("quadrotor N=50", P.quadrotor(50), True)):
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    s.session_begin()
+    x = prob.x0.copy(); goal = np.zeros(prob.nx)
+    u0 = np.zeros(prob.nu)
+    X = np.zeros((prob.nx, prob.N), order="F"); U = np.zeros((prob.nu, prob.N - 1), order="F")
+    t = [0.0, 0.0, 0.0]; n = 300; iters = 0; total = n + 20 + prob.N
+    for k in range(n + 20):
+        xx = np.ascontiguousarray(x)
+        xref = np.asfortranarray(np.stack([prob.x0 + (goal - prob.x0) * (i + k) / (total - 1) for i in range(prob.N)], axis=1))
+        t0 = time.perf_counter()
+        if refs: L.tinympc_set_x_ref(s._h, dp(xref), prob.nx, prob.N, 0)
+        t1 = time.perf_counter(); L.tinympc_session_step(s._h, dp(xx), dp(u0))
+        t2 = time.perf_counter(); L.tinympc_get_solution(s._h, dp(X), dp(U), 0)
+        t3 = time.perf_counter()
+        if k >= 20:
+            t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2; iters += s.get_stats()["iter"]
+        x = prob.A @ x + prob.B @ u0
+    s.session_end()
+    print(f"{name:16s} SESSION tick{' with per-tick x_ref' if refs else '':20s}: set_x_ref {1e6*t[0]/n:4.1f} + session_step {1e6*t[1]/n:5.1f} + get_solution {1e6*t[2]/n:4.1f} = {1e6*sum(t)/n:6.1f} us per tick ({iters/n:.1f} iterations/tick)")
+    s.reset()
