@@ -886,6 +886,8 @@ int tinympc_session_begin(tinympc_solver *s) {
     if (!s->host_path() || !(s->layout_c || (s->families_active() && s->fam_c)))
         return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles on the latency kernel only (batch 1, nx+nu <= 16, N <= 129)");
     if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
+    if (s->families_active() && s->chunk_len > 4)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
     if (!s->h_mail) {
         HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 32, hipHostMallocCoherent));

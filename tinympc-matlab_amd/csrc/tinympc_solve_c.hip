@@ -135,7 +135,10 @@ size_t solve_c_lds_bytes_refs(int nx, int nu, int N, int Lc) {
 // FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there)
 // ride on the row-local phase: every slot carries the extra duals gc|yc, gl|yl (persistent, HBM arrays GC / GL) and
 // the extra linear-cost term lx (forward -> backward, registers).
-template <int KT, int KS, int SMAX, bool FAM>
+// SESSION: the resident closed-loop variant (p.mail != NULL), a separate instantiation so that the one-shot kernel keeps
+// its register budget (wrapped in the tick loop at run time it grew from 244 to 336 VGPRs and lost its second workgroup
+// per CU).
+template <int KT, int KS, int SMAX, bool FAM, bool SESSION>
 __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, c = tid >> 4, r = tid & 15;
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     // ONCE, fully coalesced (about a hundred 64-byte requests for the quadrotor), into LDS -- and mirrored into their
     // device copies on the way; every lane then derives its own linear-cost entries from LDS behind the prologue's
     // barrier (a first version let every lane fetch its own entries from the host: ~6 us of a 25 us tick).
-    const bool session = p.mail != nullptr;
+    constexpr bool session = SESSION;
     const bool href = p.href_x != nullptr;
     const double dg_r = (href || session) ? p.ops[2 * M + 2 * CW + r] : 0.0;
     const int Xn = nx * N, Un = nu * T;
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     // ---- SESSION: the kernel stays resident; every pass of this loop is one closed-loop tick (one pass otherwise).
     double expect = p.session_expect;
     for (;;) {
-    if (session) {
+    if constexpr (SESSION) {
         // Poll the mailbox: lanes 0..23 fetch its three lines in one load, everybody sees them through LDS and takes
         // the same decision. A command is complete when the stamp of every line it uses equals `expect`. The poller's
         // clock ends the session after p.session_idle ticks without a command -- the exit every wavefront reaches
@@ -671,7 +674,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             __hip_atomic_store(p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu + 6, session ? expect : p.host_seq, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (!session) break;
+    if constexpr (!SESSION) break;
     // The next tick warm-starts from the registers. A converged solve returns before v <- vnew (admm.cpp:181-197): its
     // canonical slack is the previous iterate -- what the write-back above stored, and what an ordinary launch would
     // read back.
@@ -684,13 +687,23 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }  // ticks
 }
 
+template <int KT, int KS, int SMAX, bool FAM, bool SESSION>
+static hipError_t launch_c_s(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
+    static size_t lds_set[16] = {0};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, KS, SMAX, FAM, SESSION>), lds_bytes, lds_set);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_admm_solve_c<KT, KS, SMAX, FAM, SESSION>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
+    return hipGetLastError();
+}
 template <int KT, int KS, int SMAX, bool FAM>
 static hipError_t launch_c_f(const SolveParams &p, size_t lds_bytes, hipStream_t stream) {
-    static size_t lds_set[16] = {0};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_admm_solve_c<KT, KS, SMAX, FAM>), lds_bytes, lds_set);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_admm_solve_c<KT, KS, SMAX, FAM>), dim3(p.batch), dim3(CTHREADS), lds_bytes, stream, p);
-    return hipGetLastError();
+    if (p.mail) {
+        // (families + more than 4 slots per lane: the resident variant would not fit the register file -- the host
+        // layer refuses such sessions; ticks of that size are far above the launch overhead a session saves anyway)
+        if constexpr (FAM && SMAX > 4) return hipErrorInvalidValue;
+        else return p.batch == 1 ? launch_c_s<KT, KS, SMAX, FAM, true>(p, lds_bytes, stream) : hipErrorInvalidValue;
+    }
+    return launch_c_s<KT, KS, SMAX, FAM, false>(p, lds_bytes, stream);
 }
 
 template <int KT, int KS>
