@@ -409,6 +409,52 @@ def main() -> int:
                                       "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
                                       "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None}
             one.reset()
+        if not args.no_single:
+            # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
+            # cross-row swaps + fused DPP chain. Synthetic stable system, box constraints, 100 forced iterations.
+            rng = np.random.default_rng(0)
+            wnx, wnu, wN, wB, wit = 24, 8, 30, 4096, 100
+            wA = np.eye(wnx) + 0.03 * rng.standard_normal((wnx, wnx))
+            wBm = 0.1 * rng.standard_normal((wnx, wnu))
+            wp = P.Problem("wide", wA, wBm, np.diag(rng.uniform(1, 10, wnx)), np.diag(rng.uniform(0.5, 2, wnu)), wN, 2.0, rng.standard_normal(wnx))
+            wide = pkg.TinyMPC()
+            wide.setup(wp.A, wp.B, wp.Q, wp.R, wp.N, batch=wB, device=local_rank, rho=wp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=wit)
+            wide.set_bound_constraints(np.full(wnx, -2.0), np.full(wnx, 2.0), np.full(wnu, -0.3), np.full(wnu, 0.3))
+            wide.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((wnx, wB))))
+            ms = []
+            for k in range(6):
+                wide.reset_workspace()
+                ms.append(wide.solve_timed())
+            med = sorted(ms[1:])[len(ms[1:]) // 2]
+            wtf = wB * wit * wp.flops_per_iteration() / (med * 1e-3) / 1e12
+            out["wide_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (wnx, wnu, wN, wB, wit),
+                                  "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
+                                  "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"]}
+            wide.reset()
+            # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
+            # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
+            tick = {}
+            for mode in ("launch", "session"):
+                tk = pkg.TinyMPC()
+                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+                tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+                if mode == "session":
+                    tk.session_begin()
+                x = prob.x0.copy()
+                t_acc, its = 0.0, 0
+                for k in range(220):
+                    t0 = time.perf_counter()
+                    u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
+                    dt = time.perf_counter() - t0
+                    if k >= 20:
+                        t_acc += dt
+                        its += int(tk.get_stats()["iter"])
+                    x = prob.A @ x + prob.B @ u0
+                if mode == "session":
+                    tk.session_end()
+                tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "iterations_per_tick": its / 200}
+                tk.reset()
+            out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]

@@ -224,6 +224,26 @@ classdef TinyMPC < handle
             [dK, dP, dC1, dC2] = tinympc_matlab('compute_sensitivity', false);
         end
 
+        % --- closed-loop session (extension): the solve kernel stays resident between ticks, so a tick costs
+        % no kernel launch and no stream synchronisation. Drop-in for the loop body
+        %   solver.set_x0(x); solver.solve(); sol = solver.get_solution(); u = sol.controls(:,1);
+        % as   u = solver.session_step(x);   between session_begin() and session_end(). get_solution / get_stats
+        % keep working inside a session; any other verb ends it.
+        function session_begin(obj)
+            obj.require_setup();
+            tinympc_matlab('session_begin');
+        end
+
+        function u0 = session_step(obj, x0)
+            obj.require_setup();
+            u0 = tinympc_matlab('session_step', double(x0(:)));
+        end
+
+        function session_end(obj)
+            obj.require_setup();
+            tinympc_matlab('session_end');
+        end
+
         function reset(obj)
             if obj.is_setup
                 tinympc_matlab('reset', false);

@@ -139,6 +139,26 @@ void verb_solve(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     plhs[0] = mxCreateDoubleScalar(0);  // the reference always returns 0 here (bindings.cpp:230)
 }
 
+// Closed-loop session (extension, include/tinympc_hip.h): the solve kernel stays resident between ticks.
+void verb_session_begin(int, mxArray *[], int, const mxArray *[]) {
+    need_solver();
+    check(tinympc_session_begin(g_handle));
+}
+
+void verb_session_step(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {  // x0 -> first controls (nu x 1)
+    need_args(nrhs, 1, "session_step");
+    need_solver();
+    if ((int)(mxGetM(prhs[0]) * mxGetN(prhs[0])) != g_nx)
+        mexErrMsgIdAndTxt("TinyMPC:SetX0Failed", "session_step: x0 has %d entries, expected %d", (int)(mxGetM(prhs[0]) * mxGetN(prhs[0])), g_nx);
+    plhs[0] = matrix_out(g_nu, 1);
+    check(tinympc_session_step(g_handle, real_doubles(prhs[0]), mxGetPr(plhs[0])));
+}
+
+void verb_session_end(int, mxArray *[], int, const mxArray *[]) {
+    need_solver();
+    check(tinympc_session_end(g_handle));
+}
+
 void verb_get_solution(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     need_args(nrhs, 1, "get_solution");
     need_solver();
@@ -283,6 +303,7 @@ const Verb kVerbs[] = {
     {"set_cone_constraints", verb_set_cone_constraints},
     {"compute_cache_terms", verb_compute_cache_terms}, {"solve_lqr", verb_solve_lqr},
     {"compute_sensitivity", verb_compute_sensitivity},
+    {"session_begin", verb_session_begin}, {"session_step", verb_session_step}, {"session_end", verb_session_end},
 };
 
 }  // namespace

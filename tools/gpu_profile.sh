@@ -20,7 +20,7 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/pmc_write_$TAG" -o w -- python3 "$R/bench.py" $WL --steps 5 > "$O/pmc_write_$TAG.log" 2>&1
 echo "write done"
 if [ -n "$2" ]; then  # SQ counters of the headline kernel (instruction mix, occupancy), one pass each
-  for C in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU; do
+  for C in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE; do
     rocprofv3 --pmc $C --kernel-trace -d "$O/pmc_sq_$TAG/$C" -o c -- python3 "$R/bench.py" $WL --steps 3 > "$O/pmc_sq_${TAG}_$C.log" 2>&1 || echo "$C failed"
   done
   echo "sq done"
