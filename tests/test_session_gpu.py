@@ -106,3 +106,38 @@ def test_session_is_ended_by_other_verbs_and_survives_idling(pkg):
     a.session_end()  # ending twice is harmless
     a.reset()
     b.reset()
+
+
+def test_receding_horizon_references_travel_as_one_column(pkg):
+    """rocket_landing_constraints.m:96-101: the reference re-sent at tick k+1 is the one of tick k moved up by one knot.
+    Inside a session the library detects that (bit for bit) and ships only the new last column with the command; the
+    result must equal the full re-read (ordinary launches on a second handle), including a tick where the reference is
+    NOT a shift, a tick where it is sent twice, and ordinary solves after the session."""
+    P = pkg.problems
+    prob = P.quadrotor(20)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
+    a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
+    goal = np.array([1.0, -0.5, 0.8, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    ref_at = lambda j: prob.x0 + (goal - prob.x0) * min(j, 60) / 60
+    uref_at = lambda j: np.full(prob.nu, 0.002 * j)
+    a.session_begin()
+    x = prob.x0.copy()
+    for k in range(14):
+        off = k if k != 7 else 30  # tick 7: a jump, not a shift
+        x_ref = np.stack([ref_at(i + off) for i in range(prob.N)], axis=1)
+        u_ref = np.stack([uref_at(i + off) for i in range(prob.N - 1)], axis=1)
+        for h in (a, b):
+            h.set_x_ref(x_ref)
+            h.set_u_ref(u_ref)
+            if k == 3:
+                h.set_x_ref(x_ref)  # sent twice: unchanged the second time
+        ua = a.session_step(x)
+        ub = b.mpc_step(x)[:, 0]
+        np.testing.assert_array_equal(ua, ub, err_msg=f"tick {k}")
+        np.testing.assert_array_equal(a.get_solution()["states"], b.get_solution()["states"])
+        assert a.get_stats()["iter"] == b.get_stats()["iter"], k
+        x = prob.A @ x + prob.B @ ua
+    a.session_end()
+    np.testing.assert_array_equal(a.mpc_step(x)[:, 0], b.mpc_step(x)[:, 0])  # device copies / tables were restaged
+    a.reset()
+    b.reset()

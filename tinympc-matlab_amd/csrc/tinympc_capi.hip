@@ -127,8 +127,13 @@ struct tinympc_solver {
     double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
     // Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks
     // from this mailbox in pinned memory (layout: SolveParams::mail).
-    double *h_mail = nullptr;          // [32]
+    double *h_mail = nullptr;          // [64]
     bool session_active = false;
+    // references re-sent inside a session that turned out to be the previous ones moved up by one knot (receding horizon):
+    // only the new last column travels, with the command (flags 4 / 8); two shifts without a step in between, or any other
+    // change, fall back to the full re-read (refs_on_host)
+    bool xref_shift = false, uref_shift = false;
+    bool session_refs_shifted = false;  // the device copies / tables lag behind the pinned references
     // ONE counter stamps session commands and flag-raising launches alike (both complete by writing their stamp into the
     // same slot of h_sol: a launch after a session must not find its number already there)
     unsigned long long session_seq = 0;  // stamp of the last session command / flag-raising launch
@@ -429,13 +434,20 @@ int launch(tinympc_solver *s, bool timed) {
 constexpr double kSessionIdleSeconds = 2.0;  // the resident kernel leaves on its own after this long without a command
 
 void write_command(tinympc_solver *s, int flags, const double *x0) {
-    // payload 0 = flags, payloads 1.. = x0; line l = [7 payload | stamp]. Payload before stamp, line by line (x86 keeps
-    // the order of stores; the compiler is kept from reordering by the fences).
+    // payload: 0 flags | x0 (nx) | new last column of x_ref (flag 4) | new last column of u_ref (flag 8); line l = [7 payload |
+    // stamp]. Payload before stamp, line by line (x86 keeps the order of stores; the fences keep the compiler from
+    // reordering them).
+    double pay[56];
+    int npay = 0;
+    pay[npay++] = (double)flags;
+    for (int i = 0; i < s->nx; ++i) pay[npay++] = x0 ? x0[i] : 0.0;
+    if (flags & 4) for (int i = 0; i < s->nx; ++i) pay[npay++] = s->h_xref[(size_t)(s->N - 1) * s->nx + i];
+    if (flags & 8) for (int i = 0; i < s->nu; ++i) pay[npay++] = s->h_uref[(size_t)(s->N - 2) * s->nu + i];
     volatile double *m = s->h_mail;
     const double stamp = (double)(++s->session_seq);
-    const int npay = 1 + s->nx, nlines = (npay + 6) / 7;
+    const int nlines = (npay + 6) / 7;
     for (int l = 0; l < nlines; ++l) {
-        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = (q == 0) ? (double)flags : (x0 ? x0[q - 1] : 0.0);
+        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = pay[q];
         std::atomic_thread_fence(std::memory_order_release);
         m[8 * l + 7] = stamp;
     }
@@ -460,6 +472,7 @@ int launch_session_kernel(tinympc_solver *s) {
     p.host_sol = s->h_sol;
     p.href_x = s->h_xref; p.href_u = s->h_uref; p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;  // (re-read on request)
     s->refs_on_host = false;  // the prologue stages them
+    s->xref_shift = s->uref_shift = false;
     p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
     p.families = fam ? 1 : 0;
     p.mail = s->h_mail;
@@ -473,6 +486,8 @@ int end_session(tinympc_solver *s) {
     if (!s->session_active) return TINYMPC_OK;
     write_command(s, 1, nullptr);  // stop
     s->session_active = false;     // (before anything that could come back here)
+    if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
+    s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TINYMPC_OK;
 }
@@ -731,8 +746,16 @@ int tinympc_set_x_ref(tinympc_solver *s, const double *Xref, int rows, int cols,
     s->xref_const = rows_constant(Xref, s->nx, s->N);
     if (s->host_path()) {  // no device call: the next launch reads the pinned copy and rebuilds the table rows itself
         if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;  // a launch in flight may be reading it
-        std::memcpy(s->h_xref, Xref, sizeof(double) * s->X());
-        s->refs_on_host = true;
+        const size_t col = sizeof(double) * s->nx;
+        if (std::memcmp(s->h_xref, Xref, col * s->N) == 0) {
+            // the same reference again (tracking loops re-send it every tick): nothing to do
+        } else if (s->session_active && !s->refs_on_host && !s->xref_shift && std::memcmp(s->h_xref + s->nx, Xref, col * (s->N - 1)) == 0) {
+            s->xref_shift = true;  // moved up by one knot: only the new last column has to travel
+            std::memcpy(s->h_xref, Xref, col * s->N);
+        } else {
+            std::memcpy(s->h_xref, Xref, col * s->N);
+            s->refs_on_host = true;
+        }
         if (verbose) printf("State reference set\n");
         return TINYMPC_OK;
     }
@@ -752,8 +775,17 @@ int tinympc_set_u_ref(tinympc_solver *s, const double *Uref, int rows, int cols,
     s->uref_const = rows_constant(Uref, s->nu, s->N - 1);
     if (s->host_path()) {
         if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
-        std::memcpy(s->h_uref, Uref, sizeof(double) * s->U());
-        s->refs_on_host = true;
+        const size_t col = sizeof(double) * s->nu;
+        if (std::memcmp(s->h_uref, Uref, col * (s->N - 1)) == 0) {
+            // unchanged
+        } else if (s->session_active && !s->refs_on_host && !s->uref_shift && s->N > 2 &&
+                   std::memcmp(s->h_uref + s->nu, Uref, col * (s->N - 2)) == 0) {
+            s->uref_shift = true;
+            std::memcpy(s->h_uref, Uref, col * (s->N - 1));
+        } else {
+            std::memcpy(s->h_uref, Uref, col * (s->N - 1));
+            s->refs_on_host = true;
+        }
         if (verbose) printf("Input reference set\n");
         return TINYMPC_OK;
     }
@@ -890,8 +922,8 @@ int tinympc_session_begin(tinympc_solver *s) {
         return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
     if (!s->h_mail) {
-        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 32, hipHostMallocCoherent));
-        std::memset(s->h_mail, 0, sizeof(double) * 32);
+        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
+        std::memset(s->h_mail, 0, sizeof(double) * 64);
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = launch_session_kernel(s))) return rc;
@@ -905,11 +937,14 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
     if (rc) return rc;
     if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
     if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
-    const int flags = s->refs_on_host ? 2 : 0;
-    s->refs_on_host = false;
+    int flags = 0;
+    if (s->refs_on_host) flags = 2;  // full re-read (covers any pending shift: the pinned copies are current)
+    else flags = (s->xref_shift ? 4 : 0) | (s->uref_shift ? 8 : 0);
+    if (flags & 12) s->session_refs_shifted = true;
+    s->refs_on_host = s->xref_shift = s->uref_shift = false;
     write_command(s, flags, x0);
     const volatile double *done = s->h_sol + s->X() + s->U() + 6;
-    const double want = (double)s->session_seq;
+    double want = (double)s->session_seq;
     const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
         if (*done == want) break;
@@ -919,10 +954,12 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
             // command that is pending. A stream error or 30 s without an answer end the session with an error.
             const hipError_t q = hipStreamQuery(s->stream);
             if (q == hipSuccess) {
-                s->session_seq -= 1;  // (launch_session_kernel waits for session_seq + 1)
-                rc = launch_session_kernel(s);
-                s->session_seq += 1;
+                // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
+                // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
+                rc = launch_session_kernel(s);  // waits for session_seq + 1
                 if (rc) { s->session_active = false; return rc; }
+                write_command(s, 0, x0);
+                want = (double)s->session_seq;
             } else if (q != hipErrorNotReady) {
                 s->session_active = false;
                 return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));

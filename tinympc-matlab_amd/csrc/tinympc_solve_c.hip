@@ -125,7 +125,7 @@ size_t chunk_table_doubles(int nx, int Lc) { return (size_t)2 * Lc * CW * chunk_
 
 size_t solve_c_lds_bytes(int nx, int Lc) {
     // carry matrices + wave totals ping-pong Y[2][256] (64 used each) + boundary q Q[256] + residual partials R[16][4]
-    return sizeof(double) * ((size_t)2 * Lc * CW * (chunk_ks(nx) + 2) + 2 * 256 + 256 + 64 + 32 + 3 * MAX_LIN_ROWS * CW);
+    return sizeof(double) * ((size_t)2 * Lc * CW * (chunk_ks(nx) + 2) + 2 * 256 + 256 + 64 + 64 + 3 * MAX_LIN_ROWS * CW);
 }
 // ... + the staged references (nx x N | nu x (N-1)) of a single-instance handle, see the kernel's prologue
 size_t solve_c_lds_bytes_refs(int nx, int nu, int N, int Lc) {
@@ -155,8 +155,8 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     double *sY = sTab + (size_t)2 * Lc * ML;  // [2][256]
     double *sQ = sY + 512;                    // [256]
     double *sR = sQ + 256;                    // [16][4]
-    double *sMail = sR + 64;                  // [32] the session mailbox as last polled (+ the poller's time-out verdict)
-    double *sLin = sMail + 32;                // [MAX_LIN_ROWS][3][16]  a_k | b_k | 1/||a_k||^2 per lane row (FAM)
+    double *sMail = sR + 64;                  // [64] the session mailbox as last polled (+ the poller's time-out verdict)
+    double *sLin = sMail + 64;                // [MAX_LIN_ROWS][3][16]  a_k | b_k | 1/||a_k||^2 per lane row (FAM)
     double *sRef = sLin + 3 * MAX_LIN_ROWS * CW;  // [nx*N | nu*(N-1)] references staged from pinned host memory (href only)
     const double *PH = sTab, *PS = PH + (size_t)Lc * ML;
     for (int i = tid; i < 2 * Lc * (int)MS; i += CTHREADS) {
@@ -381,6 +381,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         return dir < 0 ? (jrow >= 2 ? lo2 : 0.0) : (jrow < 2 ? hi2 : 0.0);
     };
     auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
+#if TINY_EXP == 4  // timing experiment: no carry scan at all
+        return end_val;
+#endif
         const int jr = dir < 0 ? jrow : 3 - jrow;  // rows counted from the side the carry comes from
         // (two matrix rows live at a time: the rows of stages B and C are requested after stage A's mat-vecs, still
         // ahead of the barrier that hides their latency -- all four up front cost 48 VGPRs and a workgroup slot per CU)
@@ -420,6 +423,32 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         return is_x ? (jr == 0 ? cin : far) : 0.0;
     };
 
+    // The ADMM state in its canonical HBM layout. `conv`: the solve converged, i.e. the reference returned before v <- vnew
+    // (admm.cpp:181-197) and the canonical slack is the previous iterate.
+    auto write_state = [&](bool conv) {
+#pragma unroll
+        for (int i = 0; i < SMAX; ++i) {
+            if (ok[i]) {
+                const int kn = c * S + i + koff;
+                gG[(size_t)kn * 64] = g[i];
+                gV[(size_t)kn * 64] = conv ? vprev[i] : v[i];
+                if (FAM) {
+                    gGC[(size_t)kn * 64] = gc[i];
+                    gGL[(size_t)kn * 64] = gl[i];
+                }
+            }
+            if (step[i] && is_u) gD[(size_t)(c * S + i) * dstride] = dd[i];
+        }
+        if (k0) {
+            gG[0] = g0;
+            gV[0] = conv ? v0prev : v0;
+            if (FAM) {
+                gGC[0] = gc0;
+                gGL[0] = gl0;
+            }
+        }
+    };
+
     // ---- SESSION: the kernel stays resident; every pass of this loop is one closed-loop tick (one pass otherwise).
     double expect = p.session_expect;
     for (;;) {
@@ -429,20 +458,25 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         // clock ends the session after p.session_idle ticks without a command -- the exit every wavefront reaches
         // even if the host process is gone.
         const unsigned long long t_idle0 = __builtin_amdgcn_s_memrealtime();
-        const int nlines = (1 + nx + 6) / 7;
+        // payload: 0 flags | 1.. x0 (nx) | new last column of x_ref (nx, flag 4) | new last column of u_ref (nu, flag 8)
         bool go = false, quit = false;
         while (!go && !quit) {
-            if (tid < 24) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (tid == 0) sMail[24] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+            if (tid < 56) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
             __syncthreads();
-            go = true;
-            for (int l = 0; l < nlines; ++l) go = go && (sMail[8 * l + 7] == expect);
-            quit = !go && sMail[24] != 0.0;
+            go = sMail[7] == expect;  // line 0 carries the flags, which say how many lines the command uses
+            const int f0 = go ? (int)sMail[0] : 0;
+            const int npay = 1 + nx + ((f0 & 4) ? nx : 0) + ((f0 & 8) ? nu : 0), nlines = (npay + 6) / 7;
+            for (int l = 1; l < nlines; ++l) go = go && (sMail[8 * l + 7] == expect);
+            quit = !go && sMail[56] != 0.0;
             __syncthreads();  // (the next poll overwrites sMail)
         }
 
         const int flags = go ? (int)sMail[0] : 1;
-        if (quit || (flags & 1)) break;  // stop requested, or nobody is talking to this kernel any more
+        if (quit || (flags & 1)) {  // stop requested, or nobody is talking to this kernel any more
+            write_state(false);     // (a converged tick already rolled its slack back, see the end of the loop)
+            break;
+        }
         if (k0) {
             const int q = 1 + r;  // payload index of x0[r]
             x0v = sMail[8 * (q / 7) + q % 7];
@@ -455,6 +489,36 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             stage_refs();
             __syncthreads();
             apply_refs();
+        } else if (flags & 12) {
+            // Receding horizon (rocket_landing_constraints.m:96-101): the new reference is the previous one moved up by one
+            // knot plus ONE new last column, which came with the command -- no 6 KB PCIe read (~5 us), just a shift of the
+            // linear-cost entries through the chunk boundaries. The host checked, bit for bit, that it IS a shift.
+            const bool mine = is_x ? (flags & 4) != 0 : (flags & 8) != 0;
+            const int qn = is_x ? 1 + nx + r : 1 + nx + ((flags & 4) ? nx : 0) + (r - nx);  // payload index of this row's new entry
+            const double fresh = row_ok ? sMail[8 * (qn / 7) + qn % 7] : 0.0;
+            double first = 0.0;
+#pragma unroll
+            for (int i = 0; i < SMAX; ++i) first = (i == 0) ? lr[i] : first;
+            sQ[tid] = first;
+            __syncthreads();
+            const double next_first = (c + 1 < CGROUPS) ? sQ[(c + 1) * 16 + r] : 0.0;
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < SMAX; ++i) {
+                    const int k = c * S + i;
+                    if (ok[i]) lr[i] = (k + 1 >= T) ? -(fresh * dg_r) : ((i + 1 < S && i + 1 < SMAX) ? lr[i + 1 < SMAX ? i + 1 : i] : next_first);
+                }
+            }
+            if (flags & 4) {  // pNref = -(Xref_{N-1}' Pinf)' from the new last column, the sum of k_build_tables
+                double acc = 0.0;
+                if (is_x) {
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+                        if (q < nx) acc += sMail[8 * ((1 + nx + q) / 7) + (1 + nx + q) % 7] * p.Pinf[q + (size_t)r * nx];
+                    acc = -acc;
+                }
+                pnref = acc;
+            }
         }
 
         __syncthreads();  // sMail has been read by everyone
@@ -472,12 +536,14 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         double out[SMAX];
         {   // pass 1: end state of the chunk from a zero incoming state (chunk 0: from x_0)
             double xt = x0v;
+#if TINY_EXP != 5  // (5: timing experiment without pass 1)
 #pragma unroll
             for (int i = 0; i < SMAX; ++i)
                 if (i < S) {
                     const double o = group_matvec<CW, KT>(mf, is_x ? xt : dd[i], cf);
                     xt = step[i] ? o : xt;
                 }
+#endif
             const double xin = carry_scan(-1, PH, (is_x && c < C) ? xt : 0.0);
             // pass 2: the real sweep, from the true state entering the chunk
             xt = (c >= 1) ? xin : x0v;
@@ -576,6 +642,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             const double pend = (c == C - 1 && is_x) ? pterm : 0.0;
             // pass 1: p at the chunk's first knot from a zero incoming p (last chunk: from p_{N-1})
             double pcur = pend;
+#if TINY_EXP != 5
 #pragma unroll
             for (int i = SMAX - 1; i >= 0; --i)
                 if (i < S) {
@@ -583,6 +650,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     const double o = group_matvec<CW, KT>(mb, is_x ? pcur : lin[i], cb);
                     pcur = step[i] ? (qk + o) : pcur;
                 }
+#endif
             const double pin = carry_scan(+1, PS, (is_x && c < C) ? pcur : 0.0);
             // pass 2: the real sweep, from the true p entering the chunk; only d_k is kept
             pcur = (c < C - 1) ? pin : pend;
@@ -612,14 +680,13 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         res_du = row_max(sR[r * 4 + 3]) * rho;
     }
 
-    // ---- write-back (state for the next solve, solution, stats)
+    // ---- write-back: solution (device + pinned host) every pass; the ADMM state for the next launch only when this
+    // kernel is about to end (a session keeps it in registers from tick to tick and stores it once, on its way out)
     if (p.max_iter > 0) {
 #pragma unroll
         for (int i = 0; i < SMAX; ++i) {
             if (ok[i]) {
                 const int k = c * S + i, kn = k + koff;
-                gG[(size_t)kn * 64] = g[i];
-                gV[(size_t)kn * 64] = converged ? vprev[i] : v[i];  // converged: the reference returns before v <- vnew
                 if (is_x) {
                     p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
                 } else {
@@ -630,23 +697,13 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     if (is_x) p.host_sol[(size_t)kn * nx + r] = v[i];
                     else p.host_sol[(size_t)N * nx + (size_t)kn * nu + (r - nx)] = v[i];
                 }
-                if (FAM) {
-                    gGC[(size_t)kn * 64] = gc[i];
-                    gGL[(size_t)kn * 64] = gl[i];
-                }
             }
-            if (step[i] && is_u) gD[(size_t)(c * S + i) * dstride] = dd[i];
         }
         if (k0) {
-            gG[0] = g0;
-            gV[0] = converged ? v0prev : v0;
             p.sol_x[(size_t)inst * N * nx + r] = v0;
             if (p.host_sol) p.host_sol[r] = v0;
-            if (FAM) {
-                gGC[0] = gc0;
-                gGL[0] = gl0;
-            }
         }
+        if constexpr (!SESSION) write_state(converged);
     }
     if (tid == 0) {
         p.istats[inst * 2 + 0] = it_done;
