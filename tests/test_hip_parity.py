@@ -461,6 +461,44 @@ def test_per_tick_references_stay_one_launch_and_match_the_device_path(pkg):
     two.reset()
 
 
+@pytest.mark.parametrize("nx,nu,N", [(24, 8, 30), (20, 4, 30)])
+def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
+    """The shapes compiled into the wide layout D (32 lanes per instance, duals in registers, two wavefronts per SIMD,
+    tinympc_solve_dw.hip) against the oracle: per-instance termination inside a wavefront, ragged batch, warm start after
+    converged and unconverged solves, forced iteration counts; and layout A on the same handle state in between."""
+    if kernel_layout not in ("A", "D"):
+        pytest.skip("wide systems run on layouts A and D")
+    P = pkg.problems
+    rng = np.random.default_rng(nx * 100 + nu)
+    A = np.eye(nx) + 0.03 * rng.standard_normal((nx, nx))
+    B = 0.1 * rng.standard_normal((nx, nu))
+    prob = P.Problem("wide", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+    prob.u_min, prob.u_max = np.full(nu, -0.3), np.full(nu, 0.3)
+    prob.x_min, prob.x_max = np.full(nx, -2.0), np.full(nx, 2.0)
+    prob.x_ref = np.tile(0.1 * rng.standard_normal((nx, 1)), (1, N))   # time-invariant: layout D applies
+    prob.u_ref = np.tile(0.05 * rng.standard_normal((nu, 1)), (1, N - 1))
+    batch = 7
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.05, 1.5, batch)[None, :]
+    for settings in (dict(max_iter=150, abs_pri_tol=1e-3, abs_dua_tol=1e-3), dict(max_iter=40, abs_pri_tol=0.0, abs_dua_tol=0.0),
+                     dict(max_iter=90, abs_pri_tol=1e-4, abs_dua_tol=1e-4, check_termination=3)):
+        s = make_solver(pkg, prob, settings, batch=batch)
+        assert s.launch_info()["layout"] == kernel_layout and s.launch_info()["lanes_per_instance"] == 32
+        orc = [O.OraclePort(prob).load_problem(prob, settings) for _ in range(batch)]
+        for rnd in range(3):  # cold start, then two warm starts from perturbed states
+            xs = x0s * (1.0 - 0.3 * rnd)
+            s.set_x0_batch(xs)
+            s.solve()
+            sol, st = s.get_solution_batch(), s.get_stats_batch()
+            for b in range(batch):
+                orc[b].set_x0(xs[:, b])
+                orc[b].solve()
+                assert st["iter"][b] == orc[b].stats()["iter"], (rnd, b)
+                assert st["status"][b] == orc[b].stats()["status"]
+                assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL
+                assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL
+        s.reset()
+
+
 @pytest.mark.parametrize("batch", [1, 6, 300])
 def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a
