@@ -461,10 +461,10 @@ def test_per_tick_references_stay_one_launch_and_match_the_device_path(pkg):
     two.reset()
 
 
-@pytest.mark.parametrize("nx,nu,N", [(24, 8, 30), (20, 4, 30)])
+@pytest.mark.parametrize("nx,nu,N", [(24, 8, 30), (20, 4, 30), (48, 16, 20), (40, 8, 20)])
 def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
-    """The shapes compiled into the wide layout D (32 lanes per instance, duals in registers, two wavefronts per SIMD,
-    tinympc_solve_dw.hip) against the oracle: per-instance termination inside a wavefront, ragged batch, warm start after
+    """The shapes compiled into the wide forms of layout D (32 / 64 lanes per instance, duals in registers, two wavefronts
+    per SIMD, tinympc_solve_dw.hip / tinympc_solve_dx.hip) against the oracle: per-instance termination inside a wavefront, ragged batch, warm start after
     converged and unconverged solves, forced iteration counts; and layout A on the same handle state in between."""
     if kernel_layout not in ("A", "D"):
         pytest.skip("wide systems run on layouts A and D")
@@ -482,7 +482,7 @@ def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
     for settings in (dict(max_iter=150, abs_pri_tol=1e-3, abs_dua_tol=1e-3), dict(max_iter=40, abs_pri_tol=0.0, abs_dua_tol=0.0),
                      dict(max_iter=90, abs_pri_tol=1e-4, abs_dua_tol=1e-4, check_termination=3)):
         s = make_solver(pkg, prob, settings, batch=batch)
-        assert s.launch_info()["layout"] == kernel_layout and s.launch_info()["lanes_per_instance"] == 32
+        assert s.launch_info()["layout"] == kernel_layout and s.launch_info()["lanes_per_instance"] == (32 if nx + nu <= 32 else 64)
         orc = [O.OraclePort(prob).load_problem(prob, settings) for _ in range(batch)]
         for rnd in range(3):  # cold start, then two warm starts from perturbed states
             xs = x0s * (1.0 - 0.3 * rnd)

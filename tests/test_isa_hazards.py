@@ -17,7 +17,7 @@ from tools.isa_lint import lint as _lint
 
 CSRC = os.path.join(ROOT, "tinympc-matlab_amd", "csrc")
 SOURCES = ["tinympc_solve.hip", "tinympc_solve_b.hip", "tinympc_solve_c.hip", "tinympc_solve_fam.hip", "tinympc_solve_adapt.hip",
-           "tinympc_solve_d.hip", "tinympc_solve_dw.hip"]
+           "tinympc_solve_d.hip", "tinympc_solve_dw.hip", "tinympc_solve_dx.hip"]
 
 
 def test_lint_catches_a_planted_hazard():

@@ -416,7 +416,7 @@ int launch(tinympc_solver *s, bool timed) {
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
     } else if (s->use_layout_d()) {
-        HIP_TRY(s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
+        HIP_TRY(s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
     } else if (s->layout_c) {
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         arm_completion_flag(s, p);
@@ -623,7 +623,8 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         s->layout_c = want_c;
         // Layout D: default above the latency kernel's range for the shapes compiled in; TINYMPC_LAYOUT=D forces it at
         // any batch size (tests), =A / =B / =C exclude it.
-        const bool d_possible = (W == 16 && solve_d_supported(nx, nu, N, true)) || (W == 32 && solve_dw_supported(nx, nu, N, true));
+        const bool d_possible = (W == 16 && solve_d_supported(nx, nu, N, true)) || (W == 32 && solve_dw_supported(nx, nu, N, true)) ||
+                                (W == 64 && solve_dx_supported(nx, nu, N, true));
         bool want_d = d_possible && !want_c;
         if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = d_possible && (env[0] == 'D' || env[0] == 'd');
         s->layout_d = want_d;
