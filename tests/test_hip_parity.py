@@ -74,7 +74,16 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     s.reset()
     s = make_solver(pkg, P.quadrotor(40), {}, batch=2048)
     info = s.launch_info()
-    assert info["layout"] == "B" and info["workgroups"] == 128 and info["lds_bytes"] <= 160 * 1024  # other horizons: B where it fits
+    assert info["layout"] == "D" and info["workgroups"] == 64  # other shapes that fit the plan: layout D specialised at run time
+    s.reset()
+    monkeypatch.setenv("TINYMPC_JIT", "0")
+    s = make_solver(pkg, P.quadrotor(40), {}, batch=2048)
+    info = s.launch_info()
+    assert info["layout"] == "B" and info["workgroups"] == 128 and info["lds_bytes"] <= 160 * 1024  # without it: B where it fits
+    s.reset()
+    monkeypatch.delenv("TINYMPC_JIT")
+    s = make_solver(pkg, P.cartpole(120, True), {}, batch=2048)
+    assert s.launch_info()["layout"] in ("A", "B")  # N = 120 does not fit the register plan of layout D
     s.reset()
     monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})
@@ -497,6 +506,48 @@ def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
                 assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL
                 assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL
         s.reset()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 20), (12, 4, 30), (6, 3, 25), (20, 6, 15), (30, 10, 9)])
+def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, N):
+    """Shapes that are NOT compiled into the library get layout D through hiprtc (tinympc_jit.hip): default for large
+    batches, same results as the oracle, TINYMPC_JIT=0 falls back to layout B / A."""
+    if kernel_layout != "D":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT")  # the library's own choice
+    P = pkg.problems
+    rng = np.random.default_rng(nx * 1000 + N)
+    if (nx, nu) == (12, 4):
+        prob = P.quadrotor(N)
+    else:
+        A = np.eye(nx) + 0.03 * rng.standard_normal((nx, nx))
+        B = 0.1 * rng.standard_normal((nx, nu))
+        prob = P.Problem("jit", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+        prob.u_min, prob.u_max = np.full(nu, -0.3), np.full(nu, 0.3)
+        prob.x_min, prob.x_max = np.full(nx, -2.0), np.full(nx, 2.0)
+    settings = dict(max_iter=120, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    batch = 1500
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.02, 1.0, batch)[None, :]
+    s = make_solver(pkg, prob, settings, batch=batch)
+    assert s.launch_info()["layout"] == "D"
+    s.set_x0_batch(x0s)
+    s.solve()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    sample = [0, 1, 2, 3, 700, 1498, 1499]
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, oit, ost, _ = orc.solve_batch(x0s[:, sample])
+    np.testing.assert_array_equal(st["iter"][sample], oit)
+    np.testing.assert_array_equal(st["status"][sample], ost)
+    assert rel_err(sol["states"][:, :, sample], ox) < TOL and rel_err(sol["controls"][:, :, sample], ou) < TOL
+    s.reset()
+    monkeypatch.setenv("TINYMPC_JIT", "0")
+    s = make_solver(pkg, prob, settings, batch=batch)
+    assert s.launch_info()["layout"] in ("A", "B")
+    s.set_x0_batch(x0s)
+    s.solve()
+    np.testing.assert_array_equal(s.get_stats_batch()["iter"], st["iter"])  # every instance, both kernels
+    assert rel_err(s.get_solution_batch()["controls"], sol["controls"]) < TOL
+    s.reset()
 
 
 @pytest.mark.parametrize("batch", [1, 6, 300])

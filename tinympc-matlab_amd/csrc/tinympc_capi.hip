@@ -104,6 +104,7 @@ struct tinympc_solver {
     // batches of a shape that is compiled in; each launch still checks that bounds / references are time-invariant and
     // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
     bool layout_d = false;
+    bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
     bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
@@ -416,7 +417,8 @@ int launch(tinympc_solver *s, bool timed) {
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
     } else if (s->use_layout_d()) {
-        HIP_TRY(s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
+        HIP_TRY(s->d_jit ? launch_solve_jit(p, s->W, s->stream)
+                         : s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
     } else if (s->layout_c) {
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         arm_completion_flag(s, p);
@@ -621,12 +623,20 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
             else if (env[0] == 'A' || env[0] == 'a' || env[0] == 'B' || env[0] == 'b' || env[0] == 'D' || env[0] == 'd') want_c = false;
         }
         s->layout_c = want_c;
-        // Layout D: default above the latency kernel's range for the shapes compiled in; TINYMPC_LAYOUT=D forces it at
-        // any batch size (tests), =A / =B / =C exclude it.
-        const bool d_possible = (W == 16 && solve_d_supported(nx, nu, N, true)) || (W == 32 && solve_dw_supported(nx, nu, N, true)) ||
+        // Layout D (compile-time shape, duals in registers, two wavefronts per SIMD): default above the latency kernel's
+        // range -- for wide systems, which have no latency kernel, from 16 instances up --; TINYMPC_LAYOUT=D forces it at any
+        // batch size (tests), =A / =B / =C exclude it. The shapes compiled into the library run as they are; every other
+        // shape that fits the plan is specialised at run time (tinympc_jit.hip: hiprtc, cached), now, so that a failure
+        // simply leaves the handle on layout B / A.
+        const bool d_compiled = (W == 16 && solve_d_supported(nx, nu, N, true)) || (W == 32 && solve_dw_supported(nx, nu, N, true)) ||
                                 (W == 64 && solve_dx_supported(nx, nu, N, true));
-        bool want_d = d_possible && !want_c;
-        if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = d_possible && (env[0] == 'D' || env[0] == 'd');
+        bool want_d = (W == 16) ? !want_c : batch >= 16;
+        if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = (env[0] == 'D' || env[0] == 'd');
+        if (want_d && !d_compiled) {
+            HIP_TRY_S(hipSetDevice(s->device));
+            s->d_jit = solve_jit_supported(W, nx, nu, N, true);
+            want_d = s->d_jit;
+        }
         s->layout_d = want_d;
         if (want_d) s->layout_c = false;
         // The families: k_admm_solve_fam keeps the whole ADMM state in LDS (layout A), so a long horizon leaves it

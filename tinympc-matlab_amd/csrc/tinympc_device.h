@@ -7,7 +7,9 @@
 // reference (TinyWorkspace, types.hpp:79-136) that is indexed [row, knot] therefore becomes
 // [knot][lane]: one 512-byte line per knot per wavefront, in LDS and in HBM alike.
 #pragma once
+#ifndef __HIPCC_RTC__  // (run-time compilation, tinympc_jit.hip: hiprtc brings its own runtime header)
 #include <hip/hip_runtime.h>
+#endif
 
 namespace tinympc {
 
@@ -180,6 +182,7 @@ struct AdaptTableParams {
 constexpr int MAX_LIN_ROWS = 8;
 __host__ __device__ inline size_t fam_doubles(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
 
+#ifndef __HIPCC_RTC__  // host side only
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
@@ -234,14 +237,22 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cach
     return e;
 }
 
+// Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
+// hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
+bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables);
+hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream);
+#endif  // !__HIPCC_RTC__
+
 // Doubles of working state per group in layout A (G and V with N+2 rows, D with 64 dummy slots).
 __host__ __device__ inline size_t state_scratch_doubles(int nu, int N, int W) {
     return (size_t)2 * (N + 2) * 64 + ((((size_t)(N - 1) * (64 / W) * nu + 64) + 1) & ~(size_t)1);
 }
 
+#ifndef __HIPCC_RTC__
 // Geometry helpers shared with the host layer.
 bool choose_geometry(int nx, int nu, int *W, int *KT);
 size_t solve_lds_bytes(int nx, int nu, int N, int W, bool tables_in_lds);
 size_t precompute_scratch_doubles(int nx, int nu);
+#endif
 
 }  // namespace tinympc

@@ -39,12 +39,18 @@ struct DStep;  // specialised per (nx, nu) by tinympc_solve_d_chain.h
 }  // namespace tinympc
 
 // The (nx, nu) pairs compiled into the library: quadrotor, cartpole, rocket landing (BASELINE.json configs 2-5).
+#ifdef TINY_JIT  // run-time specialisation (tinympc_jit.hip): exactly one (nx, nu, N), from -D options
+#define D_NX TINY_JIT_NX
+#define D_NU TINY_JIT_NU
+#include "tinympc_solve_d_chain.h"
+#else
 #define D_NX 12
 #define D_NU 4
 #include "tinympc_solve_d_chain.h"
 #define D_NX 4
 #define D_NU 1
 #include "tinympc_solve_d_chain.h"
+#endif
 
 namespace tinympc {
 
@@ -59,7 +65,11 @@ __device__ __forceinline__ void static_for(F &&f) {
 // ---- LDS plan per workgroup, in doubles: operators [2][16 k][16 r] | tables (!CT) | per wave: V[VL][64], D[(N-1)*4*nu]
 constexpr int D_OPS_DOUBLES = 2 * 16 * 16;
 constexpr int D_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
-constexpr int D_VREG_MAX = 24;    // slack knots kept in registers (the rest goes to LDS)
+#ifdef TINY_JIT_VREG
+constexpr int D_VREG_MAX = TINY_JIT_VREG;  // chosen by the host from its register estimate
+#else
+constexpr int D_VREG_MAX = 24;
+#endif    // slack knots kept in registers (the rest goes to LDS)
 constexpr int D_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int d_d_doubles(int nu, int N) { return ((N - 1) * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int d_tab_doubles(int N) { return 3 * (N + 2) * 16 + 16; }
@@ -122,8 +132,7 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 }
 
 template <int NX, int NU, int N, bool CT, int WPG, int VL>
-__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
     constexpr int TOFF = (N + 2) * W;
@@ -418,6 +427,25 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+#ifndef TINY_JIT
+template <int NX, int NU, int N, bool CT, int WPG, int VL>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL>(p, smem);
+}
+#endif
+
+#ifdef TINY_JIT
+}  // namespace tinympc
+// The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
+extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, true, 8);
+    static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, true, 8, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, true, 8, VLJ>(p, smem_jit);
+}
+namespace tinympc {
+#else
 // ------------------------------------------------------------------------------------------------------------
 // Host side: the instantiation table. A shape runs on layout D only if it was compiled in.
 // ------------------------------------------------------------------------------------------------------------
@@ -464,5 +492,7 @@ hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
 }
 
 int solve_d_workgroups(int groups) { return (groups + D_WPG - 1) / D_WPG; }
+
+#endif  // TINY_JIT
 
 }  // namespace tinympc

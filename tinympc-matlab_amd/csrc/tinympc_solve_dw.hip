@@ -20,12 +20,18 @@ struct DWStep;  // specialised per (nx, nu) by tinympc_solve_dw_chain.h
 }  // namespace tinympc
 
 // The (nx, nu) pairs compiled into the library (see TINY_DW_SHAPES below).
+#ifdef TINY_JIT  // run-time specialisation (tinympc_jit.hip): exactly one (nx, nu, N), from -D options
+#define DW_NX TINY_JIT_NX
+#define DW_NU TINY_JIT_NU
+#include "tinympc_solve_dw_chain.h"
+#else
 #define DW_NX 24
 #define DW_NU 8
 #include "tinympc_solve_dw_chain.h"
 #define DW_NX 20
 #define DW_NU 4
 #include "tinympc_solve_dw_chain.h"
+#endif
 
 namespace tinympc {
 
@@ -41,7 +47,11 @@ __device__ __forceinline__ void static_for_w(F &&f) {
 // ---- LDS plan per workgroup, in doubles: operators [2][32 k][32 r] | per wave: V[VL][64], D[(N-1)*2*nu]
 constexpr int DW_OPS_DOUBLES = 2 * 32 * 32;
 constexpr int DW_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
-constexpr int DW_VREG_MAX = 20;    // slack knots kept in registers (the rest goes to LDS)
+#ifdef TINY_JIT_VREG
+constexpr int DW_VREG_MAX = TINY_JIT_VREG;  // chosen by the host from its register estimate
+#else
+constexpr int DW_VREG_MAX = 20;
+#endif    // slack knots kept in registers (the rest goes to LDS)
 constexpr int DW_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int dw_d_doubles(int nu, int N) { return ((N - 1) * 2 * nu + 1) & ~1; }
 // number of slack slots in LDS; -1 if the shape does not fit the plan (8 waves per CU)
@@ -99,8 +109,7 @@ __device__ __forceinline__ bool wave_may_converge_w(unsigned long long bad, unsi
 }  // namespace
 
 template <int NX, int NU, int N, int WPG, int VL>
-__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_dw(const SolveParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void k_admm_solve_dw_body(const SolveParams &p, double *smem) {
     constexpr int W = 32, IPW = 2, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr bool CT = true;  // time-invariant bounds / references only
     constexpr int KT = 32;  // row stride of p.ops (choose_geometry)
@@ -403,6 +412,25 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+#ifndef TINY_JIT
+template <int NX, int NU, int N, int WPG, int VL>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_dw(const SolveParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    k_admm_solve_dw_body<NX, NU, N, WPG, VL>(p, smem);
+}
+#endif
+
+#ifdef TINY_JIT
+}  // namespace tinympc
+// The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
+extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr int VLJ = tinympc::dw_vl(TINY_JIT_NU, TINY_JIT_N, 8);
+    static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dw_lds_bytes(TINY_JIT_NU, TINY_JIT_N, 8, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_dw_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, 8, VLJ>(p, smem_jit);
+}
+namespace tinympc {
+#else
 // ------------------------------------------------------------------------------------------------------------
 // Host side: the instantiation table. A shape runs on the wide layout D only if it was compiled in.
 // ------------------------------------------------------------------------------------------------------------
@@ -446,5 +474,7 @@ hipError_t launch_solve_dw(const SolveParams &p, hipStream_t stream) {
 #undef X
     return hipErrorInvalidValue;
 }
+
+#endif  // TINY_JIT
 
 }  // namespace tinympc

@@ -13,12 +13,18 @@ template <int NX, int NU>
 struct DXStep;  // specialised per (nx, nu) by tinympc_solve_dx_chain.h
 }  // namespace tinympc
 
+#ifdef TINY_JIT  // run-time specialisation (tinympc_jit.hip): exactly one (nx, nu, N), from -D options
+#define DX_NX TINY_JIT_NX
+#define DX_NU TINY_JIT_NU
+#include "tinympc_solve_dx_chain.h"
+#else
 #define DX_NX 48
 #define DX_NU 16
 #include "tinympc_solve_dx_chain.h"
 #define DX_NX 40
 #define DX_NU 8
 #include "tinympc_solve_dx_chain.h"
+#endif
 
 namespace tinympc {
 
@@ -42,7 +48,11 @@ __device__ __forceinline__ void replicate_rows(double w, double &r0, double &r1,
 // ---- LDS plan per workgroup, in doubles: operators [2][64 k][64 r] | per wave: V[VL][64], D[(N-1)*nu]
 constexpr int DX_OPS_DOUBLES = 2 * 64 * 64;
 constexpr int DW_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
-constexpr int DX_VREG_MAX = 12;    // slack knots kept in registers (the rest goes to LDS)
+#ifdef TINY_JIT_VREG
+constexpr int DX_VREG_MAX = TINY_JIT_VREG;  // chosen by the host from its register estimate
+#else
+constexpr int DX_VREG_MAX = 12;
+#endif    // slack knots kept in registers (the rest goes to LDS)
 constexpr int DX_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int dx_d_doubles(int nu, int N) { return ((N - 1) * nu + 1) & ~1; }
 __host__ __device__ constexpr int dx_vl(int nu, int N, int wpg) {
@@ -87,8 +97,7 @@ __device__ __forceinline__ void lds_wait_w() { asm volatile("s_waitcnt lgkmcnt(0
 }  // namespace
 
 template <int NX, int NU, int N, int WPG, int VL>
-__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_dx(const SolveParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, double *smem) {
     constexpr int W = 64, IPW = 1, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr bool CT = true;  // time-invariant bounds / references only
     constexpr int KT = 64;  // row stride of p.ops (choose_geometry)
@@ -397,6 +406,25 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+#ifndef TINY_JIT
+template <int NX, int NU, int N, int WPG, int VL>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_dx(const SolveParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    k_admm_solve_dx_body<NX, NU, N, WPG, VL>(p, smem);
+}
+#endif
+
+#ifdef TINY_JIT
+}  // namespace tinympc
+// The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
+extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, 8);
+    static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, 8, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, 8, VLJ>(p, smem_jit);
+}
+namespace tinympc {
+#else
 // ------------------------------------------------------------------------------------------------------------
 // Host side: the instantiation table.
 // ------------------------------------------------------------------------------------------------------------
@@ -440,5 +468,7 @@ hipError_t launch_solve_dx(const SolveParams &p, hipStream_t stream) {
 #undef X
     return hipErrorInvalidValue;
 }
+
+#endif  // TINY_JIT
 
 }  // namespace tinympc

@@ -2,7 +2,9 @@
 // layout B: tinympc_solve_b.hip): the fused DPP mat-vec chain, the row-local projection block, and the
 // group-wide max reduction.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include "tinympc_device.h"
 

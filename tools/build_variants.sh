@@ -10,6 +10,6 @@ mkdir -p tools/bin
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   C="${SRC:-tinympc-matlab_amd/csrc}"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -w -Iinclude -I$C $flags $C/*.hip -o tools/bin/libtinympc_hip_$name.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -w -Iinclude -I$C $flags $C/*.hip -lhiprtc -o tools/bin/libtinympc_hip_$name.so
   echo "built tools/bin/libtinympc_hip_$name.so ($flags)"
 done
