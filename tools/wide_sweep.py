@@ -29,8 +29,11 @@ def system(nx, nu, N, seed=0):
     return prob
 
 
-print(f"# library: {os.environ.get('TINYMPC_HIP_LIBRARY', 'tinympc-matlab_amd/libtinympc_hip.so')}; {ITERS} forced iterations per solve")
-for nx, nu, N, batch in ((12, 4, 50, 4096), (20, 4, 30, 4096), (24, 8, 30, 4096), (24, 8, 30, 16384), (40, 8, 20, 4096), (48, 16, 20, 2048), (48, 16, 20, 8192)):
+print(f"# library: {os.environ.get('TINYMPC_HIP_LIBRARY', 'tinympc-matlab_amd/libtinympc_hip.so')}; {ITERS} forced iterations per solve; "
+      f"TINYMPC_JIT={os.environ.get('TINYMPC_JIT', '1')} TINYMPC_LAYOUT={os.environ.get('TINYMPC_LAYOUT', '-')}")
+print("# (12,4,50) (20,4,30) (24,8,30) (40,8,20) (48,16,20) are compiled into the library; the other shapes are specialised at run time")
+for nx, nu, N, batch in ((12, 4, 50, 4096), (12, 4, 20, 8192), (20, 4, 30, 4096), (24, 8, 30, 4096), (24, 8, 30, 16384), (28, 4, 24, 4096), (40, 8, 20, 4096),
+                         (48, 16, 20, 2048), (48, 16, 20, 8192), (36, 12, 16, 4096)):
     prob = system(nx, nu, N)
     rng = np.random.default_rng(1)
     x0s = np.asfortranarray(rng.standard_normal((nx, batch)))
