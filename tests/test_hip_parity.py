@@ -550,6 +550,41 @@ def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, 
     s.reset()
 
 
+@pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25"])
+def test_layout_d_with_bounds_and_references_that_vary_over_the_horizon(pkg, kernel_layout, monkeypatch, shape):
+    """Layout D reads per-knot bounds / references from the workgroup's LDS copy of the tables (16-lane form; the
+    compiled-in cartpole shape and a run-time specialised one): large batch, library's own layout choice."""
+    if kernel_layout != "D":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    P = pkg.problems
+    prob = P.cartpole(20, True) if shape == "cartpole20" else P.quadrotor(25)
+    rng = np.random.default_rng(5)
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    xlim, ulim = (2.0, 0.5) if shape == "cartpole20" else (5.0, 0.5)
+    prob.x_min = -xlim - rng.uniform(0, 0.5, (nx, N))
+    prob.x_max = xlim + rng.uniform(0, 0.5, (nx, N))
+    prob.u_min = -ulim * rng.uniform(0.6, 1.0, (nu, N - 1))
+    prob.u_max = ulim * rng.uniform(0.6, 1.0, (nu, N - 1))
+    prob.x_ref = 0.05 * rng.standard_normal((nx, N))
+    prob.u_ref = 0.02 * rng.standard_normal((nu, N - 1))
+    settings = dict(max_iter=150, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    batch = 1300
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.02, 0.6, batch)[None, :]
+    s = make_solver(pkg, prob, settings, batch=batch)
+    s.set_x0_batch(x0s)
+    s.solve()
+    assert s.launch_info()["layout"] == "D"
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    sample = [0, 1, 2, 3, 650, 1298, 1299]
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, oit, ost, _ = orc.solve_batch(x0s[:, sample])
+    np.testing.assert_array_equal(st["iter"][sample], oit)
+    np.testing.assert_array_equal(st["status"][sample], ost)
+    assert rel_err(sol["states"][:, :, sample], ox) < TOL and rel_err(sol["controls"][:, :, sample], ou) < TOL
+    s.reset()
+
+
 @pytest.mark.parametrize("batch", [1, 6, 300])
 def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     """tinympc_mpc_step_batch == set_x0_batch + solve + get_first_controls_batch, bit for bit, over a

@@ -105,6 +105,7 @@ struct tinympc_solver {
     // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
     bool layout_d = false;
     bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
+    int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
     bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
@@ -154,7 +155,7 @@ struct tinympc_solver {
     bool tables_in_lds_a = false;
 
     bool use_layout_d() const {
-        return layout_d && tables_const() && !families_active() && !st.adaptive_rho;
+        return layout_d && (tables_const() || d_varying == 1) && !families_active() && !st.adaptive_rho;
     }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
@@ -349,6 +350,11 @@ void arm_completion_flag(tinympc_solver *s, SolveParams &p) {
 int launch(tinympc_solver *s, bool timed) {
     int rc;
     s->flag_pending = false;
+    if (s->layout_d && s->d_varying < 0 && !s->tables_const()) {
+        // first launch with time-varying tables on a layout-D handle: is there a kernel for that (16-lane form: compiled
+        // in or specialised now)? Otherwise these launches run on layout B / A, as before.
+        s->d_varying = (s->W == 16 && (s->d_jit ? solve_jit_supported(s->W, s->nx, s->nu, s->N, false) : solve_d_supported(s->nx, s->nu, s->N, false))) ? 1 : 0;
+    }
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
     if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts

@@ -43,7 +43,7 @@ struct JitPlan {
 //   VGPRs  2*(N-1) for the duals + 2*vreg for the register part of the slack + the operator row + ~76 for everything else
 //          must stay <= 256 (two wavefronts per SIMD);
 //   LDS    per wave (N-1-vreg) slack rows of 512 B + the feed-forward d, eight waves + the operators <= 160 KB.
-JitPlan plan_for(int W, int nx, int nu, int N) {
+JitPlan plan_for(int W, int nx, int nu, int N, bool ct) {
     JitPlan pl;
     const int nxu = nx + nu, ns = N - 1;
     if (N < 4 || nx < 1 || nu < 1) return pl;
@@ -52,11 +52,13 @@ JitPlan plan_for(int W, int nx, int nu, int N) {
     else if (W == 32 && nxu > 16 && nxu <= 32) { mregs = 64; ops_doubles = 2 * 32 * 32; d_doubles = ((ns * 2 * nu) + 1) & ~1; pl.source = "tinympc_solve_dw.hip"; }
     else if (W == 64 && nxu > 32 && nxu <= 64) { mregs = 128; ops_doubles = 2 * 64 * 64; d_doubles = ((ns * nu) + 1) & ~1; pl.source = "tinympc_solve_dx.hip"; }
     else return pl;
-    const int budget = 256 - 76 - mregs - 2 * ns;
+    if (!ct && W != 16) return pl;  // bounds / references that vary over the horizon: 16-lane form only
+    const int tab_doubles = ct ? 0 : 3 * (N + 2) * 16 + 16;  // the workgroup's LDS copy of the per-knot tables
+    const int budget = 256 - 76 - (ct ? 0 : 8) - mregs - 2 * ns;
     if (budget < 0) return pl;
     int vreg = budget / 2;
     if (vreg > ns) vreg = ns;
-    const int wave_doubles = (160 * 1024 / 8 - ops_doubles) / 8 - d_doubles;
+    const int wave_doubles = (160 * 1024 / 8 - ops_doubles - tab_doubles) / 8 - d_doubles;
     if (wave_doubles < 0) return pl;
     const int vlmax = wave_doubles / 64;
     if (ns - vreg > vlmax) return pl;  // the LDS part of the slack does not fit
@@ -120,7 +122,7 @@ struct JitKernel {
     hipFunction_t fn = nullptr;
     bool failed = false;
 };
-using Key = std::tuple<int, int, int, int, int>;  // device, W, nx, nu, N
+using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables
 std::map<Key, JitKernel> &cache() {
     static std::map<Key, JitKernel> c;
     return c;
@@ -131,7 +133,7 @@ std::mutex &cache_mutex() {
 }
 
 // Compile (or fetch from the disk cache) the code object of one shape. Empty on failure; `why` says why.
-std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, const std::string &arch, std::string &why) {
+std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, const std::string &arch, std::string &why) {
     const std::string sdir = source_dir(), idir = include_dir();
     const std::string spath = sdir + "/" + pl.source;
     if (!file_exists(spath) || !file_exists(sdir + "/tinympc_device.h")) {
@@ -144,7 +146,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, co
     for (const char *dep : {"tinympc_device.h", "tinympc_sweep.h", "tinympc_solve_d_chain.h", "tinympc_solve_dw_chain.h", "tinympc_solve_dx_chain.h"})
         h = fnv1a(read_file(sdir + "/" + dep), h);
     char shape[160];
-    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d %s", pl.source, nx, nu, N, pl.vreg, arch.c_str());
+    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d ct=%d %s", pl.source, nx, nu, N, pl.vreg, (int)ct, arch.c_str());
     h = fnv1a(shape, h);
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
@@ -160,7 +162,8 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, co
     }
     std::vector<std::string> o = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-I" + sdir, "-I" + idir, "-DTINY_JIT=1",
                                   "-DTINY_JIT_NX=" + std::to_string(nx), "-DTINY_JIT_NU=" + std::to_string(nu),
-                                  "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg)};
+                                  "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg),
+                                  std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0")};
     std::vector<const char *> opts;
     for (const auto &x : o) opts.push_back(x.c_str());
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -197,15 +200,15 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, co
     return code;
 }
 
-JitKernel *get_kernel(int W, int nx, int nu, int N) {
+JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(cache_mutex());
-    const Key key{dev, W, nx, nu, N};
+    const Key key{dev, W, nx, nu, N, (int)ct};
     auto it = cache().find(key);
     if (it != cache().end()) return it->second.failed ? nullptr : &it->second;
     JitKernel k;
-    const JitPlan pl = plan_for(W, nx, nu, N);
+    const JitPlan pl = plan_for(W, nx, nu, N, ct);
     std::string why;
     if (!pl.ok) {
         k.failed = true;
@@ -217,7 +220,7 @@ JitKernel *get_kernel(int W, int nx, int nu, int N) {
             const size_t colon = arch.find(':');  // "gfx950:sramecc+:xnack-"
             if (colon != std::string::npos) arch = arch.substr(0, colon);
         }
-        const std::vector<char> code = build_code_object(pl, nx, nu, N, arch, why);
+        const std::vector<char> code = build_code_object(pl, nx, nu, N, ct, arch, why);
         if (code.empty() || hipModuleLoadData(&k.mod, code.data()) != hipSuccess ||
             hipModuleGetFunction(&k.fn, k.mod, "tinympc_jit_solve") != hipSuccess) {
             if (why.empty()) why = "loading the compiled module failed";
@@ -233,15 +236,14 @@ JitKernel *get_kernel(int W, int nx, int nu, int N) {
 }  // namespace
 
 bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables) {
-    if (!const_tables || !jit_enabled()) return false;
-    if (!plan_for(W, nx, nu, N).ok) return false;
-    // compile now (setup time), so that a failure is known before the layout is chosen
-    return get_kernel(W, nx, nu, N) != nullptr;
+    if (!jit_enabled()) return false;
+    if (!plan_for(W, nx, nu, N, const_tables).ok) return false;
+    // compile now, so that a failure is known before the layout is chosen
+    return get_kernel(W, nx, nu, N, const_tables) != nullptr;
 }
 
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream) {
-    if (!p.const_tables) return hipErrorInvalidValue;
-    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N);
+    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0);
     if (!k) return hipErrorInvalidValue;
     SolveParams arg = p;
     void *args[] = {&arg};

@@ -196,7 +196,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double *const sDw = sD + dIdx;
     const double *const sTl = sT + koff * W + r;  // (!CT) row of slot s: sTl[(s + 1) * W]
     const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
-    const unsigned aV = lds_addr(sVl), aD = lds_addr(sDr);
+    const unsigned aV = lds_addr(sVl), aD = lds_addr(sDr), aT = lds_addr(sTl);
     const int ct = p.check_termination;
 
     // Control: an instance that converges stops being `active` but its lanes keep iterating as a zombie (the sweeps are
@@ -287,22 +287,35 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         double xcur = x0v;
         double dcur = lds_read_async<0>(aD), vcur = 0.0;
         if constexpr (VL > 0) vcur = lds_read_async<0>(aV);
+        // (!CT: bounds that vary over the horizon come from the workgroup's LDS copy of the tables, one step ahead like d)
+        double locur = lo_c, hicur = hi_c;
+        if constexpr (!CT) {
+            locur = lds_read_async<W * 8>(aT);
+            hicur = lds_read_async<(TOFF + W) * 8>(aT);
+        }
         lds_wait();
         auto fstep = [&](auto S) {
             constexpr int q = decltype(S)::value;
-            double dn = 0.0, vn = 0.0;
+            double dn = 0.0, vn = 0.0, lon = lo_c, hin = hi_c;
             if constexpr (q + 1 < NS) dn = lds_read_async<(q + 1) * DS * 8>(aD);
             if constexpr (q + 1 < VL) vn = lds_read_async<(q + 1) * 512>(aV);
-            static_assert(CT, "time-varying tables: not in this build");
+            if constexpr (!CT && q + 1 < NS) {
+                lon = lds_read_async<(q + 2) * W * 8>(aT);
+                hin = lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
+            }
             if constexpr (q >= VL) {
-                xcur = Step::fwd_reg(xcur, dcur, m, cf, lo_c, hi_c, G[q], Vr[q - VL], pri, dua);
+                xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], Vr[q - VL], pri, dua);
             } else {
                 double vnew;
-                xcur = Step::fwd_lds(xcur, dcur, m, cf, lo_c, hi_c, G[q], vcur, vnew, pri, dua);
+                xcur = Step::fwd_lds(xcur, dcur, m, cf, locur, hicur, G[q], vcur, vnew, pri, dua);
                 lds_write_async<q * 512>(aV, vnew);
             }
             dcur = dn;
             vcur = vn;
+            if constexpr (!CT) {
+                locur = lon;
+                hicur = hin;
+            }
         };
         constexpr int NG = (NS + D_GROUP - 1) / D_GROUP;
         static_for<0, NG>([&](auto Gi) {
@@ -439,10 +452,14 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 }  // namespace tinympc
 // The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
 extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
-    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, true, 8);
+#ifndef TINY_JIT_CT
+#define TINY_JIT_CT 1
+#endif
+    constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, 8);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, true, 8, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, true, 8, VLJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, 8, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, 8, VLJ>(p, smem_jit);
 }
 namespace tinympc {
 #else
@@ -474,18 +491,17 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
     X(4, 1, 10)
 
 bool solve_d_supported(int nx, int nu, int N, bool const_tables) {
-    if (!const_tables) return false;
 #define X(NX_, NU_, N_) \
-    if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, true, D_WPG) >= 0;
+    if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, const_tables, D_WPG) >= 0;
     TINY_D_SHAPES(X)
 #undef X
     return false;
 }
 
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
-    if (!p.const_tables) return hipErrorInvalidValue;
-#define X(NX_, NU_, N_) \
-    if (p.nx == NX_ && p.nu == NU_ && p.N == N_) return launch_d_one<NX_, NU_, N_, true>(p, stream);
+#define X(NX_, NU_, N_)                                       \
+    if (p.nx == NX_ && p.nu == NU_ && p.N == N_)              \
+        return p.const_tables ? launch_d_one<NX_, NU_, N_, true>(p, stream) : launch_d_one<NX_, NU_, N_, false>(p, stream);
     TINY_D_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
