@@ -431,6 +431,29 @@ def main() -> int:
                                   "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
                                   "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"]}
             wide.reset()
+            # Large systems (64 < nx+nu <= 128): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
+            # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
+            lnx, lnu, lN, lB, lit = 96, 32, 20, 4096, 50
+            rng = np.random.default_rng(lnx)
+            lA = np.eye(lnx) * 0.98 + 0.015 * rng.standard_normal((lnx, lnx))
+            lBm = 0.08 * rng.standard_normal((lnx, lnu))
+            lp = P.Problem("large", lA, lBm, np.diag(rng.uniform(1, 10, lnx)), np.diag(rng.uniform(0.5, 2, lnu)), lN, 2.0, rng.standard_normal(lnx))
+            big = pkg.TinyMPC()
+            big.setup(lp.A, lp.B, lp.Q, lp.R, lp.N, batch=lB, device=local_rank, rho=lp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=lit)
+            big.set_bound_constraints(np.full(lnx, -2.0), np.full(lnx, 2.0), np.full(lnu, -0.3), np.full(lnu, 0.3))
+            big.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((lnx, lB))))
+            ms = []
+            for k in range(4):
+                big.reset_workspace()
+                ms.append(big.solve_timed())
+            med = sorted(ms[1:])[1]
+            ltf = lB * lit * lp.flops_per_iteration() / (med * 1e-3) / 1e12
+            lgb = lB * lit * lp.bytes_per_iteration() / (med * 1e-3) / 1e9
+            out["large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (lnx, lnu, lN, lB, lit),
+                                   "iters_per_s": lB * lit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": ltf, "fp64_frac": ltf / PEAK_FP64_TFLOPS,
+                                   "hbm_algorithmic_gbs": lgb, "hbm_algorithmic_frac": lgb / PEAK_HBM_GBS, "layout": big.launch_info()["layout"],
+                                   "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)"}
+            big.reset()
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
             tick = {}

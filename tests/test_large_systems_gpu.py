@@ -1,0 +1,98 @@
+"""Large systems, 64 < nx+nu <= 128 (the reference takes any nx, nu: types.hpp:16-17): the step of sixteen instances is a
+GEMM on the FP64 matrix cores (tinympc_solve_m.hip, v_mfma_f64_16x16x4_f64), the ADMM state streams through HBM in the
+tile's own layout. Against the oracle: caches, per-instance termination inside a tile, ragged last tile, warm starts after
+converged and unconverged solves, bounds and references that vary over the horizon."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from conftest import rel_err
+
+import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _system(pkg, nx, nu, N, seed, varying):
+    P = pkg.problems
+    rng = np.random.default_rng(seed)
+    A = np.eye(nx) * 0.98 + 0.015 * rng.standard_normal((nx, nx))
+    B = 0.08 * rng.standard_normal((nx, nu))
+    prob = P.Problem("large", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+    if varying:
+        prob.x_min = -2.0 - rng.uniform(0, 0.5, (nx, N))
+        prob.x_max = 2.0 + rng.uniform(0, 0.5, (nx, N))
+        prob.u_min = -0.3 * rng.uniform(0.7, 1.0, (nu, N - 1))
+        prob.u_max = 0.3 * rng.uniform(0.7, 1.0, (nu, N - 1))
+        prob.x_ref = 0.05 * rng.standard_normal((nx, N))
+        prob.u_ref = 0.02 * rng.standard_normal((nu, N - 1))
+    else:
+        prob.x_min, prob.x_max = np.full(nx, -2.0), np.full(nx, 2.0)
+        prob.u_min, prob.u_max = np.full(nu, -0.3), np.full(nu, 0.3)
+    return prob
+
+
+def _solver(pkg, prob, settings, batch):
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if prob.x_ref is not None:
+        s.set_x_ref(prob.x_ref)
+        s.set_u_ref(prob.u_ref)
+    return s
+
+
+@pytest.mark.parametrize("nx,nu,N,varying", [(60, 10, 8, False), (70, 14, 10, True), (90, 20, 6, False), (96, 32, 12, True)])
+def test_large_systems_match_the_oracle(pkg, nx, nu, N, varying):
+    prob = _system(pkg, nx, nu, N, nx + nu, varying)
+    batch = 21  # two tiles of 16, the second one ragged
+    rng = np.random.default_rng(3)
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.02, 1.2, batch)[None, :]
+    for settings in (dict(max_iter=120, abs_pri_tol=1e-3, abs_dua_tol=1e-3), dict(max_iter=25, abs_pri_tol=0.0, abs_dua_tol=0.0),
+                     dict(max_iter=60, abs_pri_tol=1e-4, abs_dua_tol=1e-4, check_termination=4)):
+        s = _solver(pkg, prob, settings, batch)
+        assert s.launch_info()["layout"] == "M"
+        c = s.get_cache()
+        orc = [O.OraclePort(prob).load_problem(prob, settings) for _ in range(batch)]
+        for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+            assert rel_err(c[n], orc[0].get(n)) < 1e-9, n
+        for rnd in range(3):  # cold start, then two warm starts
+            xs = x0s * (1.0 - 0.35 * rnd)
+            s.set_x0_batch(xs)
+            s.solve()
+            sol, st = s.get_solution_batch(), s.get_stats_batch()
+            for b in range(batch):
+                orc[b].set_x0(xs[:, b])
+                orc[b].solve()
+                assert st["iter"][b] == orc[b].stats()["iter"], (rnd, b)
+                assert st["status"][b] == orc[b].stats()["status"], (rnd, b)
+                assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL, (rnd, b)
+                assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+            for b in (0, batch // 2, batch - 1):  # the four inf-norms of the last check
+                ob = orc[b].stats()
+                np.testing.assert_allclose(st["residuals"][:, b], [ob["pri_x"], ob["dua_x"], ob["pri_u"], ob["dua_u"]], rtol=1e-6, atol=1e-10)
+        s.reset()
+
+
+def test_large_system_single_instance_and_unsupported_features(pkg):
+    prob = _system(pkg, 66, 6, 6, 1, False)
+    settings = dict(max_iter=80, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    s = _solver(pkg, prob, settings, 1)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    x = prob.x0.copy()
+    for k in range(4):  # a short closed loop on the single-instance verbs
+        s.set_x0(x)
+        s.solve()
+        orc.set_x0(x)
+        orc.solve()
+        assert s.get_stats()["iter"] == orc.stats()["iter"]
+        assert rel_err(s.get_solution()["controls"], orc.solution()[1]) < TOL
+        x = prob.A @ x + prob.B @ s.get_solution()["controls"][:, 0]
+    with pytest.raises(pkg.TinyMPCError):
+        s.session_begin()
+    s.update_settings(adaptive_rho=1)
+    with pytest.raises(pkg.TinyMPCError) as ei:
+        s.solve()
+    assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
+    s.reset()

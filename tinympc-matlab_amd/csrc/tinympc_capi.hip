@@ -105,6 +105,10 @@ struct tinympc_solver {
     // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
     bool layout_d = false;
     bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
+    // Large systems, 64 < nx+nu <= 128: tiles of 16 instances on the FP64 matrix cores, state streamed from HBM in the tile's
+    // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
+    // adaptive rho / session.
+    bool layout_m = false;
     int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
@@ -147,7 +151,7 @@ struct tinympc_solver {
     bool refs_on_host = false;         // the pinned references are newer than dXref / dUref and the tables
     bool x0_on_host = false;           // h_x0 is newer than dx0
     int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
-    bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d; }  // (layout D writes to device memory only)
+    bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d && !layout_m; }  // (layout D writes to device memory only)
     bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
     double *dscratch_state = nullptr;
     bool fam_dirty = true;
@@ -165,9 +169,9 @@ struct tinympc_solver {
 
     size_t X() const { return (size_t)nx * N; }
     size_t U() const { return (size_t)nu * (N - 1); }
-    size_t state_doubles() const { return (size_t)groups * (N + 1) * 64; }  // G; row N: per-lane dummy slot
-    size_t v_doubles() const { return (size_t)groups * v_rows(N) * 64; }     // V (and V2)
-    size_t d_doubles() const { return (size_t)groups * (N - 1) * IPW * nu; }
+    size_t state_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N + 1) * 64; }  // G; row N: per-lane dummy slot
+    size_t v_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * v_rows(N) * 64; }     // V (and V2)
+    size_t d_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N - 1) * IPW * nu; }
 };
 
 namespace {
@@ -363,6 +367,8 @@ int launch(tinympc_solver *s, bool timed) {
     if ((rc = refresh_derived(s))) return rc;
     if (adaptive && fam)
         return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
+    if (s->layout_m && (adaptive || fam))
+        return fail(TINYMPC_ERR_UNSUPPORTED, "systems with nx+nu > 64 support box constraints only (no cone / linear families, no adaptive_rho)");
     if (adaptive) {  // tiny tables from the current cache, sensitivities and Xref; rebuilt per launch (a few microseconds)
         AdaptTableParams a{};
         a.nx = s->nx; a.nu = s->nu; a.N = s->N; a.W = s->W; a.KT = s->KT;
@@ -383,7 +389,7 @@ int launch(tinympc_solver *s, bool timed) {
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     p.const_tables = s->tables_const() ? 1 : 0;
-    if (s->zero_copy_tick && !s->use_layout_d()) {  // set by tinympc_mpc_step_batch for the duration of one launch
+    if (s->zero_copy_tick && !s->use_layout_d() && !s->layout_m) {  // set by tinympc_mpc_step_batch for the duration of one launch
         p.x0 = s->h_x0;
         p.x0_mirror = s->dx0;
         p.u0_host = s->h_u0;
@@ -407,7 +413,9 @@ int launch(tinympc_solver *s, bool timed) {
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-    if (adaptive) {
+    if (s->layout_m) {
+        HIP_TRY(launch_solve_m(p, s->stream));
+    } else if (adaptive) {
         // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
@@ -542,8 +550,12 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     if (N < 2) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: N must be >= 2 (TinyMPC.m:52), got %d", N);
     if (batch < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "setup: batch must be >= 1, got %d", batch);
     int W = 0, KT = 0;
-    if (!choose_geometry(nx, nu, &W, &KT))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d exceeds the 64 lanes of a wavefront; not supported by this build", nx + nu);
+    const bool large = solve_m_supported(nx, nu);
+    if (large) {
+        W = KT = 128;  // geometry of the operators / tables; the kernel works on 16-instance tiles
+    } else if (!choose_geometry(nx, nu, &W, &KT)) {
+        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d: systems beyond 128 rows are not supported by this build", nx + nu);
+    }
     int ndev = tinympc_device_count();
     if (ndev < 1) return fail(TINYMPC_ERR_NO_DEVICE, "no HIP device visible: the HIP path has no CPU fallback");
     if (device >= ndev) return fail(TINYMPC_ERR_INVALID_INPUT, "device %d out of range (have %d)", device, ndev);
@@ -556,7 +568,10 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         s->device = device;
     }
     s->nx = nx; s->nu = nu; s->N = N; s->batch = batch; s->rho = rho;
-    s->W = W; s->KT = KT; s->IPW = 64 / W; s->groups = (batch + s->IPW - 1) / s->IPW;
+    s->W = W; s->KT = KT;
+    s->layout_m = large;
+    s->IPW = large ? 16 : 64 / W;
+    s->groups = (batch + s->IPW - 1) / s->IPW;  // wave groups; tiles of 16 instances for the large-system kernel
     // tiny_set_default_settings (tiny_api.cpp:213-231, tiny_api_constants.hpp:5-10)
     s->st = Settings{1e-3, 1e-3, 1000, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, 100.0, 1};
 
@@ -584,11 +599,13 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     HIP_TRY_S(hipEventCreate(&s->ev1));
 
     // LDS plan: ADMM state always; the per-knot tables too when the total fits the 160 KB of a CU.
-    const size_t with_tables = solve_lds_bytes(nx, nu, N, W, true);
-    const size_t without = solve_lds_bytes(nx, nu, N, W, false);
+    // (the large-system kernel plans its own LDS: everything below describes layouts A - D and stays unused for it)
+    const int Wp = large ? 64 : W;
+    const size_t with_tables = solve_lds_bytes(nx, nu, N, Wp, true);
+    const size_t without = solve_lds_bytes(nx, nu, N, Wp, false);
     constexpr size_t kLdsMax = 160 * 1024;
     // Horizons whose state does not fit a CU's LDS run the same kernels on an HBM working copy (GMEM variant).
-    s->state_in_global = without > kLdsMax;
+    s->state_in_global = !large && without > kLdsMax;
     // Two workgroups per CU need <= 80 KB each; prefer LDS tables whenever they do not cost a workgroup slot.
     const size_t slots_without = s->state_in_global ? 0 : kLdsMax / without;
     const size_t slots_with = kLdsMax / with_tables;
@@ -636,7 +653,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         // simply leaves the handle on layout B / A.
         const bool d_compiled = (W == 16 && solve_d_supported(nx, nu, N, true)) || (W == 32 && solve_dw_supported(nx, nu, N, true)) ||
                                 (W == 64 && solve_dx_supported(nx, nu, N, true));
-        bool want_d = (W == 16) ? !want_c : batch >= 16;
+        bool want_d = (W == 16) ? !want_c : (batch >= 16 && !large);
         if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = (env[0] == 'D' || env[0] == 'd');
         if (want_d && !d_compiled) {
             HIP_TRY_S(hipSetDevice(s->device));
@@ -908,7 +925,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         s->host_sol_state = 2;
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
-    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d()) {
+    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->layout_m) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
@@ -1428,7 +1445,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     return TINYMPC_OK;
 }
 
-int tinympc_get_layout(tinympc_solver *s) { return s ? (s->use_layout_d() ? 'D' : s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
+int tinympc_get_layout(tinympc_solver *s) { return s ? (s->layout_m ? 'M' : s->use_layout_d() ? 'D' : s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
 
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 

@@ -237,6 +237,10 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cach
     return e;
 }
 
+// Large systems (64 < nx+nu <= 128) on the FP64 matrix cores, 16 instances per tile (tinympc_solve_m.hip)
+bool solve_m_supported(int nx, int nu);
+size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
+hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
 bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables);

@@ -1,0 +1,354 @@
+// tinympc_solve_m.hip -- k_admm_solve_m ("layout M"): LARGE systems, 64 < nx+nu <= 128, on the FP64 matrix cores.
+//
+// Same algorithm as the other solve kernels (tinympc_solve.hip has the reference citations: M1 solve admm.cpp:109-207 = F1
+// :25-35, S1 :43-59, D1 :65-69, L1 :75-83, R1 :89-107, C1 :196-197, B1 :13-20). Up to 64 rows an instance fits the lanes of
+// a wavefront and the sweep step is a mat-vec on the VALU with the operator row in registers (layouts A-D); beyond that a lane
+// would need several operand entries and an operator row no register file holds. This is the regime BASELINE.json's
+// north_star reserves MFMA for: the step of SIXTEEN instances at once is a GEMM,
+//     [x_{i+1}; u_i] (nxu x 16) = Mf (nxu x nxu) * [x_i; d_i] (nxu x 16) + cf,
+// on v_mfma_f64_16x16x4_f64 tiles -- FP64 MFMA has the VALU's peak on MI355X (tools/microbench_mfma_f64.hip), but it shares
+// the operator tile between 16 instances and needs no per-column operand broadcast.
+//
+// One workgroup = 4 wavefronts = one tile of 16 instances. Wavefront w owns the 16-row output tiles t = w and t = w + 4
+// (R = ceil(nxu / 16) <= 8 tiles) and keeps its operator tiles register-resident for a whole sweep: A[t][kb] = the 16 x 4 block
+// (rows 16t.., columns 4kb..), one double per lane, 2 * 4R <= 64 doubles. The MFMA layouts (MI355X_MICROARCH.md) make the
+// data flow closed: a result register D_t[reg] holds out[16t + (lane>>4) + 4 reg][instance lane&15], and the B operand of
+// k-block kb = 4t + reg wants x[4kb + (lane>>4)][instance lane&15] -- the same lane, the same value. So the operand vector
+// of the next step is the result of this one, exchanged between the four wavefronts through a double-buffered LDS array
+// Xb[kb][lane] behind ONE barrier per step; nothing is ever transposed.
+// Everything row-local (slack projection, dual ascent, residual maxima, linear cost) happens on the result registers, 8
+// (row, instance) entries per lane. The ADMM state does not fit on chip at these sizes (16 instances x 128 rows x N knots x
+// (g, v) = 650 KB at N = 20) and streams through HBM once per sweep, in the tile's own layout
+//     G, V, V2, D : [tile][knot][4R (= t, reg)][64 lanes]      (512-byte lines)
+// which only this kernel reads (these sizes run on no other layout). The slack is a ping-pong pair V / V2 by iteration
+// parity: a converged solve must keep the PREVIOUS iterate (admm.cpp:181-197), which is then simply the buffer last read.
+// Arithmetic intensity ~ nxu / 20 flop per byte of state: HBM-bound below nxu ~ 128, at a few tenths of the FP64 peak.
+#include "tinympc_device.h"
+
+#ifndef TINY_EXP_M
+#define TINY_EXP_M 0  // timing experiments (tools/build_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs
+#endif
+
+namespace tinympc {
+
+typedef double double4_m __attribute__((ext_vector_type(4)));
+
+constexpr int M_INST = 16;       // instances per tile (the N dimension of the MFMA)
+constexpr int M_WAVES = 4;
+
+// doubles per (tile, knot) of a state array
+__host__ __device__ constexpr size_t m_knot_doubles(int R) { return (size_t)4 * R * 64; }
+size_t solve_m_state_doubles(int nx, int nu, int N, int tiles) {
+    const int R = (nx + nu + 15) / 16;
+    return (size_t)tiles * N * m_knot_doubles(R);
+}
+bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 128 && nx >= 1 && nu >= 1; }
+
+template <int R>
+__global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
+    constexpr int KB = 4 * R;  // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
+    __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
+    __shared__ unsigned sFlag[2][M_WAVES];                          // per-wave "instance still below tolerance" masks
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu, T = N - 1;
+    const int W = 128, KT = 128;  // ops / tables geometry of these sizes (choose_geometry_m)
+    const long tile = blockIdx.x;
+    const int jn = lane & 15, kq = lane >> 4;  // instance within the tile, row within a k-block / result quad
+    const long inst = tile * M_INST + jn;
+    const bool inst_ok = inst < p.batch;
+    const int TOFF = (N + 2) * W;
+    const size_t KD = m_knot_doubles(R);
+    // Addressing: every state access is (tile- and knot-uniform base, in SGPRs) + (a 32-bit per-lane offset that depends on
+    // the entry only): no 64-bit VGPR address per (array, entry) -- those cost the first version 200 VGPRs and its spills.
+    double *const gG = p.G + (size_t)tile * N * KD;
+    double *const gVa = p.V + (size_t)tile * N * KD;
+    double *const gVb = p.V2 + (size_t)tile * N * KD;
+    double *const gD = p.D + (size_t)tile * N * KD;
+
+    // this wave's result entries: e = 0..7 <-> tile t = wv + 4 (e >> 2), reg = e & 3, row = 16 t + kq + 4 reg. Rows and their
+    // kind are recomputed from `rowbase` where they are needed (cheap integer work) instead of living in 8 x 3 masks.
+    const int rowbase = 16 * wv + kq;
+    auto row_of = [&](int e) -> int { return rowbase + 64 * (e >> 2) + 4 * (e & 3); };
+    auto kind_of = [&](int e) -> int { const int r = row_of(e); return r < nx ? 1 : (r < nxu ? 2 : 0); };  // 1 state, 2 input, 0 padding
+    const bool has1 = wv + 4 < R;  // (uniform) this wave owns a second tile
+    auto slot = [&](int e) -> unsigned { return (unsigned)((4 * (wv + 4 * (e >> 2)) + (e & 3)) * 64 + lane); };  // offset of entry e inside a knot
+    const double rho = p.rho;
+    const int ct = p.check_termination;
+    // lo / hi / linref of (row, knot): table row kn + 1 (L2-resident; a run-time switch to an LDS copy for tables that do not
+    // vary over the horizon pushed the kernel over its register file and was slower)
+    auto tab = [&](int which, int kn, int e) -> double {
+        return p.tables[(unsigned)(which * TOFF + (kn + 1) * W + row_of(e))];  // (uniform base + 32-bit offset)
+    };
+    const double *const cf_tab = p.ops + (size_t)2 * W * KT, *const cb_tab = cf_tab + W;
+
+    // A tiles of the sweep operator `which` (0: Mf, 1: Mb), register-resident for one sweep
+    double A0[KB], A1[KB];
+    auto load_A = [&](int which) {
+        const double *M = p.ops + (size_t)which * W * KT;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int col = 4 * kb + kq;
+            A0[kb] = M[(size_t)(16 * wv + jn) * KT + col];
+            A1[kb] = has1 ? M[(size_t)(16 * (wv + 4) + jn) * KT + col] : 0.0;
+        }
+    };
+    // out[e] = start[e] + (operator) * (operand vector in sX[buf]). FOUR accumulation chains (two per tile, even / odd
+    // k-blocks): a dependent FP64 MFMA can only issue when its predecessor has left the pipe, and two chains leave it idle
+    // half of the time (3.6 -> 2 us per step).
+    auto gemm = [&](int buf, const double (&start)[8], double (&out)[8]) {
+        double4_m c0 = {start[0], start[1], start[2], start[3]}, c1 = {start[4], start[5], start[6], start[7]};
+        double4_m d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+#if TINY_EXP_M != 2
+#pragma unroll
+        for (int kb = 0; kb < KB; kb += 2) {
+            const double b0 = sX[buf][kb][lane], b1 = sX[buf][kb + 1][lane];
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb], b0, c0, 0, 0, 0);
+            if (has1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[kb], b0, c1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb + 1], b1, d0, 0, 0, 0);
+            if (has1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[kb + 1], b1, d1, 0, 0, 0);
+        }
+#else
+        c0[0] += sX[buf][0][lane] * A0[0];
+        c1[0] += sX[buf][1][lane] * A1[0];
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            out[q] = c0[q] + d0[q];
+            out[4 + q] = c1[q] + d1[q];
+        }
+    };
+    // entry e of the next operand vector goes to k-block 4 t + reg, same lane
+    auto put = [&](int buf, int e, double v) {
+        if (wv + 4 * (e >> 2) < R) sX[buf][4 * (wv + 4 * (e >> 2)) + (e & 3)][lane] = v;
+    };
+
+    bool active = inst_ok;      // (per lane: its instance is still iterating)
+    int it_done = 0, status = 11;
+    bool res_valid = false;
+    double snap_pri_x = 0.0, snap_pri_u = 0.0, snap_dua_x = 0.0, snap_dua_u = 0.0;
+    int par = 0;                // the slack buffer this iteration READS: 0 = V, 1 = V2
+    int buf = 0;
+
+    for (int it = 0; it < p.max_iter; ++it) {  // admm.cpp:129
+        if (__syncthreads_or(active ? 1 : 0) == 0) break;
+        const bool check = (ct > 0) && (((it + 1) % ct) == 0);
+        double *const Vr = par ? gVb : gVa, *const Vw = par ? gVa : gVb;
+        double pri_x = 0.0, pri_u = 0.0, dua_x = 0.0, dua_u = 0.0;
+
+        // ================= forward sweep (F1) with S1 + D1 + R1 fused in =================
+        load_A(0);
+        double start[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) start[e] = kind_of(e) ? cf_tab[row_of(e)] : 0.0;
+        // operand of step 0: [x_0; d_0]; and knot 0 of the state rows: x_0 is given, only projected
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kd = kind_of(e);
+            double w = 0.0;
+            if (kd == 1) {
+                const double x0 = inst_ok ? p.x0[inst * nx + row_of(e)] : 0.0;
+                const double g = gG[slot(e)], vold = Vr[slot(e)];
+                const double s = x0 + g;
+                const double snew = fmin(tab(1, 0, e), fmax(tab(0, 0, e), s));
+                pri_x = fmax(pri_x, fabs(x0 - snew));
+                dua_x = fmax(dua_x, fabs(vold - snew));
+                if (active) {
+                    gG[slot(e)] = s - snew;
+                    Vw[slot(e)] = snew;
+                }
+                w = x0;
+            } else if (kd == 2) {
+                w = gD[slot(e)];
+            }
+            put(buf, e, w);
+        }
+        __syncthreads();
+        for (int i = 0; i < T; ++i) {
+            // The row-local operands of this step (dual, old slack, the next step's feed-forward entry) do not depend on the
+            // GEMM: they are requested first and arrive while the matrix cores work -- the state streams through HBM at these
+            // sizes, and a step that waited for it AFTER its MFMAs ran at a fifth of this speed.
+            double pg[8], pv[8], pd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kd = kind_of(e);
+                pg[e] = pv[e] = pd[e] = 0.0;
+                if (kd != 0 && TINY_EXP_M != 1) {
+                    const unsigned o = (unsigned)((i + (kd == 1 ? 1 : 0)) * (int)KD) + slot(e);
+                    pg[e] = gG[o];
+                    pv[e] = Vr[o];
+                    if (kd == 2 && i + 1 < T) pd[e] = gD[(unsigned)((i + 1) * (int)KD) + slot(e)];
+                }
+            }
+            double out[8];
+            gemm(buf, start, out);  // state rows: x_{i+1}; input rows: u_i
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kd = kind_of(e);
+                if (kd != 0) {
+                    const int kn = i + (kd == 1 ? 1 : 0);
+                    const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
+                    const double s = out[e] + pg[e];
+                    const double snew = fmin(tab(1, kn, e), fmax(tab(0, kn, e), s));  // (bounds: L2-resident table)
+                    const double tp = fabs(out[e] - snew), td = fabs(pv[e] - snew);
+                    if (kd == 1) {
+                        pri_x = fmax(pri_x, tp);
+                        dua_x = fmax(dua_x, td);
+                    } else {
+                        pri_u = fmax(pri_u, tp);
+                        dua_u = fmax(dua_u, td);
+                    }
+                    if (active && TINY_EXP_M != 1) {
+                        gG[o] = s - snew;
+                        Vw[o] = snew;
+                    }
+                    put(buf ^ 1, e, kd == 2 ? pd[e] : out[e]);  // next operand: state rows carry x_{i+1}, input rows bring d_{i+1}
+                } else {
+                    put(buf ^ 1, e, 0.0);
+                }
+            }
+            buf ^= 1;
+            __syncthreads();
+        }
+        if (active) it_done = it + 1;  // admm.cpp:143
+
+        // ================= R1: termination (admm.cpp:93-101), per instance over all rows and all four waves =================
+        bool conv = false;
+        if (check) {
+            const bool below = (pri_x < p.abs_pri_tol) && (pri_u < p.abs_pri_tol) && (dua_x * rho < p.abs_dua_tol) && (dua_u * rho < p.abs_dua_tol);
+            const unsigned long long m = __ballot(below);
+            const unsigned q = (unsigned)(m & (m >> 16) & (m >> 32) & (m >> 48)) & 0xffffu;  // instance j: all four row quads of this wave
+            if (lane == 0) sFlag[it & 1][wv] = q;
+            __syncthreads();
+            const unsigned all = sFlag[it & 1][0] & sFlag[it & 1][1] & sFlag[it & 1][2] & sFlag[it & 1][3];
+            conv = ((all >> jn) & 1u) != 0u;
+            // the four inf-norms of this instance: maxima over its lanes in this wave now, over the waves after the loop
+            if (active) {
+                snap_pri_x = pri_x;
+                snap_pri_u = pri_u;
+                snap_dua_x = dua_x;
+                snap_dua_u = dua_u;
+                res_valid = true;
+                if (conv) {
+                    status = 1;  // TINY_SOLVED: stops before the backward pass; its canonical slack is the buffer just READ
+                    active = false;
+                }
+            }
+        }
+        const int par_read = par;
+        par ^= 1;
+
+        // ================= backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) from V (just written), G =================
+        load_A(1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) start[e] = kind_of(e) ? cb_tab[row_of(e)] : 0.0;
+        double *const Vn = par_read ? gVa : gVb;  // the slack written by this iteration's forward sweep
+        {   // operand of step N-2: [p_{N-1}; r_{N-2}]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kd = kind_of(e);
+                double w = 0.0;
+                if (kd == 1) {
+                    const unsigned o = (unsigned)((N - 1) * (int)KD) + slot(e);
+                    w = p.tables[(size_t)3 * TOFF + row_of(e)] - rho * (Vn[o] - gG[o]);  // p_{N-1}, admm.cpp:81-82
+                } else if (kd == 2) {
+                    const unsigned o = (unsigned)((N - 2) * (int)KD) + slot(e);
+                    w = tab(2, N - 2, e) - rho * (Vn[o] - gG[o]);  // r_{N-2}, admm.cpp:77-78
+                }
+                put(buf, e, w);
+            }
+        }
+        __syncthreads();
+        for (int i = T - 1; i >= 0; --i) {
+            // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM
+            double lin[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kd = kind_of(e);
+                lin[e] = 0.0;
+                if ((kd == 1 || (kd == 2 && i >= 1)) && TINY_EXP_M != 1) {
+                    const int kn = kd == 1 ? i : i - 1;
+                    const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
+                    lin[e] = tab(2, kn, e) - rho * (Vn[o] - gG[o]);  // admm.cpp:77-80
+                }
+            }
+            double out[8];
+            gemm(buf, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kd = kind_of(e);
+                double w = lin[e];
+                if (kd == 1) w = lin[e] + out[e];                                                      // p_i = q_i + ...
+                else if (kd == 2 && active && TINY_EXP_M != 1) gD[(unsigned)(i * (int)KD) + slot(e)] = out[e];  // d_i (a converged instance keeps its last real d)
+                put(buf ^ 1, e, w);
+            }
+            buf ^= 1;
+            __syncthreads();
+        }
+    }
+
+    // ---- canonical slack: an instance that stopped at max_iter has v <- vnew (admm.cpp:196-197): the buffer `par` now points
+    // at; a converged one keeps the previous iterate: the buffer it READ in its last iteration. Both must end up in p.V.
+    // Lanes remember: which buffer holds (a) the canonical slack, (b) the solution vnew (the one written last).
+    // par was flipped after every forward sweep this lane's instance took part in... but `par` is block-uniform, so track
+    // per lane through the iteration count instead: after k forward sweeps the last-written buffer is V2 if k is odd, V if even.
+    if (p.max_iter > 0 && inst_ok) {
+        const bool last_written_is_b = (it_done & 1) != 0;
+        double *const Vsol = last_written_is_b ? gVb : gVa;
+        double *const Vold = last_written_is_b ? gVa : gVb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kd = kind_of(e), rw = row_of(e);
+            if (kd == 0) continue;
+            const int knots = kd == 1 ? N : N - 1;
+            for (int kn = 0; kn < knots; ++kn) {
+                const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
+                const double sol = Vsol[o];
+                if (kd == 1) p.sol_x[((size_t)inst * N + kn) * nx + rw] = sol;
+                else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (rw - nx)] = sol;
+                const double canon = (status == 1) ? Vold[o] : sol;
+                if (it_done > 0) {
+                    gVa[o] = canon;  // p.V is the canonical copy between solves (both stores are by this lane, in order)
+                }
+            }
+        }
+    }
+    // residual norms of the last check: max over this instance's lanes in the wave, then over the four waves
+    __syncthreads();
+    double *sR = &sX[0][0][0];  // reuse: [4 waves][4 norms][16 instances]
+    {
+        double v4[4] = {snap_pri_x, snap_dua_x, snap_pri_u, snap_dua_u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = v4[q];
+            v = fmax(v, __shfl_xor(v, 16));
+            v = fmax(v, __shfl_xor(v, 32));
+            if (kq == 0) sR[(wv * 4 + q) * 16 + jn] = v;
+        }
+    }
+    __syncthreads();
+    if (wv == 0 && kq == 0 && inst_ok) {
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            for (int q = 0; q < 4; ++q) {
+                const double v = fmax(fmax(sR[(0 * 4 + q) * 16 + jn], sR[(1 * 4 + q) * 16 + jn]), fmax(sR[(2 * 4 + q) * 16 + jn], sR[(3 * 4 + q) * 16 + jn]));
+                p.dstats[inst * 4 + q] = (q == 1 || q == 3) ? v * rho : v;
+            }
+        }
+    }
+}
+
+hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
+    const int R = (p.nx + p.nu + 15) / 16;
+    const int tiles = (p.batch + M_INST - 1) / M_INST;
+    switch (R) {
+        case 5: hipLaunchKernelGGL(k_admm_solve_m<5>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
+        case 6: hipLaunchKernelGGL(k_admm_solve_m<6>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
+        case 7: hipLaunchKernelGGL(k_admm_solve_m<7>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
+        case 8: hipLaunchKernelGGL(k_admm_solve_m<8>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tinympc
