@@ -44,11 +44,16 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles) {
 }
 bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 128 && nx >= 1 && nu >= 1; }
 
-template <int R>
+// CT: bounds and references are the same at every knot (p.const_tables): they are served from a 3 KB LDS copy instead of
+// the L2-resident per-knot tables -- 24 L2 round trips less behind every GEMM. (A compile-time switch: as a run-time one it
+// pushed the kernel over its register file. Likewise, requesting the state a whole step ahead instead of right before the
+// step's own GEMM cost more in spills than it hid in latency: the register file, not HBM, bounds this version.)
+template <int R, bool CT>
 __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;  // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
     __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
     __shared__ unsigned sFlag[2][M_WAVES];                          // per-wave "instance still below tolerance" masks
+    __shared__ double sTab[CT ? 3 : 1][128];                        // CT: lo | hi | linref of every row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu, T = N - 1;
     const int W = 128, KT = 128;  // ops / tables geometry of these sizes (choose_geometry_m)
@@ -74,10 +79,14 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     auto slot = [&](int e) -> unsigned { return (unsigned)((4 * (wv + 4 * (e >> 2)) + (e & 3)) * 64 + lane); };  // offset of entry e inside a knot
     const double rho = p.rho;
     const int ct = p.check_termination;
-    // lo / hi / linref of (row, knot): table row kn + 1 (L2-resident; a run-time switch to an LDS copy for tables that do not
-    // vary over the horizon pushed the kernel over its register file and was slower)
+    // lo / hi / linref of (row, knot): table row kn + 1
+    if constexpr (CT) {
+        for (int i = tid; i < 3 * 128; i += 64 * M_WAVES) sTab[i / 128][i % 128] = p.tables[(unsigned)((i / 128) * TOFF + W + (i % 128))];
+        __syncthreads();
+    }
     auto tab = [&](int which, int kn, int e) -> double {
-        return p.tables[(unsigned)(which * TOFF + (kn + 1) * W + row_of(e))];  // (uniform base + 32-bit offset)
+        if constexpr (CT) return sTab[which][row_of(e)];
+        else return p.tables[(unsigned)(which * TOFF + (kn + 1) * W + row_of(e))];  // (uniform base + 32-bit offset)
     };
     const double *const cf_tab = p.ops + (size_t)2 * W * KT, *const cb_tab = cf_tab + W;
 
@@ -341,13 +350,19 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
     const int R = (p.nx + p.nu + 15) / 16;
     const int tiles = (p.batch + M_INST - 1) / M_INST;
+#define TINY_M_LAUNCH(R_)                                                                                                \
+    case R_:                                                                                                              \
+        if (p.const_tables) hipLaunchKernelGGL((k_admm_solve_m<R_, true>), dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); \
+        else hipLaunchKernelGGL((k_admm_solve_m<R_, false>), dim3(tiles), dim3(64 * M_WAVES), 0, stream, p);              \
+        break;
     switch (R) {
-        case 5: hipLaunchKernelGGL(k_admm_solve_m<5>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
-        case 6: hipLaunchKernelGGL(k_admm_solve_m<6>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
-        case 7: hipLaunchKernelGGL(k_admm_solve_m<7>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
-        case 8: hipLaunchKernelGGL(k_admm_solve_m<8>, dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); break;
+        TINY_M_LAUNCH(5)
+        TINY_M_LAUNCH(6)
+        TINY_M_LAUNCH(7)
+        TINY_M_LAUNCH(8)
         default: return hipErrorInvalidValue;
     }
+#undef TINY_M_LAUNCH
     return hipGetLastError();
 }
 
