@@ -121,6 +121,7 @@ struct JitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     bool failed = false;
+    std::vector<char> image;  // the code object stays alive as long as the module does
 };
 using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables
 std::map<Key, JitKernel> &cache() {
@@ -133,7 +134,7 @@ std::mutex &cache_mutex() {
 }
 
 // Compile (or fetch from the disk cache) the code object of one shape. Empty on failure; `why` says why.
-std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, const std::string &arch, std::string &why) {
+std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, const std::string &arch, bool use_disk_cache, std::string &why) {
     const std::string sdir = source_dir(), idir = include_dir();
     const std::string spath = sdir + "/" + pl.source;
     if (!file_exists(spath) || !file_exists(sdir + "/tinympc_device.h")) {
@@ -151,10 +152,11 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
     const std::string cpath = cache_dir() + name;
-    if (file_exists(cpath)) {
+    if (use_disk_cache && file_exists(cpath)) {
         const std::string blob = read_file(cpath);
         if (!blob.empty()) return std::vector<char>(blob.begin(), blob.end());
     }
+    if (!use_disk_cache) (void)unlink(cpath.c_str());  // (a cached image that did not load: replace it)
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), pl.source, 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         why = "hiprtcCreateProgram failed";
@@ -220,16 +222,22 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
             const size_t colon = arch.find(':');  // "gfx950:sramecc+:xnack-"
             if (colon != std::string::npos) arch = arch.substr(0, colon);
         }
-        const std::vector<char> code = build_code_object(pl, nx, nu, N, ct, arch, why);
-        if (code.empty() || hipModuleLoadData(&k.mod, code.data()) != hipSuccess ||
-            hipModuleGetFunction(&k.fn, k.mod, "tinympc_jit_solve") != hipSuccess) {
-            if (why.empty()) why = "loading the compiled module failed";
-            k.failed = true;
+        // first the disk cache; an image from there that does not load (truncated file, other driver) is compiled again
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            k.image = build_code_object(pl, nx, nu, N, ct, arch, attempt == 0, why);
+            k.failed = k.image.empty() || hipModuleLoadData(&k.mod, k.image.data()) != hipSuccess ||
+                       hipModuleGetFunction(&k.fn, k.mod, "tinympc_jit_solve") != hipSuccess;
+            if (!k.failed || k.image.empty()) break;
+            (void)hipGetLastError();
+            if (k.mod) (void)hipModuleUnload(k.mod);
+            k.mod = nullptr;
+            k.fn = nullptr;
         }
+        if (k.failed && why.empty()) why = "loading the compiled module failed";
     }
     if (k.failed && !why.empty() && getenv("TINYMPC_JIT_VERBOSE"))
         fprintf(stderr, "tinympc-hip: no run-time specialisation for nx=%d nu=%d N=%d: %s\n", nx, nu, N, why.c_str());
-    auto ins = cache().emplace(key, k);
+    auto ins = cache().emplace(key, std::move(k));
     return ins.first->second.failed ? nullptr : &ins.first->second;
 }
 

@@ -47,7 +47,8 @@ bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 128 &
 // CT: bounds and references are the same at every knot (p.const_tables): they are served from a 3 KB LDS copy instead of
 // the L2-resident per-knot tables -- 24 L2 round trips less behind every GEMM. (A compile-time switch: as a run-time one it
 // pushed the kernel over its register file. Likewise, requesting the state a whole step ahead instead of right before the
-// step's own GEMM cost more in spills than it hid in latency: the register file, not HBM, bounds this version.)
+// step's own GEMM, and interleaving two instance tiles per workgroup over shared operator tiles, both cost far more in
+// spills than they hid in latency: the register file, not HBM, bounds this version.)
 template <int R, bool CT>
 __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;  // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
