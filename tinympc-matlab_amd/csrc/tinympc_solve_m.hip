@@ -9,14 +9,17 @@
 // on v_mfma_f64_16x16x4_f64 tiles -- FP64 MFMA has the VALU's peak on MI355X (tools/microbench_mfma_f64.hip), but it shares
 // the operator tile between 16 instances and needs no per-column operand broadcast.
 //
-// One workgroup = 4 wavefronts = one tile of 16 instances. Wavefront w owns the 16-row output tiles t = w and t = w + 4
-// (R = ceil(nxu / 16) <= 8 tiles) and keeps its operator tiles register-resident for a whole sweep: A[t][kb] = the 16 x 4 block
-// (rows 16t.., columns 4kb..), one double per lane, 2 * 4R <= 64 doubles. The MFMA layouts (MI355X_MICROARCH.md) make the
+// One workgroup = 8 wavefronts = one tile of 16 instances. Wavefront w owns the 16-row output tile t = w (R = ceil(nxu / 16)
+// <= 8 tiles; wavefronts beyond R only take part in the barriers) and keeps its operator tiles register-resident for a whole
+// sweep: A[kb] = the 16 x 4 block (rows 16w.., columns 4kb..), one double per lane, 4R <= 32 doubles. (The first version gave
+// a wavefront two row tiles and a workgroup four wavefronts: 408 VGPRs, one wavefront per SIMD, and every wait for state or
+// for the exchange left its SIMD idle -- 18 M iterations/s at nx=96 against 22.5 M now. Half the rows per wavefront halve
+// every per-lane array; two wavefronts share a SIMD.) The MFMA layouts (MI355X_MICROARCH.md) make the
 // data flow closed: a result register D_t[reg] holds out[16t + (lane>>4) + 4 reg][instance lane&15], and the B operand of
 // k-block kb = 4t + reg wants x[4kb + (lane>>4)][instance lane&15] -- the same lane, the same value. So the operand vector
 // of the next step is the result of this one, exchanged between the four wavefronts through a double-buffered LDS array
 // Xb[kb][lane] behind ONE barrier per step; nothing is ever transposed.
-// Everything row-local (slack projection, dual ascent, residual maxima, linear cost) happens on the result registers, 8
+// Everything row-local (slack projection, dual ascent, residual maxima, linear cost) happens on the result registers, 4
 // (row, instance) entries per lane. The ADMM state does not fit on chip at these sizes (16 instances x 128 rows x N knots x
 // (g, v) = 650 KB at N = 20) and streams through HBM once per sweep, in the tile's own layout
 //     G, V, V2, D : [tile][knot][4R (= t, reg)][64 lanes]      (512-byte lines)
@@ -34,7 +37,7 @@ namespace tinympc {
 typedef double double4_m __attribute__((ext_vector_type(4)));
 
 constexpr int M_INST = 16;       // instances per tile (the N dimension of the MFMA)
-constexpr int M_WAVES = 4;
+constexpr int M_WAVES = 8;       // one 16-row output tile per wavefront (R <= 8)
 
 // doubles per (tile, knot) of a state array
 __host__ __device__ constexpr size_t m_knot_doubles(int R) { return (size_t)4 * R * 64; }
@@ -47,8 +50,8 @@ bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 128 &
 // CT: bounds and references are the same at every knot (p.const_tables): they are served from a 3 KB LDS copy instead of
 // the L2-resident per-knot tables -- 24 L2 round trips less behind every GEMM. (A compile-time switch: as a run-time one it
 // pushed the kernel over its register file. Likewise, requesting the state a whole step ahead instead of right before the
-// step's own GEMM, and interleaving two instance tiles per workgroup over shared operator tiles, both cost far more in
-// spills than they hid in latency: the register file, not HBM, bounds this version.)
+// step's own GEMM, and interleaving two instance tiles per workgroup over shared operator tiles, both cost more in spills
+// than they hid in latency.)
 template <int R, bool CT>
 __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;  // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
@@ -71,13 +74,13 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     double *const gVb = p.V2 + (size_t)tile * N * KD;
     double *const gD = p.D + (size_t)tile * N * KD;
 
-    // this wave's result entries: e = 0..7 <-> tile t = wv + 4 (e >> 2), reg = e & 3, row = 16 t + kq + 4 reg. Rows and their
-    // kind are recomputed from `rowbase` where they are needed (cheap integer work) instead of living in 8 x 3 masks.
+    // this wave's result entries: e = 0..3 <-> reg = e, row = 16 wv + kq + 4 e. Rows and their kind are recomputed from
+    // `rowbase` where they are needed (cheap integer work) instead of living in masks.
     const int rowbase = 16 * wv + kq;
-    auto row_of = [&](int e) -> int { return rowbase + 64 * (e >> 2) + 4 * (e & 3); };
-    auto kind_of = [&](int e) -> int { const int r = row_of(e); return r < nx ? 1 : (r < nxu ? 2 : 0); };  // 1 state, 2 input, 0 padding
-    const bool has1 = wv + 4 < R;  // (uniform) this wave owns a second tile
-    auto slot = [&](int e) -> unsigned { return (unsigned)((4 * (wv + 4 * (e >> 2)) + (e & 3)) * 64 + lane); };  // offset of entry e inside a knot
+    const bool has_tile = wv < R;  // (uniform) this wave owns a row tile
+    auto row_of = [&](int e) -> int { return rowbase + 4 * e; };
+    auto kind_of = [&](int e) -> int { const int r = row_of(e); return !has_tile ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
+    auto slot = [&](int e) -> unsigned { return (unsigned)((4 * wv + e) * 64 + lane); };  // offset of entry e inside a knot
     const double rho = p.rho;
     const int ct = p.check_termination;
     // lo / hi / linref of (row, knot): table row kn + 1
@@ -92,44 +95,30 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     const double *const cf_tab = p.ops + (size_t)2 * W * KT, *const cb_tab = cf_tab + W;
 
     // A tiles of the sweep operator `which` (0: Mf, 1: Mb), register-resident for one sweep
-    double A0[KB], A1[KB];
+    double A0[KB];
     auto load_A = [&](int which) {
         const double *M = p.ops + (size_t)which * W * KT;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int col = 4 * kb + kq;
-            A0[kb] = M[(size_t)(16 * wv + jn) * KT + col];
-            A1[kb] = has1 ? M[(size_t)(16 * (wv + 4) + jn) * KT + col] : 0.0;
-        }
+        for (int kb = 0; kb < KB; ++kb) A0[kb] = has_tile ? M[(size_t)(16 * wv + jn) * KT + 4 * kb + kq] : 0.0;
     };
-    // out[e] = start[e] + (operator) * (operand vector in sX[buf]). FOUR accumulation chains (two per tile, even / odd
-    // k-blocks): a dependent FP64 MFMA can only issue when its predecessor has left the pipe, and two chains leave it idle
-    // half of the time (3.6 -> 2 us per step).
-    auto gemm = [&](int buf, const double (&start)[8], double (&out)[8]) {
-        double4_m c0 = {start[0], start[1], start[2], start[3]}, c1 = {start[4], start[5], start[6], start[7]};
-        double4_m d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
-#if TINY_EXP_M != 2
+    // out[e] = start[e] + (operator) * (operand vector in sX[buf]). Two accumulation chains per wavefront (even / odd
+    // k-blocks), i.e. four per SIMD: a dependent FP64 MFMA only issues when its predecessor has left the pipe.
+    auto gemm = [&](int buf, const double (&start)[4], double (&out)[4]) {
+        double4_m c0 = {start[0], start[1], start[2], start[3]}, d0 = {0.0, 0.0, 0.0, 0.0};
+        if (has_tile) {
 #pragma unroll
-        for (int kb = 0; kb < KB; kb += 2) {
-            const double b0 = sX[buf][kb][lane], b1 = sX[buf][kb + 1][lane];
-            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb], b0, c0, 0, 0, 0);
-            if (has1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[kb], b0, c1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb + 1], b1, d0, 0, 0, 0);
-            if (has1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[kb + 1], b1, d1, 0, 0, 0);
+            for (int kb = 0; kb < KB; kb += 2) {
+                const double b0 = sX[buf][kb][lane], b1 = sX[buf][kb + 1][lane];
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb], b0, c0, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb + 1], b1, d0, 0, 0, 0);
+            }
         }
-#else
-        c0[0] += sX[buf][0][lane] * A0[0];
-        c1[0] += sX[buf][1][lane] * A1[0];
-#endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            out[q] = c0[q] + d0[q];
-            out[4 + q] = c1[q] + d1[q];
-        }
+        for (int q = 0; q < 4; ++q) out[q] = c0[q] + d0[q];
     };
     // entry e of the next operand vector goes to k-block 4 t + reg, same lane
     auto put = [&](int buf, int e, double v) {
-        if (wv + 4 * (e >> 2) < R) sX[buf][4 * (wv + 4 * (e >> 2)) + (e & 3)][lane] = v;
+        if (has_tile) sX[buf][4 * wv + e][lane] = v;
     };
 
     bool active = inst_ok;      // (per lane: its instance is still iterating)
@@ -147,12 +136,12 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 
         // ================= forward sweep (F1) with S1 + D1 + R1 fused in =================
         load_A(0);
-        double start[8];
+        double start[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) start[e] = kind_of(e) ? cf_tab[row_of(e)] : 0.0;
+        for (int e = 0; e < 4; ++e) start[e] = kind_of(e) ? cf_tab[row_of(e)] : 0.0;
         // operand of step 0: [x_0; d_0]; and knot 0 of the state rows: x_0 is given, only projected
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const int kd = kind_of(e);
             double w = 0.0;
             if (kd == 1) {
@@ -177,9 +166,9 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             // The row-local operands of this step (dual, old slack, the next step's feed-forward entry) do not depend on the
             // GEMM: they are requested first and arrive while the matrix cores work -- the state streams through HBM at these
             // sizes, and a step that waited for it AFTER its MFMAs ran at a fifth of this speed.
-            double pg[8], pv[8], pd[8];
+            double pg[4], pv[4], pd[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(e);
                 pg[e] = pv[e] = pd[e] = 0.0;
                 if (kd != 0 && TINY_EXP_M != 1) {
@@ -189,10 +178,10 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
                     if (kd == 2 && i + 1 < T) pd[e] = gD[(unsigned)((i + 1) * (int)KD) + slot(e)];
                 }
             }
-            double out[8];
+            double out[4];
             gemm(buf, start, out);  // state rows: x_{i+1}; input rows: u_i
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(e);
                 if (kd != 0) {
                     const int kn = i + (kd == 1 ? 1 : 0);
@@ -229,7 +218,9 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             const unsigned q = (unsigned)(m & (m >> 16) & (m >> 32) & (m >> 48)) & 0xffffu;  // instance j: all four row quads of this wave
             if (lane == 0) sFlag[it & 1][wv] = q;
             __syncthreads();
-            const unsigned all = sFlag[it & 1][0] & sFlag[it & 1][1] & sFlag[it & 1][2] & sFlag[it & 1][3];
+            unsigned all = 0xffffu;
+#pragma unroll
+            for (int w8 = 0; w8 < M_WAVES; ++w8) all &= sFlag[it & 1][w8];
             conv = ((all >> jn) & 1u) != 0u;
             // the four inf-norms of this instance: maxima over its lanes in this wave now, over the waves after the loop
             if (active) {
@@ -250,11 +241,11 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         // ================= backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) from V (just written), G =================
         load_A(1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) start[e] = kind_of(e) ? cb_tab[row_of(e)] : 0.0;
+        for (int e = 0; e < 4; ++e) start[e] = kind_of(e) ? cb_tab[row_of(e)] : 0.0;
         double *const Vn = par_read ? gVa : gVb;  // the slack written by this iteration's forward sweep
         {   // operand of step N-2: [p_{N-1}; r_{N-2}]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(e);
                 double w = 0.0;
                 if (kd == 1) {
@@ -270,9 +261,9 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         __syncthreads();
         for (int i = T - 1; i >= 0; --i) {
             // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM
-            double lin[8];
+            double lin[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(e);
                 lin[e] = 0.0;
                 if ((kd == 1 || (kd == 2 && i >= 1)) && TINY_EXP_M != 1) {
@@ -281,10 +272,10 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
                     lin[e] = tab(2, kn, e) - rho * (Vn[o] - gG[o]);  // admm.cpp:77-80
                 }
             }
-            double out[8];
+            double out[4];
             gemm(buf, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(e);
                 double w = lin[e];
                 if (kd == 1) w = lin[e] + out[e];                                                      // p_i = q_i + ...
@@ -306,7 +297,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         double *const Vsol = last_written_is_b ? gVb : gVa;
         double *const Vold = last_written_is_b ? gVa : gVb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4; ++e) {
             const int kd = kind_of(e), rw = row_of(e);
             if (kd == 0) continue;
             const int knots = kd == 1 ? N : N - 1;
@@ -324,7 +315,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     }
     // residual norms of the last check: max over this instance's lanes in the wave, then over the four waves
     __syncthreads();
-    double *sR = &sX[0][0][0];  // reuse: [4 waves][4 norms][16 instances]
+    double *sR = &sX[0][0][0];  // reuse: [8 waves][4 norms][16 instances]
     {
         double v4[4] = {snap_pri_x, snap_dua_x, snap_pri_u, snap_dua_u};
 #pragma unroll
@@ -341,7 +332,8 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         p.istats[inst * 2 + 1] = status;
         if (res_valid) {
             for (int q = 0; q < 4; ++q) {
-                const double v = fmax(fmax(sR[(0 * 4 + q) * 16 + jn], sR[(1 * 4 + q) * 16 + jn]), fmax(sR[(2 * 4 + q) * 16 + jn], sR[(3 * 4 + q) * 16 + jn]));
+                double v = 0.0;
+                for (int w8 = 0; w8 < M_WAVES; ++w8) v = fmax(v, sR[(w8 * 4 + q) * 16 + jn]);
                 p.dstats[inst * 4 + q] = (q == 1 || q == 3) ? v * rho : v;
             }
         }
