@@ -96,3 +96,66 @@ def test_large_system_single_instance_and_unsupported_features(pkg):
         s.solve()
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     s.reset()
+
+
+def test_large_system_lifecycle_edges(pkg):
+    """Cold start after reset_workspace reproduces the first solve; a 0-iteration solve leaves everything alone;
+    check_termination = 0 never checks; the batched tick (mpc_step) equals set_x0_batch + solve + first controls."""
+    prob = _system(pkg, 72, 8, 7, 5, False)
+    settings = dict(max_iter=30, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    batch = 18
+    rng = np.random.default_rng(9)
+    x0s = rng.standard_normal((prob.nx, batch)) * 0.3
+    s = _solver(pkg, prob, settings, batch)
+    s.set_x0_batch(x0s)
+    s.solve()
+    first = s.get_solution_batch()
+    it1 = s.get_stats_batch()["iter"].copy()
+    s.reset_workspace()
+    s.solve()
+    np.testing.assert_array_equal(s.get_solution_batch()["controls"], first["controls"])
+    np.testing.assert_array_equal(s.get_stats_batch()["iter"], it1)
+    s.update_settings(max_iter=0)
+    s.solve()
+    np.testing.assert_array_equal(s.get_solution_batch()["controls"], first["controls"])
+    s.update_settings(max_iter=12, check_termination=0)
+    s.solve()
+    st = s.get_stats_batch()
+    assert np.all(st["iter"] == 12) and np.all(st["status"] == 11)
+    # tick: one call vs three verbs, warm-started from the same state on two handles
+    a, b = _solver(pkg, prob, settings, batch), _solver(pkg, prob, settings, batch)
+    x = x0s.copy()
+    for k in range(3):
+        ua = a.mpc_step(x)
+        b.set_x0_batch(x)
+        b.solve()
+        np.testing.assert_array_equal(ua, b.get_first_controls_batch())
+        x = prob.A @ x + prob.B @ ua
+    for h in (s, a, b):
+        h.reset()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(17, 2, 10), (15, 2, 10), (33, 2, 6), (62, 2, 5)])
+def test_edge_widths_on_the_run_time_specialised_layout_d(pkg, monkeypatch, nx, nu, N):
+    """Just above 16 and 32 rows and at 64: the 32- and 64-lane forms of layout D with almost empty upper DPP rows.
+    (A stable A and nu = 2: a weakly controllable unstable system makes the Riccati recursion itself ill-conditioned, and
+    its round-off then moves the solution by more than the tolerance in every layout alike.)"""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    prob = _system(pkg, nx, nu, N, 11, False)
+    rng = np.random.default_rng(5)
+    prob.A = 0.85 * np.eye(nx) + (0.1 / np.sqrt(nx)) * rng.standard_normal((nx, nx))  # stable: two inputs cannot hold 60 unstable modes
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    batch = 70
+    rng = np.random.default_rng(2)
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.05, 1.0, batch)[None, :]
+    s = _solver(pkg, prob, settings, batch)
+    assert s.launch_info()["layout"] == "D"
+    s.set_x0_batch(x0s)
+    s.solve()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    ox, ou, oit, ost, _ = orc.solve_batch(x0s)
+    np.testing.assert_array_equal(st["iter"], oit)
+    np.testing.assert_array_equal(st["status"], ost)
+    assert rel_err(sol["states"], ox) < TOL and rel_err(sol["controls"], ou) < TOL
+    s.reset()
