@@ -508,10 +508,12 @@ def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
         s.reset()
 
 
-@pytest.mark.parametrize("nx,nu,N", [(12, 4, 20), (12, 4, 30), (6, 3, 25), (20, 6, 15), (30, 10, 9)])
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 20), (12, 4, 30), (6, 3, 25), (20, 6, 15), (30, 10, 9),
+                                     (12, 4, 75), (12, 4, 100), (6, 3, 100), (24, 8, 60), (48, 16, 40)])
 def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, N):
     """Shapes that are NOT compiled into the library get layout D through hiprtc (tinympc_jit.hip): default for large
-    batches, same results as the oracle, TINYMPC_JIT=0 falls back to layout B / A."""
+    batches, same results as the oracle, TINYMPC_JIT=0 falls back to layout B / A. The second row are horizons whose duals
+    do not fit 256 registers: the plan with one wavefront per SIMD (512 registers, four wavefronts per workgroup)."""
     if kernel_layout != "D":
         pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")  # the library's own choice
@@ -550,7 +552,7 @@ def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, 
     s.reset()
 
 
-@pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25"])
+@pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25", "quadrotor80"])
 def test_layout_d_with_bounds_and_references_that_vary_over_the_horizon(pkg, kernel_layout, monkeypatch, shape):
     """Layout D reads per-knot bounds / references from the workgroup's LDS copy of the tables (16-lane form; the
     compiled-in cartpole shape and a run-time specialised one): large batch, library's own layout choice."""
@@ -558,7 +560,7 @@ def test_layout_d_with_bounds_and_references_that_vary_over_the_horizon(pkg, ker
         pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
-    prob = P.cartpole(20, True) if shape == "cartpole20" else P.quadrotor(25)
+    prob = P.cartpole(20, True) if shape == "cartpole20" else P.quadrotor(int(shape[9:]))  # (80: one wavefront per SIMD)
     rng = np.random.default_rng(5)
     nx, nu, N = prob.nx, prob.nu, prob.N
     xlim, ulim = (2.0, 0.5) if shape == "cartpole20" else (5.0, 0.5)

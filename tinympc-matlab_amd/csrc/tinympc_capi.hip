@@ -1439,7 +1439,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? solve_d_workgroups(s->groups) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->use_layout_d() ? (s->d_jit ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->d_varying != 1, s->groups) : solve_d_workgroups(s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)(s->layout_c ? s->lds_bytes_c : s->lds_bytes);
     if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
     return TINYMPC_OK;

@@ -36,6 +36,7 @@ namespace {
 struct JitPlan {
     bool ok = false;
     int vreg = 0;  // slack knots kept in registers
+    int wps = 2;   // wavefronts per SIMD: 2 (256 registers each), or 1 (512 registers) for long horizons
     const char *source = nullptr;
 };
 
@@ -54,16 +55,22 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct) {
     else return pl;
     if (!ct && W != 16) return pl;  // bounds / references that vary over the horizon: 16-lane form only
     const int tab_doubles = ct ? 0 : 3 * (N + 2) * 16 + 16;  // the workgroup's LDS copy of the per-knot tables
-    const int budget = 256 - 76 - (ct ? 0 : 8) - mregs - 2 * ns;
-    if (budget < 0) return pl;
-    int vreg = budget / 2;
-    if (vreg > ns) vreg = ns;
-    const int wave_doubles = (160 * 1024 / 8 - ops_doubles - tab_doubles) / 8 - d_doubles;
-    if (wave_doubles < 0) return pl;
-    const int vlmax = wave_doubles / 64;
-    if (ns - vreg > vlmax) return pl;  // the LDS part of the slack does not fit
-    pl.ok = true;
-    pl.vreg = vreg;
+    // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
+    // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
+    for (int wps = 2; wps >= 1; --wps) {
+        const int budget = 256 * (3 - wps) - (wps == 2 ? 76 : 110) - (ct ? 0 : 8) - mregs - 2 * ns;
+        if (budget < 0) continue;
+        int vreg = budget / 2;
+        if (vreg > ns) vreg = ns;
+        const int wave_doubles = (160 * 1024 / 8 - ops_doubles - tab_doubles) / (4 * wps) - d_doubles;
+        if (wave_doubles < 0) continue;
+        const int vlmax = wave_doubles / 64;
+        if (ns - vreg > vlmax) continue;  // the LDS part of the slack does not fit
+        pl.ok = true;
+        pl.vreg = vreg;
+        pl.wps = wps;
+        return pl;
+    }
     return pl;
 }
 
@@ -121,6 +128,7 @@ struct JitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     bool failed = false;
+    int wpg = 8;  // wavefronts per workgroup
     std::vector<char> image;  // the code object stays alive as long as the module does
 };
 using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables
@@ -147,7 +155,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     for (const char *dep : {"tinympc_device.h", "tinympc_sweep.h", "tinympc_solve_d_chain.h", "tinympc_solve_dw_chain.h", "tinympc_solve_dx_chain.h"})
         h = fnv1a(read_file(sdir + "/" + dep), h);
     char shape[160];
-    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d ct=%d %s", pl.source, nx, nu, N, pl.vreg, (int)ct, arch.c_str());
+    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d ct=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, (int)ct, arch.c_str());
     h = fnv1a(shape, h);
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
@@ -165,7 +173,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     std::vector<std::string> o = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-I" + sdir, "-I" + idir, "-DTINY_JIT=1",
                                   "-DTINY_JIT_NX=" + std::to_string(nx), "-DTINY_JIT_NU=" + std::to_string(nu),
                                   "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg),
-                                  std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0")};
+                                  "-DTINY_JIT_WPS=" + std::to_string(pl.wps), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0")};
     std::vector<const char *> opts;
     for (const auto &x : o) opts.push_back(x.c_str());
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -233,6 +241,7 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
             k.mod = nullptr;
             k.fn = nullptr;
         }
+        k.wpg = 4 * pl.wps;
         if (k.failed && why.empty()) why = "loading the compiled module failed";
     }
     if (k.failed && !why.empty() && getenv("TINYMPC_JIT_VERBOSE"))
@@ -250,13 +259,18 @@ bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables) {
     return get_kernel(W, nx, nu, N, const_tables) != nullptr;
 }
 
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups) {
+    const int wpg = 4 * plan_for(W, nx, nu, N, const_tables).wps;
+    return (groups + wpg - 1) / wpg;
+}
+
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream) {
     JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0);
     if (!k) return hipErrorInvalidValue;
     SolveParams arg = p;
     void *args[] = {&arg};
-    const int wgs = (p.groups + 7) / 8;
-    return hipModuleLaunchKernel(k->fn, (unsigned)wgs, 1, 1, 512, 1, 1, 0, stream, args, nullptr);
+    const int wgs = (p.groups + k->wpg - 1) / k->wpg;
+    return hipModuleLaunchKernel(k->fn, (unsigned)wgs, 1, 1, 64u * k->wpg, 1, 1, 0, stream, args, nullptr);
 }
 
 }  // namespace tinympc

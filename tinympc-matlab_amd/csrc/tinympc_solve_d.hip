@@ -73,10 +73,11 @@ constexpr int D_VREG_MAX = 24;
 constexpr int D_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int d_d_doubles(int nu, int N) { return ((N - 1) * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int d_tab_doubles(int N) { return 3 * (N + 2) * 16 + 16; }
-// number of slack slots in LDS; -1 if the shape does not fit the plan (8 waves per CU)
-__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg) {
+// number of slack slots in LDS; -1 if the shape does not fit the plan (cu_waves wavefronts per CU: 8, or 4 for the
+// long-horizon plan with one wavefront per SIMD and 512 registers)
+__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8) {
     const int ns = N - 1;
-    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / 8 - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N));
+    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / cu_waves - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N));
     const int wave_doubles = wg_doubles / wpg - d_d_doubles(nu, N);
     if (wave_doubles < 0) return -1;
     const int vlmax = wave_doubles / 64;
@@ -451,15 +452,20 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 #ifdef TINY_JIT
 }  // namespace tinympc
 // The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
-extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
+#ifndef TINY_JIT_WPS
+#define TINY_JIT_WPS 2  // wavefronts per SIMD: 2 (256 registers each), or 1 (512) for horizons whose duals need them
+#endif
+extern "C" __global__ void __launch_bounds__(256 * TINY_JIT_WPS) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
+tinympc_jit_solve(const tinympc::SolveParams p) {
 #ifndef TINY_JIT_CT
 #define TINY_JIT_CT 1
 #endif
     constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
-    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, 8);
+    constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, 8, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, 8, VLJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ>(p, smem_jit);
 }
 namespace tinympc {
 #else

@@ -55,9 +55,9 @@ constexpr int DX_VREG_MAX = 12;
 #endif    // slack knots kept in registers (the rest goes to LDS)
 constexpr int DX_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int dx_d_doubles(int nu, int N) { return ((N - 1) * nu + 1) & ~1; }
-__host__ __device__ constexpr int dx_vl(int nu, int N, int wpg) {
+__host__ __device__ constexpr int dx_vl(int nu, int N, int wpg, int cu_waves = 8) {  // cu_waves 4: one wavefront per SIMD, 512 registers
     const int ns = N - 1;
-    const int wg_doubles = DX_LDS_PER_CU / 8 * wpg / 8 - DX_OPS_DOUBLES;
+    const int wg_doubles = DX_LDS_PER_CU / 8 * wpg / cu_waves - DX_OPS_DOUBLES;
     const int wave_doubles = wg_doubles / wpg - dx_d_doubles(nu, N);
     if (wave_doubles < 0) return -1;
     const int vlmax = wave_doubles / 64;
@@ -417,11 +417,16 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 #ifdef TINY_JIT
 }  // namespace tinympc
 // The one kernel of a run-time specialised module: a fixed C name, static LDS (its size is known here).
-extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) tinympc_jit_solve(const tinympc::SolveParams p) {
-    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, 8);
+#ifndef TINY_JIT_WPS
+#define TINY_JIT_WPS 2  // wavefronts per SIMD: 2 (256 registers each), or 1 (512) for horizons whose duals need them
+#endif
+extern "C" __global__ void __launch_bounds__(256 * TINY_JIT_WPS) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
+tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
+    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, WPGJ, WPGJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, 8, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, 8, VLJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, WPGJ, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, WPGJ, VLJ>(p, smem_jit);
 }
 namespace tinympc {
 #else
