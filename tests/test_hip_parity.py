@@ -552,18 +552,25 @@ def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, 
     s.reset()
 
 
-@pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25", "quadrotor80"])
+@pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25", "quadrotor80", "wide24x8x30", "wide20x6x15", "wide48x16x20", "wide24x8x60"])
 def test_layout_d_with_bounds_and_references_that_vary_over_the_horizon(pkg, kernel_layout, monkeypatch, shape):
-    """Layout D reads per-knot bounds / references from the workgroup's LDS copy of the tables (16-lane form; the
-    compiled-in cartpole shape and a run-time specialised one): large batch, library's own layout choice."""
+    """Layout D reads per-knot bounds / references from the workgroup's LDS copy of the tables (the compiled-in cartpole
+    shape, run-time specialised ones, the 32- and 64-lane forms -- there this variant is always specialised at run time,
+    also for shapes whose constant-table kernel is compiled in): large batch, library's own layout choice."""
     if kernel_layout != "D":
         pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
-    prob = P.cartpole(20, True) if shape == "cartpole20" else P.quadrotor(int(shape[9:]))  # (80: one wavefront per SIMD)
     rng = np.random.default_rng(5)
+    if shape.startswith("wide"):
+        nx, nu, N = (int(t) for t in shape[4:].split("x"))
+        A = np.eye(nx) + 0.03 * rng.standard_normal((nx, nx))
+        B = 0.1 * rng.standard_normal((nx, nu))
+        prob = P.Problem("wide", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+    else:
+        prob = P.cartpole(20, True) if shape == "cartpole20" else P.quadrotor(int(shape[9:]))  # (80: one wavefront per SIMD)
     nx, nu, N = prob.nx, prob.nu, prob.N
-    xlim, ulim = (2.0, 0.5) if shape == "cartpole20" else (5.0, 0.5)
+    xlim, ulim = (2.0, 0.5) if shape == "cartpole20" else (2.0, 0.3) if shape.startswith("wide") else (5.0, 0.5)
     prob.x_min = -xlim - rng.uniform(0, 0.5, (nx, N))
     prob.x_max = xlim + rng.uniform(0, 0.5, (nx, N))
     prob.u_min = -ulim * rng.uniform(0.6, 1.0, (nu, N - 1))

@@ -61,12 +61,14 @@ def test_generated_code_has_no_dpp_hazard(source, tmp_path):
     assert not bad, f"{len(bad)} DPP hazard(s) in {source}, first: {bad[:3]}"
 
 
-@pytest.mark.parametrize("source,nx,nu,N,vreg,wps", [("tinympc_solve_d.hip", 12, 4, 20, 19, 2), ("tinympc_solve_d.hip", 6, 3, 30, 29, 2), ("tinympc_solve_d.hip", 4, 1, 45, 30, 2),
-                                                    ("tinympc_solve_dw.hip", 20, 6, 15, 14, 2), ("tinympc_solve_dw.hip", 13, 4, 25, 16, 2),
-                                                    ("tinympc_solve_dx.hip", 30, 10, 9, 8, 2), ("tinympc_solve_dx.hip", 40, 12, 8, 7, 2),
-                                                    ("tinympc_solve_d.hip", 12, 4, 100, 86, 1), ("tinympc_solve_dw.hip", 24, 8, 60, 59, 1),
-                                                    ("tinympc_solve_dx.hip", 48, 16, 40, 39, 1)])
-def test_run_time_specialisations_have_no_dpp_hazard(source, nx, nu, N, vreg, wps, tmp_path):
+@pytest.mark.parametrize("source,nx,nu,N,vreg,wps,ct", [("tinympc_solve_d.hip", 12, 4, 20, 19, 2, 1), ("tinympc_solve_d.hip", 6, 3, 30, 29, 2, 1), ("tinympc_solve_d.hip", 4, 1, 45, 30, 2, 1),
+                                                       ("tinympc_solve_dw.hip", 20, 6, 15, 14, 2, 1), ("tinympc_solve_dw.hip", 13, 4, 25, 16, 2, 1),
+                                                       ("tinympc_solve_dx.hip", 30, 10, 9, 8, 2, 1), ("tinympc_solve_dx.hip", 40, 12, 8, 7, 2, 1),
+                                                       ("tinympc_solve_d.hip", 12, 4, 100, 86, 1, 1), ("tinympc_solve_dw.hip", 24, 8, 60, 59, 1, 1),
+                                                       ("tinympc_solve_dx.hip", 48, 16, 40, 39, 1, 1),
+                                                       ("tinympc_solve_d.hip", 12, 4, 25, 24, 2, 0), ("tinympc_solve_dw.hip", 24, 8, 30, 10, 2, 0),
+                                                       ("tinympc_solve_dx.hip", 48, 16, 20, 19, 1, 0)])
+def test_run_time_specialisations_have_no_dpp_hazard(source, nx, nu, N, vreg, wps, ct, tmp_path):
     """tinympc_jit.hip compiles these sources with -DTINY_JIT ... through hiprtc on the GPU box, where nothing lints the
     result; the same specialisations are compiled here with hipcc (same front end, same flags) and linted."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -75,7 +77,7 @@ def test_run_time_specialisations_have_no_dpp_hazard(source, nx, nu, N, vreg, wp
     out = tmp_path / "jit.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_VREG={vreg}",
-                    f"-DTINY_JIT_WPS={wps}", "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, source)], check=True, timeout=900)
+                    f"-DTINY_JIT_WPS={wps}", f"-DTINY_JIT_CT={ct}", "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, source)], check=True, timeout=900)
     text = out.read_text()
     checked, bad = _lint(text)
     assert checked > 50 and not bad, bad[:3]

@@ -109,6 +109,7 @@ struct tinympc_solver {
     // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
     // adaptive rho / session.
     bool layout_m = false;
+    bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
     int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
@@ -355,9 +356,14 @@ int launch(tinympc_solver *s, bool timed) {
     int rc;
     s->flag_pending = false;
     if (s->layout_d && s->d_varying < 0 && !s->tables_const()) {
-        // first launch with time-varying tables on a layout-D handle: is there a kernel for that (16-lane form: compiled
-        // in or specialised now)? Otherwise these launches run on layout B / A, as before.
-        s->d_varying = (s->W == 16 && (s->d_jit ? solve_jit_supported(s->W, s->nx, s->nu, s->N, false) : solve_d_supported(s->nx, s->nu, s->N, false))) ? 1 : 0;
+        // first launch with time-varying tables on a layout-D handle: is there a kernel for that (compiled in -- 16-lane
+        // form only -- or specialised now)? Otherwise these launches run on layout B / A, as before.
+        if (s->W == 16 && !s->d_jit && solve_d_supported(s->nx, s->nu, s->N, false)) {
+            s->d_varying = 1;
+        } else {
+            s->d_varying_jit = solve_jit_supported(s->W, s->nx, s->nu, s->N, false);
+            s->d_varying = s->d_varying_jit ? 1 : 0;
+        }
     }
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
@@ -431,7 +437,7 @@ int launch(tinympc_solver *s, bool timed) {
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
     } else if (s->use_layout_d()) {
-        HIP_TRY(s->d_jit ? launch_solve_jit(p, s->W, s->stream)
+        HIP_TRY((s->d_jit || (!p.const_tables && s->d_varying_jit)) ? launch_solve_jit(p, s->W, s->stream)
                          : s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
     } else if (s->layout_c) {
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;

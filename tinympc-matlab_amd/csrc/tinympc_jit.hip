@@ -53,8 +53,7 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct) {
     else if (W == 32 && nxu > 16 && nxu <= 32) { mregs = 64; ops_doubles = 2 * 32 * 32; d_doubles = ((ns * 2 * nu) + 1) & ~1; pl.source = "tinympc_solve_dw.hip"; }
     else if (W == 64 && nxu > 32 && nxu <= 64) { mregs = 128; ops_doubles = 2 * 64 * 64; d_doubles = ((ns * nu) + 1) & ~1; pl.source = "tinympc_solve_dx.hip"; }
     else return pl;
-    if (!ct && W != 16) return pl;  // bounds / references that vary over the horizon: 16-lane form only
-    const int tab_doubles = ct ? 0 : 3 * (N + 2) * 16 + 16;  // the workgroup's LDS copy of the per-knot tables
+    const int tab_doubles = ct ? 0 : 3 * (N + 2) * W + W;  // the workgroup's LDS copy of the per-knot tables
     // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
     // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
     for (int wps = 2; wps >= 1; --wps) {

@@ -55,17 +55,18 @@ constexpr int DX_VREG_MAX = 12;
 #endif    // slack knots kept in registers (the rest goes to LDS)
 constexpr int DX_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int dx_d_doubles(int nu, int N) { return ((N - 1) * nu + 1) & ~1; }
-__host__ __device__ constexpr int dx_vl(int nu, int N, int wpg, int cu_waves = 8) {  // cu_waves 4: one wavefront per SIMD, 512 registers
+__host__ __device__ constexpr int dx_tab_doubles(int N) { return 3 * (N + 2) * 64 + 64; }  // the workgroup's copy of the per-knot tables (!CT)
+__host__ __device__ constexpr int dx_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8) {  // cu_waves 4: one wavefront per SIMD, 512 registers
     const int ns = N - 1;
-    const int wg_doubles = DX_LDS_PER_CU / 8 * wpg / cu_waves - DX_OPS_DOUBLES;
+    const int wg_doubles = DX_LDS_PER_CU / 8 * wpg / cu_waves - DX_OPS_DOUBLES - (ct ? 0 : dx_tab_doubles(N));
     const int wave_doubles = wg_doubles / wpg - dx_d_doubles(nu, N);
     if (wave_doubles < 0) return -1;
     const int vlmax = wave_doubles / 64;
     const int want = ns > DX_VREG_MAX ? ns - DX_VREG_MAX : 0;
     return want <= vlmax ? want : -1;
 }
-__host__ __device__ constexpr size_t dx_lds_bytes(int nu, int N, int wpg, int vl) {
-    return sizeof(double) * ((size_t)DX_OPS_DOUBLES + (size_t)wpg * (vl * 64 + dx_d_doubles(nu, N)));
+__host__ __device__ constexpr size_t dx_lds_bytes(int nu, int N, bool ct, int wpg, int vl) {
+    return sizeof(double) * ((size_t)DX_OPS_DOUBLES + (ct ? 0 : dx_tab_doubles(N)) + (size_t)wpg * (vl * 64 + dx_d_doubles(nu, N)));
 }
 typedef __attribute__((address_space(3))) double lds_double_w;
 __device__ __forceinline__ unsigned lds_addr_w(const double *p) { return (unsigned)(size_t)(const lds_double_w *)p; }
@@ -96,10 +97,9 @@ __device__ __forceinline__ void lds_wait_w() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
-template <int NX, int NU, int N, int WPG, int VL>
+template <int NX, int NU, int N, bool CT, int WPG, int VL>
 __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, double *smem) {
     constexpr int W = 64, IPW = 1, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
-    constexpr bool CT = true;  // time-invariant bounds / references only
     constexpr int KT = 64;  // row stride of p.ops (choose_geometry)
     constexpr int TOFF = (N + 2) * W;
     static_assert(NS >= 3 && VL >= 0 && VL <= NS && NXU > 32 && NXU <= 64, "64-lane layout D: N >= 4, 32 < nx+nu <= 64");
@@ -118,7 +118,7 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
 
     double *sOps = smem;
     double *sT = smem + DX_OPS_DOUBLES;
-    double *sV = sT + 0 + (size_t)wv * (VL * 64 + dx_d_doubles(NU, N));
+    double *sV = sT + (CT ? 0 : dx_tab_doubles(N)) + (size_t)wv * (VL * 64 + dx_d_doubles(NU, N));
     double *sD = sV + VL * 64;
 
     // ---- workgroup-shared: the two sweep operators, transposed to [k][r] (conflict-free row reads), and the tables
@@ -126,6 +126,8 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
         const int which = i >> 12, k = (i >> 6) & 63, rr = i & 63;
         sOps[i] = p.ops[(size_t)which * W * KT + (size_t)rr * KT + k];
     }
+    if constexpr (!CT)
+        for (int i = threadIdx.x; i < dx_tab_doubles(N); i += 64 * WPG) sT[i] = p.tables[i];
 
     const size_t g0 = grp_ok ? (size_t)grp : 0;
     double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
@@ -160,7 +162,7 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
     double *const sDw = sD + dIdx;
     const double *const sTl = sT + koff * W + r;  // (!CT) row of slot s: sTl[(s + 1) * W]
     const double *const sMf = sOps + r, *const sMb = sOps + 4096 + r;
-    const unsigned aV = lds_addr_w(sVl), aD = lds_addr_w(sDr);
+    const unsigned aV = lds_addr_w(sVl), aD = lds_addr_w(sDr), aT = lds_addr_w(sTl);
     const int ct = p.check_termination;
 
     // Control: an instance that converges stops being `active` but its lanes keep iterating as a zombie (the sweeps are
@@ -251,13 +253,22 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
         double xcur = x0v;
         double dcur = lds_read_async_w<0>(aD), vcur = 0.0;
         if constexpr (VL > 0) vcur = lds_read_async_w<0>(aV);
+        // (!CT: bounds that vary over the horizon come from the workgroup's LDS copy of the tables, one step ahead like d)
+        double locur = lo_c, hicur = hi_c;
+        if constexpr (!CT) {
+            locur = lds_read_async_w<W * 8>(aT);
+            hicur = lds_read_async_w<(TOFF + W) * 8>(aT);
+        }
         lds_wait_w();
         auto fstep = [&](auto S) {
             constexpr int q = decltype(S)::value;
-            double dn = 0.0, vn = 0.0;
+            double dn = 0.0, vn = 0.0, lon = lo_c, hin = hi_c;
             if constexpr (q + 1 < NS) dn = lds_read_async_w<(q + 1) * DS * 8>(aD);
             if constexpr (q + 1 < VL) vn = lds_read_async_w<(q + 1) * 512>(aV);
-            static_assert(CT, "time-varying tables: not in this build");
+            if constexpr (!CT && q + 1 < NS) {
+                lon = lds_read_async_w<(q + 2) * W * 8>(aT);
+                hin = lds_read_async_w<(TOFF + (q + 2) * W) * 8>(aT);
+            }
             // operand vector [x_q; d_q]: one entry per lane, replicated across the instance's two DPP rows
             double r0, r1, r2, r3;
             replicate_rows(is_x ? xcur : dcur, r0, r1, r2, r3);
@@ -265,15 +276,19 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
             Step::q1(a, r1, m);
             Step::q2(a, r2, m);
             if constexpr (q >= VL) {
-                Step::q3_fwd_reg(a, r3, m, lo_c, hi_c, G[q], Vr[q - VL], pri, dua);
+                Step::q3_fwd_reg(a, r3, m, locur, hicur, G[q], Vr[q - VL], pri, dua);
             } else {
                 double vnew;
-                Step::q3_fwd_lds(a, r3, m, lo_c, hi_c, G[q], vcur, vnew, pri, dua);
+                Step::q3_fwd_lds(a, r3, m, locur, hicur, G[q], vcur, vnew, pri, dua);
                 lds_write_async_w<q * 512>(aV, vnew);
             }
             xcur = a;
             dcur = dn;
             vcur = vn;
+            if constexpr (!CT) {
+                locur = lon;
+                hicur = hin;
+            }
         };
         constexpr int NG = (NS + DW_GROUP - 1) / DW_GROUP;
         static_for_w<0, NG>([&](auto Gi) {
@@ -410,7 +425,7 @@ __device__ __forceinline__ void k_admm_solve_dx_body(const SolveParams &p, doubl
 template <int NX, int NU, int N, int WPG, int VL>
 __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_dx(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    k_admm_solve_dx_body<NX, NU, N, WPG, VL>(p, smem);
+    k_admm_solve_dx_body<NX, NU, N, true, WPG, VL>(p, smem);  // (compiled in: time-invariant tables; the other form is specialised at run time)
 }
 #endif
 
@@ -422,11 +437,15 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 #endif
 extern "C" __global__ void __launch_bounds__(256 * TINY_JIT_WPS) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
+#ifndef TINY_JIT_CT
+#define TINY_JIT_CT 1
+#endif
+    constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
     constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
-    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, WPGJ, WPGJ);
+    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, WPGJ, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, WPGJ, VLJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double)];
+    tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ>(p, smem_jit);
 }
 namespace tinympc {
 #else
@@ -437,11 +456,11 @@ constexpr int DX_WPG = 8;
 
 template <int NX, int NU, int N>
 static hipError_t launch_dx_one(const SolveParams &p, hipStream_t stream) {
-    constexpr int VL = dx_vl(NU, N, DX_WPG);
+    constexpr int VL = dx_vl(NU, N, true, DX_WPG);
     if constexpr (VL < 0) {
         return hipErrorInvalidValue;
     } else {
-        constexpr size_t lds = dx_lds_bytes(NU, N, DX_WPG, VL);
+        constexpr size_t lds = dx_lds_bytes(NU, N, true, DX_WPG, VL);
         static size_t lds_set[16] = {0};
         auto fn = &k_admm_solve_dx<NX, NU, N, DX_WPG, VL>;
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
@@ -459,7 +478,7 @@ static hipError_t launch_dx_one(const SolveParams &p, hipStream_t stream) {
 bool solve_dx_supported(int nx, int nu, int N, bool const_tables) {
     if (!const_tables) return false;
 #define X(NX_, NU_, N_) \
-    if (nx == NX_ && nu == NU_ && N == N_) return dx_vl(NU_, N_, DX_WPG) >= 0;
+    if (nx == NX_ && nu == NU_ && N == N_) return dx_vl(NU_, N_, true, DX_WPG) >= 0;
     TINY_DX_SHAPES(X)
 #undef X
     return false;
