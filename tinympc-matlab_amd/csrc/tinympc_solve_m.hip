@@ -36,6 +36,11 @@ namespace tinympc {
 
 typedef double double4_m __attribute__((ext_vector_type(4)));
 
+// The barrier of a sweep step: only the LDS operand exchange crosses it (a lane's HBM state is read back by that lane alone),
+// so it must not wait for the step's global stores the way __syncthreads()' fence does -- that wait sat in front of every
+// GEMM.
+__device__ __forceinline__ void lds_exchange_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int M_INST = 16;       // instances per tile (the N dimension of the MFMA)
 constexpr int M_WAVES = 8;       // one 16-row output tile per wavefront (R <= 8)
 
@@ -81,6 +86,14 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     auto row_of = [&](int e) -> int { return rowbase + 4 * e; };
     auto kind_of = [&](int e) -> int { const int r = row_of(e); return !has_tile ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
     auto slot = [&](int e) -> unsigned { return (unsigned)((4 * wv + e) * 64 + lane); };  // offset of entry e inside a knot
+    bool isx[4], isu[4];
+    int kx[4];  // state rows own knot i + 1 of step i, input rows knot i
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        isx[e] = kind_of(e) == 1;
+        isu[e] = kind_of(e) == 2;
+        kx[e] = isx[e] ? 1 : 0;
+    }
     const double rho = p.rho;
     const int ct = p.check_termination;
     // lo / hi / linref of (row, knot): table row kn + 1
@@ -166,47 +179,51 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             // The row-local operands of this step (dual, old slack, the next step's feed-forward entry) do not depend on the
             // GEMM: they are requested first and arrive while the matrix cores work -- the state streams through HBM at these
             // sizes, and a step that waited for it AFTER its MFMAs ran at a fifth of this speed.
-            double pg[4], pv[4], pd[4];
+            // BRANCH-FREE on purpose: every lane of a wavefront that owns a row tile loads and stores all four of its entries
+            // (padding rows have slots of their own; lanes without a feed-forward entry all read one dummy address). With the
+            // loads inside `if (row is real)` regions the compiler put an s_waitcnt vmcnt(0) in front of every entry's address
+            // arithmetic -- four serialised HBM round trips per step instead of one.
+            double pg[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
+            unsigned okn[4] = {0u, 0u, 0u, 0u};
+            if (has_tile && TINY_EXP_M != 1) {
+                const bool more = i + 1 < T;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kd = kind_of(e);
-                pg[e] = pv[e] = pd[e] = 0.0;
-                if (kd != 0 && TINY_EXP_M != 1) {
-                    const unsigned o = (unsigned)((i + (kd == 1 ? 1 : 0)) * (int)KD) + slot(e);
-                    pg[e] = gG[o];
-                    pv[e] = Vr[o];
-                    if (kd == 2 && i + 1 < T) pd[e] = gD[(unsigned)((i + 1) * (int)KD) + slot(e)];
+                for (int e = 0; e < 4; ++e) {
+                    okn[e] = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
+                    pg[e] = gG[okn[e]];
+                    pv[e] = Vr[okn[e]];
+                    pd[e] = gD[(isu[e] && more) ? (unsigned)((i + 1) * (int)KD) + slot(e) : 0u];
                 }
             }
             double out[4];
             gemm(buf, start, out);  // state rows: x_{i+1}; input rows: u_i
+            if (has_tile) {
+                double gn[4], sn[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kd = kind_of(e);
-                if (kd != 0) {
-                    const int kn = i + (kd == 1 ? 1 : 0);
-                    const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
+                for (int e = 0; e < 4; ++e) {
+                    const int kn = i + kx[e];
                     const double s = out[e] + pg[e];
-                    const double snew = fmin(tab(1, kn, e), fmax(tab(0, kn, e), s));  // (bounds: L2-resident table)
+                    const double snew = fmin(tab(1, kn, e), fmax(tab(0, kn, e), s));  // (bounds: LDS copy, or the L2-resident table)
                     const double tp = fabs(out[e] - snew), td = fabs(pv[e] - snew);
-                    if (kd == 1) {
-                        pri_x = fmax(pri_x, tp);
-                        dua_x = fmax(dua_x, td);
-                    } else {
-                        pri_u = fmax(pri_u, tp);
-                        dua_u = fmax(dua_u, td);
+                    pri_x = fmax(pri_x, isx[e] ? tp : 0.0);
+                    dua_x = fmax(dua_x, isx[e] ? td : 0.0);
+                    pri_u = fmax(pri_u, isu[e] ? tp : 0.0);
+                    dua_u = fmax(dua_u, isu[e] ? td : 0.0);
+                    gn[e] = s - snew;
+                    sn[e] = snew;
+                    // next operand: state rows carry x_{i+1}, input rows bring d_{i+1}, padding rows stay zero
+                    sX[buf ^ 1][4 * wv + e][lane] = isu[e] ? pd[e] : (isx[e] ? out[e] : 0.0);
+                }
+                if (active && TINY_EXP_M != 1) {  // (one masked region, stores only)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gG[okn[e]] = gn[e];
+                        Vw[okn[e]] = sn[e];
                     }
-                    if (active && TINY_EXP_M != 1) {
-                        gG[o] = s - snew;
-                        Vw[o] = snew;
-                    }
-                    put(buf ^ 1, e, kd == 2 ? pd[e] : out[e]);  // next operand: state rows carry x_{i+1}, input rows bring d_{i+1}
-                } else {
-                    put(buf ^ 1, e, 0.0);
                 }
             }
             buf ^= 1;
-            __syncthreads();
+            lds_exchange_barrier();
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
@@ -261,29 +278,35 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         __syncthreads();
         for (int i = T - 1; i >= 0; --i) {
             // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM
-            double lin[4];
+            // (branch-free like the forward step: padding rows and the input rows of step 0 load their own slot and drop it)
+            double lv[4] = {0.0, 0.0, 0.0, 0.0}, lg[4] = {0.0, 0.0, 0.0, 0.0};
+            if (has_tile && TINY_EXP_M != 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kd = kind_of(e);
-                lin[e] = 0.0;
-                if ((kd == 1 || (kd == 2 && i >= 1)) && TINY_EXP_M != 1) {
-                    const int kn = kd == 1 ? i : i - 1;
+                for (int e = 0; e < 4; ++e) {
+                    const int kn = (isu[e] && i >= 1) ? i - 1 : i;
                     const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
-                    lin[e] = tab(2, kn, e) - rho * (Vn[o] - gG[o]);  // admm.cpp:77-80
+                    lv[e] = Vn[o];
+                    lg[e] = gG[o];
                 }
             }
             double out[4];
             gemm(buf, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
+            if (has_tile) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kd = kind_of(e);
-                double w = lin[e];
-                if (kd == 1) w = lin[e] + out[e];                                                      // p_i = q_i + ...
-                else if (kd == 2 && active && TINY_EXP_M != 1) gD[(unsigned)(i * (int)KD) + slot(e)] = out[e];  // d_i (a converged instance keeps its last real d)
-                put(buf ^ 1, e, w);
+                for (int e = 0; e < 4; ++e) {
+                    const int kn = (isu[e] && i >= 1) ? i - 1 : i;
+                    const bool real = isx[e] || (isu[e] && i >= 1);
+                    const double lin = (real && TINY_EXP_M != 1) ? tab(2, kn, e) - rho * (lv[e] - lg[e]) : 0.0;  // admm.cpp:77-80
+                    sX[buf ^ 1][4 * wv + e][lane] = isx[e] ? lin + out[e] : lin;                                   // p_i = q_i + ...
+                }
+                if (active && TINY_EXP_M != 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (isu[e]) gD[(unsigned)(i * (int)KD) + slot(e)] = out[e];  // d_i (a converged instance keeps its last real d)
+                }
             }
             buf ^= 1;
-            __syncthreads();
+            lds_exchange_barrier();
         }
     }
 
