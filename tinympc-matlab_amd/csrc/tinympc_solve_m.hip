@@ -29,7 +29,7 @@
 #include "tinympc_device.h"
 
 #ifndef TINY_EXP_M
-#define TINY_EXP_M 0  // timing experiments (tools/build_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs
+#define TINY_EXP_M 0  // timing experiments (tools/build_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs, 3 = cycle stamps of one forward step
 #endif
 
 namespace tinympc {
@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
     __shared__ unsigned sFlag[2][M_WAVES];                          // per-wave "instance still below tolerance" masks
     __shared__ double sTab[CT ? 3 : 1][128];                        // CT: lo | hi | linref of every row
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (an SGPR: branches on it are scalar branches, not EXEC-masked regions)
     const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu, T = N - 1;
     const int W = 128, KT = 128;  // ops / tables geometry of these sizes (choose_geometry_m)
     const long tile = blockIdx.x;
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     // this wave's result entries: e = 0..3 <-> reg = e, row = 16 wv + kq + 4 e. Rows and their kind are recomputed from
     // `rowbase` where they are needed (cheap integer work) instead of living in masks.
     const int rowbase = 16 * wv + kq;
-    const bool has_tile = wv < R;  // (uniform) this wave owns a row tile
+    const bool has_tile = (R == M_WAVES) || wv < R;  // (uniform) this wave owns a row tile
     auto row_of = [&](int e) -> int { return rowbase + 4 * e; };
     auto kind_of = [&](int e) -> int { const int r = row_of(e); return !has_tile ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
     auto slot = [&](int e) -> unsigned { return (unsigned)((4 * wv + e) * 64 + lane); };  // offset of entry e inside a knot
@@ -119,11 +120,33 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     auto gemm = [&](int buf, const double (&start)[4], double (&out)[4]) {
         double4_m c0 = {start[0], start[1], start[2], start[3]}, d0 = {0.0, 0.0, 0.0, 0.0};
         if (has_tile) {
+            // operand reads run a batch of eight k-blocks ahead of the matrix instructions that consume them (left to the
+            // scheduler they ran two ahead, and an MFMA issued every 78 cycles instead of every 64)
+            constexpr int BATCH = CT ? 8 : (R == 8 ? 2 : 4);  // (per-knot tables: fewer registers to spare)
+            static_assert(KB % 4 == 0, "k-blocks come in fours");
+            double b[2][BATCH];
 #pragma unroll
-            for (int kb = 0; kb < KB; kb += 2) {
-                const double b0 = sX[buf][kb][lane], b1 = sX[buf][kb + 1][lane];
-                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb], b0, c0, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[kb + 1], b1, d0, 0, 0, 0);
+            for (int q = 0; q < BATCH; ++q) b[0][q] = q < KB ? sX[buf][q][lane] : 0.0;
+#pragma unroll
+            for (int k0 = 0; k0 < KB; k0 += BATCH) {
+                const int cur = (k0 / BATCH) & 1;
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q)
+                    if (k0 + BATCH + q < KB) b[cur ^ 1][q] = sX[buf][k0 + BATCH + q][lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < BATCH; q += 2) {
+                    if (k0 + q < KB) {
+#if TINY_EXP_M == 2  // timing experiment: the operand reads without the matrix instructions
+                        c0[0] += A0[k0 + q] * b[cur][q];
+                        d0[0] += A0[k0 + q + 1] * b[cur][q + 1];
+#else
+                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[k0 + q], b[cur][q], c0, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[k0 + q + 1], b[cur][q + 1], d0, 0, 0, 0);
+#endif
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -175,28 +198,40 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             put(buf, e, w);
         }
         __syncthreads();
-        for (int i = 0; i < T; ++i) {
-            // The row-local operands of this step (dual, old slack, the next step's feed-forward entry) do not depend on the
-            // GEMM: they are requested first and arrive while the matrix cores work -- the state streams through HBM at these
-            // sizes, and a step that waited for it AFTER its MFMAs ran at a fifth of this speed.
-            // BRANCH-FREE on purpose: every lane of a wavefront that owns a row tile loads and stores all four of its entries
-            // (padding rows have slots of their own; lanes without a feed-forward entry all read one dummy address). With the
-            // loads inside `if (row is real)` regions the compiler put an s_waitcnt vmcnt(0) in front of every entry's address
-            // arithmetic -- four serialised HBM round trips per step instead of one.
-            double pg[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
-            unsigned okn[4] = {0u, 0u, 0u, 0u};
+        // The row-local operands of a step (dual, old slack, the next step's feed-forward entry) do not depend on its GEMM: they
+        // are requested in front of it and arrive while the matrix cores work -- the state streams through HBM at these sizes
+        // (the kernel without its MFMAs runs at the HBM roof), and a step that waited for its operands AFTER its MFMAs ran at
+        // a fifth of this speed. (Requesting them a whole step ahead, behind the previous step's row-local phase, was measured
+        // too: no faster, and it spills.)
+        // BRANCH-FREE on purpose: every lane of a wavefront that owns a row tile loads and stores all four of its entries
+        // (padding rows have slots of their own; lanes without a feed-forward entry all read one dummy address). With the
+        // loads inside `if (row is real)` regions the compiler put an s_waitcnt vmcnt(0) in front of every entry's address
+        // arithmetic -- four serialised HBM round trips per step instead of one.
+        double pg[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
+        auto fetch_fwd = [&](int i) {
             if (has_tile && TINY_EXP_M != 1) {
                 const bool more = i + 1 < T;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    okn[e] = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
-                    pg[e] = gG[okn[e]];
-                    pv[e] = Vr[okn[e]];
+                    const unsigned o = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
+                    pg[e] = gG[o];
+                    pv[e] = Vr[o];
                     pd[e] = gD[(isu[e] && more) ? (unsigned)((i + 1) * (int)KD) + slot(e) : 0u];
                 }
             }
+        };
+        for (int i = 0; i < T; ++i) {
+#if TINY_EXP_M == 3  // timing experiment: where does a forward step spend its cycles (tools/large_pmc.py prints the stamps)
+            const bool stamp = it == 5 && i == 7 && blockIdx.x == 1;
+            unsigned long long t_top = 0, t_gemm = 0, t_ops = 0, t_end = 0, t_bar = 0;
+            if (stamp) t_top = __builtin_readcyclecounter();
+#endif
+            fetch_fwd(i);
             double out[4];
             gemm(buf, start, out);  // state rows: x_{i+1}; input rows: u_i
+#if TINY_EXP_M == 3
+            if (stamp) { asm volatile("s_nop 0" :: "v"(out[0]), "v"(out[3])); t_gemm = __builtin_readcyclecounter(); }
+#endif
             if (has_tile) {
                 double gn[4], sn[4];
 #pragma unroll
@@ -211,19 +246,34 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
                     dua_u = fmax(dua_u, isu[e] ? td : 0.0);
                     gn[e] = s - snew;
                     sn[e] = snew;
+#if TINY_EXP_M == 3
+                    if (stamp && e == 3) { asm volatile("s_nop 0" :: "v"(gn[0]), "v"(gn[3])); t_ops = __builtin_readcyclecounter(); }
+#endif
                     // next operand: state rows carry x_{i+1}, input rows bring d_{i+1}, padding rows stay zero
                     sX[buf ^ 1][4 * wv + e][lane] = isu[e] ? pd[e] : (isx[e] ? out[e] : 0.0);
                 }
                 if (active && TINY_EXP_M != 1) {  // (one masked region, stores only)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        gG[okn[e]] = gn[e];
-                        Vw[okn[e]] = sn[e];
+                        const unsigned o = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
+                        gG[o] = gn[e];
+                        Vw[o] = sn[e];
                     }
                 }
             }
             buf ^= 1;
+#if TINY_EXP_M == 3
+            if (stamp) { asm volatile("s_nop 0" :: "v"(pri_x), "v"(dua_u)); t_end = __builtin_readcyclecounter(); }
+#endif
             lds_exchange_barrier();
+#if TINY_EXP_M == 3
+            if (stamp) {
+                t_bar = __builtin_readcyclecounter();
+                if (lane == 0)
+                    printf("wave %d: top %llu | gemm done +%llu | operands arrived, row-local math +%llu | stores issued, residuals +%llu | barrier +%llu\n", wv,
+                           t_top, t_gemm - t_top, t_ops - t_gemm, t_end - t_ops, t_bar - t_end);
+            }
+#endif
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
@@ -276,10 +326,10 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             }
         }
         __syncthreads();
-        for (int i = T - 1; i >= 0; --i) {
-            // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM
-            // (branch-free like the forward step: padding rows and the input rows of step 0 load their own slot and drop it)
-            double lv[4] = {0.0, 0.0, 0.0, 0.0}, lg[4] = {0.0, 0.0, 0.0, 0.0};
+        // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM like the
+        // forward operands (branch-free: padding rows and the input rows of step 0 load their own slot and drop it)
+        double lv[4] = {0.0, 0.0, 0.0, 0.0}, lg[4] = {0.0, 0.0, 0.0, 0.0};
+        auto fetch_bwd = [&](int i) {
             if (has_tile && TINY_EXP_M != 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -289,6 +339,9 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
                     lg[e] = gG[o];
                 }
             }
+        };
+        for (int i = T - 1; i >= 0; --i) {
+            fetch_bwd(i);
             double out[4];
             gemm(buf, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
             if (has_tile) {
