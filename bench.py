@@ -452,6 +452,8 @@ def main() -> int:
             out["large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (lnx, lnu, lN, lB, lit),
                                    "iters_per_s": lB * lit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": ltf, "fp64_frac": ltf / PEAK_FP64_TFLOPS,
                                    "hbm_algorithmic_gbs": lgb, "hbm_algorithmic_frac": lgb / PEAK_HBM_GBS, "layout": big.launch_info()["layout"],
+                                   "hbm_note": "algorithmic = SURVEY.md section 8d streaming model; the kernel's measured traffic is 130.5 KB per instance and "
+                                               "iteration (profiles/r02_large_pmc.json), about 2/3 of the model",
                                    "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)"}
             big.reset()
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
