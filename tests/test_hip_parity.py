@@ -83,7 +83,11 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     s.reset()
     monkeypatch.delenv("TINYMPC_JIT")
     s = make_solver(pkg, P.cartpole(120, True), {}, batch=2048)
-    assert s.launch_info()["layout"] in ("A", "B")  # N = 120 does not fit the register plan of layout D
+    info = s.launch_info()
+    assert info["layout"] == "D" and info["workgroups"] == 128  # N = 120: the plan with one wavefront per SIMD (four per workgroup)
+    s.reset()
+    s = make_solver(pkg, P.cartpole(250, True), {}, batch=2048)
+    assert s.launch_info()["layout"] in ("A", "B")  # N = 250 fits neither register plan of layout D
     s.reset()
     monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})
