@@ -431,6 +431,24 @@ def main() -> int:
                                   "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
                                   "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"]}
             wide.reset()
+            # Long horizon: the quadrotor at N = 100. The duals of 99 knots do not fit 256 registers, so layout D runs its second
+            # plan (one wavefront per SIMD with all 512 registers; the kernel is specialised at run time by tinympc_jit.hip).
+            hp = P.quadrotor(100)
+            hB, hit = 8192, 100
+            longh = pkg.TinyMPC()
+            longh.setup(hp.A, hp.B, hp.Q, hp.R, hp.N, batch=hB, device=local_rank, rho=hp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=hit)
+            longh.set_bound_constraints(hp.x_min, hp.x_max, hp.u_min, hp.u_max)
+            longh.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(hB)))
+            ms = []
+            for k in range(5):
+                longh.reset_workspace()
+                ms.append(longh.solve_timed())
+            med = sorted(ms[1:])[len(ms[1:]) // 2]
+            htf = hB * hit * hp.flops_per_iteration() / (med * 1e-3) / 1e12
+            out["long_horizon"] = {"workload": "quadrotor N=100, box constraints, %d instances x %d forced iterations" % (hB, hit),
+                                   "iters_per_s": hB * hit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": htf, "fp64_frac": htf / PEAK_FP64_TFLOPS,
+                                   "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"]}
+            longh.reset()
             # Large systems (64 < nx+nu <= 128): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
             # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
             lnx, lnu, lN, lB, lit = 96, 32, 20, 4096, 50
