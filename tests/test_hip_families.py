@@ -179,3 +179,52 @@ def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
         assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL
         assert rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL
     s.reset()
+
+
+@pytest.mark.parametrize("variant", ["cones", "linear", "both"])
+@pytest.mark.parametrize("N", [10, 20, 28])
+def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
+    """Short horizons, large batches: the families ride on the run-time specialised layout D (gc, gl, lx in registers next to
+    g and v; tinympc_jit.hip with -DTINY_JIT_FAM=1). The library's own choice; cold start and a warm start against the
+    restatement for every instance, then the same two solves on k_admm_solve_fam (TINYMPC_JIT=0)."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    P = pkg.problems
+    rk = P.rocket(N, with_linear=variant in ("linear", "both"))
+    if variant == "linear":
+        rk.cones = {}
+    settings = dict(max_iter=150, abs_pri_tol=2e-3, abs_dua_tol=1e-4)
+    batch = 1301  # beyond the latency kernel's range; ragged last wavefront and workgroup
+    rng = np.random.default_rng(N)
+    x0a = rk.x0[:, None] * rng.uniform(0.6, 1.2, (1, batch)) + 0.1 * rng.standard_normal((6, batch))
+    x0b = x0a + 0.05 * rng.standard_normal((6, batch))
+    results = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("TINYMPC_JIT", jit)
+        s = make(pkg, rk, settings, batch=batch)
+        out = []
+        for x0s in (x0a, x0b):
+            s.set_x0_batch(x0s)
+            s.solve()
+            out.append((s.get_solution_batch(), s.get_stats_batch()))
+        assert (s.launch_info()["layout"] == "D") == (jit == "1")  # (without it: k_admm_solve_fam, whatever the box path's layout)
+        results[jit] = out
+        s.reset()
+    orc = [oracle(rk, settings) for _ in range(batch)]
+    for rnd, x0s in enumerate((x0a, x0b)):
+        sol, st = results["1"][rnd]
+        for b in range(batch):
+            orc[b].set_x0(x0s[:, b])
+            orc[b].solve()
+        oit = np.array([o.stats()["iter"] for o in orc])
+        ost = np.array([o.stats()["status"] for o in orc])
+        np.testing.assert_array_equal(st["iter"], oit)
+        np.testing.assert_array_equal(st["status"], ost)
+        for b in range(0, batch, 7):
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL
+            assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL
+        sol0, st0 = results["0"][rnd]
+        np.testing.assert_array_equal(st["iter"], st0["iter"])
+        assert rel_err(sol["controls"], sol0["controls"]) < TOL and rel_err(sol["states"], sol0["states"]) < TOL
+    assert (results["1"][0][1]["status"] == 1).any() and (results["1"][1][1]["iter"] < results["1"][0][1]["iter"]).any()

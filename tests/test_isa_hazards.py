@@ -85,3 +85,21 @@ def test_run_time_specialisations_have_no_dpp_hazard(source, nx, nu, N, vreg, wp
         assert "vgpr_spill_count: 0" in text, "the specialisation spills"
     else:  # 512 registers: values beyond the 256 architectural ones sit in accumulation registers, counted as spills; no scratch
         assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"
+
+
+@pytest.mark.parametrize("nx,nu,N,vreg,ct", [(6, 3, 10, 9, 0), (6, 3, 20, 19, 1), (12, 4, 15, 14, 0)])
+def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, ct, tmp_path):
+    """Layout D with the cone / linear families (-DTINY_JIT_FAM=1, one wavefront per SIMD): the family code adds masked
+    mat-vecs (the same fused DPP chain) between the sweep blocks -- lint what hiprtc will build on the GPU box."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "jit_fam.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_VREG={vreg}",
+                    "-DTINY_JIT_WPS=1", f"-DTINY_JIT_CT={ct}", "-DTINY_JIT_FAM=1", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(CSRC, "tinympc_solve_d.hip")], check=True, timeout=900)
+    text = out.read_text()
+    checked, bad = _lint(text)
+    assert checked > 200 and not bad, bad[:3]
+    assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"

@@ -110,6 +110,7 @@ struct tinympc_solver {
     // adaptive rho / session.
     bool layout_m = false;
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
+    int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
     int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
@@ -160,7 +161,7 @@ struct tinympc_solver {
     bool tables_in_lds_a = false;
 
     bool use_layout_d() const {
-        return layout_d && (tables_const() || d_varying == 1) && !families_active() && !st.adaptive_rho;
+        return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && !st.adaptive_rho;
     }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
@@ -367,6 +368,11 @@ int launch(tinympc_solver *s, bool timed) {
     }
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
+    if (fam && s->layout_d && !adaptive) {
+        // families on a layout-D handle: is there a run-time specialisation (16-lane form, horizons whose five register pairs
+        // per knot fit)? Asked per launch -- the answer is cached inside -- because it also depends on the tables' kind.
+        s->d_fam = (s->W == 16 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+    }
     if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts
         if ((rc = flush_host_refs(s))) return rc;
     }
@@ -425,6 +431,9 @@ int launch(tinympc_solver *s, bool timed) {
         // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (fam && s->use_layout_d()) {
+        p.families = 1;
+        HIP_TRY(launch_solve_jit(p, s->W, s->stream));
     } else if (fam && s->fam_c) {
         // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
@@ -1445,7 +1454,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? (s->d_jit ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->d_varying != 1, s->groups) : solve_d_workgroups(s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active()) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : solve_d_workgroups(s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)(s->layout_c ? s->lds_bytes_c : s->lds_bytes);
     if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
     return TINYMPC_OK;

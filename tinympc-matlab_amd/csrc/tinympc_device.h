@@ -243,9 +243,9 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
-bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables);
+bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families = false);
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream);
-int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups);  // 8 wavefronts per workgroup, 4 on the long-horizon plan
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false);  // 8 wavefronts per workgroup, 4 on the long-horizon plan
 #endif  // !__HIPCC_RTC__
 
 // Doubles of working state per group in layout A (G and V with N+2 rows, D with 64 dummy slots).

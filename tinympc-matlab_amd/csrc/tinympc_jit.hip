@@ -44,7 +44,7 @@ struct JitPlan {
 //   VGPRs  2*(N-1) for the duals + 2*vreg for the register part of the slack + the operator row + ~76 for everything else
 //          must stay <= 256 (two wavefronts per SIMD);
 //   LDS    per wave (N-1-vreg) slack rows of 512 B + the feed-forward d, eight waves + the operators <= 160 KB.
-JitPlan plan_for(int W, int nx, int nu, int N, bool ct) {
+JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false) {
     JitPlan pl;
     const int nxu = nx + nu, ns = N - 1;
     if (N < 4 || nx < 1 || nu < 1) return pl;
@@ -53,11 +53,14 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct) {
     else if (W == 32 && nxu > 16 && nxu <= 32) { mregs = 64; ops_doubles = 2 * 32 * 32; d_doubles = ((ns * 2 * nu) + 1) & ~1; pl.source = "tinympc_solve_dw.hip"; }
     else if (W == 64 && nxu > 32 && nxu <= 64) { mregs = 128; ops_doubles = 2 * 64 * 64; d_doubles = ((ns * nu) + 1) & ~1; pl.source = "tinympc_solve_dx.hip"; }
     else return pl;
-    const int tab_doubles = ct ? 0 : 3 * (N + 2) * W + W;  // the workgroup's LDS copy of the per-knot tables
+    if (fam && W != 16) return pl;  // cone / linear families: 16-lane form only
+    const int tab_doubles = (ct ? 0 : 3 * (N + 2) * W + W) + (fam ? 3 * MAX_LIN_ROWS * 16 : 0);
+    // families: three more register pairs per knot (gc, gl, lx), the three mask rows (3 x 16 doubles) and their scalars
+    const int fam_regs = fam ? 6 * ns + 96 + 24 : 0;  // the workgroup's LDS copy of the per-knot tables
     // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
     // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
     for (int wps = 2; wps >= 1; --wps) {
-        const int budget = 256 * (3 - wps) - (wps == 2 ? 76 : 110) - (ct ? 0 : 8) - mregs - 2 * ns;
+        const int budget = 256 * (3 - wps) - (wps == 2 ? 76 : 110) - (ct ? 0 : 8) - mregs - 2 * ns - fam_regs;
         if (budget < 0) continue;
         int vreg = budget / 2;
         if (vreg > ns) vreg = ns;
@@ -130,7 +133,7 @@ struct JitKernel {
     int wpg = 8;  // wavefronts per workgroup
     std::vector<char> image;  // the code object stays alive as long as the module does
 };
-using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables
+using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables + 2 * families
 std::map<Key, JitKernel> &cache() {
     static std::map<Key, JitKernel> c;
     return c;
@@ -141,7 +144,7 @@ std::mutex &cache_mutex() {
 }
 
 // Compile (or fetch from the disk cache) the code object of one shape. Empty on failure; `why` says why.
-std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, const std::string &arch, bool use_disk_cache, std::string &why) {
+std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, bool fam, const std::string &arch, bool use_disk_cache, std::string &why) {
     const std::string sdir = source_dir(), idir = include_dir();
     const std::string spath = sdir + "/" + pl.source;
     if (!file_exists(spath) || !file_exists(sdir + "/tinympc_device.h")) {
@@ -154,7 +157,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     for (const char *dep : {"tinympc_device.h", "tinympc_sweep.h", "tinympc_solve_d_chain.h", "tinympc_solve_dw_chain.h", "tinympc_solve_dx_chain.h"})
         h = fnv1a(read_file(sdir + "/" + dep), h);
     char shape[160];
-    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d ct=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, (int)ct, arch.c_str());
+    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d ct=%d fam=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, (int)ct, (int)fam, arch.c_str());
     h = fnv1a(shape, h);
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
@@ -172,7 +175,8 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     std::vector<std::string> o = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-I" + sdir, "-I" + idir, "-DTINY_JIT=1",
                                   "-DTINY_JIT_NX=" + std::to_string(nx), "-DTINY_JIT_NU=" + std::to_string(nu),
                                   "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg),
-                                  "-DTINY_JIT_WPS=" + std::to_string(pl.wps), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0")};
+                                  "-DTINY_JIT_WPS=" + std::to_string(pl.wps), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0"),
+                                  std::string("-DTINY_JIT_FAM=") + (fam ? "1" : "0")};
     std::vector<const char *> opts;
     for (const auto &x : o) opts.push_back(x.c_str());
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -209,15 +213,15 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     return code;
 }
 
-JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
+JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(cache_mutex());
-    const Key key{dev, W, nx, nu, N, (int)ct};
+    const Key key{dev, W, nx, nu, N, (int)ct + 2 * (int)fam};
     auto it = cache().find(key);
     if (it != cache().end()) return it->second.failed ? nullptr : &it->second;
     JitKernel k;
-    const JitPlan pl = plan_for(W, nx, nu, N, ct);
+    const JitPlan pl = plan_for(W, nx, nu, N, ct, fam);
     std::string why;
     if (!pl.ok) {
         k.failed = true;
@@ -231,7 +235,7 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
         }
         // first the disk cache; an image from there that does not load (truncated file, other driver) is compiled again
         for (int attempt = 0; attempt < 2; ++attempt) {
-            k.image = build_code_object(pl, nx, nu, N, ct, arch, attempt == 0, why);
+            k.image = build_code_object(pl, nx, nu, N, ct, fam, arch, attempt == 0, why);
             k.failed = k.image.empty() || hipModuleLoadData(&k.mod, k.image.data()) != hipSuccess ||
                        hipModuleGetFunction(&k.fn, k.mod, "tinympc_jit_solve") != hipSuccess;
             if (!k.failed || k.image.empty()) break;
@@ -251,20 +255,20 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct) {
 
 }  // namespace
 
-bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables) {
+bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families) {
     if (!jit_enabled()) return false;
-    if (!plan_for(W, nx, nu, N, const_tables).ok) return false;
+    if (!plan_for(W, nx, nu, N, const_tables, families).ok) return false;
     // compile now, so that a failure is known before the layout is chosen
-    return get_kernel(W, nx, nu, N, const_tables) != nullptr;
+    return get_kernel(W, nx, nu, N, const_tables, families) != nullptr;
 }
 
-int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups) {
-    const int wpg = 4 * plan_for(W, nx, nu, N, const_tables).wps;
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families) {
+    const int wpg = 4 * plan_for(W, nx, nu, N, const_tables, families).wps;
     return (groups + wpg - 1) / wpg;
 }
 
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream) {
-    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0);
+    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0, p.families != 0);
     if (!k) return hipErrorInvalidValue;
     SolveParams arg = p;
     void *args[] = {&arg};

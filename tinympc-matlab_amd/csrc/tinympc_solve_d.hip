@@ -73,19 +73,20 @@ constexpr int D_VREG_MAX = 24;
 constexpr int D_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int d_d_doubles(int nu, int N) { return ((N - 1) * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int d_tab_doubles(int N) { return 3 * (N + 2) * 16 + 16; }
+constexpr int D_FAM_DOUBLES = 3 * MAX_LIN_ROWS * 16;  // FAM: a_k | b_k | 1/||a_k||^2 of the linear rows, per lane row
 // number of slack slots in LDS; -1 if the shape does not fit the plan (cu_waves wavefronts per CU: 8, or 4 for the
 // long-horizon plan with one wavefront per SIMD and 512 registers)
-__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8) {
+__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8, bool fam = false) {
     const int ns = N - 1;
-    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / cu_waves - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N));
+    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / cu_waves - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N)) - (fam ? D_FAM_DOUBLES : 0);
     const int wave_doubles = wg_doubles / wpg - d_d_doubles(nu, N);
     if (wave_doubles < 0) return -1;
     const int vlmax = wave_doubles / 64;
     const int want = ns > D_VREG_MAX ? ns - D_VREG_MAX : 0;
     return want <= vlmax ? want : -1;
 }
-__host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg, int vl) {
-    return sizeof(double) * ((size_t)D_OPS_DOUBLES + (ct ? 0 : d_tab_doubles(N)) + (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
+__host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg, int vl, bool fam = false) {
+    return sizeof(double) * ((size_t)D_OPS_DOUBLES + (ct ? 0 : d_tab_doubles(N)) + (fam ? D_FAM_DOUBLES : 0) + (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
 }
 
 // LDS traffic of the sweeps goes through asm volatile so that WHERE a read is issued is this file's decision, not the
@@ -132,7 +133,11 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
     return any;
 }
 
-template <int NX, int NU, int N, bool CT, int WPG, int VL>
+// FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there) ride on
+// the forward step exactly as in the latency kernel (tinympc_solve_c.hip): every knot carries two more duals gc|yc, gl|yl
+// (persistent: the HBM arrays GC / GL) and the families' linear-cost term lx (forward -> backward), all in registers.
+// Run-time specialised only (tinympc_jit.hip, -DTINY_JIT_FAM=1): 10 VGPRs per knot instead of 4, so short horizons.
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false>
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
@@ -153,7 +158,8 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
     double *sOps = smem;
     double *sT = smem + D_OPS_DOUBLES;
-    double *sV = sT + (CT ? 0 : d_tab_doubles(N)) + (size_t)wv * (VL * 64 + d_d_doubles(NU, N));
+    double *sLin = sT + (CT ? 0 : d_tab_doubles(N));  // FAM
+    double *sV = sLin + (FAM ? D_FAM_DOUBLES : 0) + (size_t)wv * (VL * 64 + d_d_doubles(NU, N));
     double *sD = sV + VL * 64;
 
     // ---- workgroup-shared: the two sweep operators, transposed to [k][r] (conflict-free row reads), and the tables
@@ -163,6 +169,14 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     }
     if constexpr (!CT)
         for (int i = threadIdx.x; i < d_tab_doubles(N); i += 64 * WPG) sT[i] = p.tables[i];
+    if constexpr (FAM) {  // layout of fam_doubles(): ... | nl | per linear row k: a_k[W] b_k[W] ||a_k||^2[W]
+        const double *lin_rows = p.fam + 4 * W + (size_t)3 * W * KT;
+        for (int i = threadIdx.x; i < D_FAM_DOUBLES; i += 64 * WPG) {
+            const int k3 = i / W, rr = i % W;
+            const double v = lin_rows[1 + (size_t)k3 * W + rr];
+            sLin[i] = (k3 % 3 == 2) ? 1.0 / v : v;  // 1 / ||a_k||^2
+        }
+    }
 
     const size_t g0 = grp_ok ? (size_t)grp : 0;
     double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
@@ -184,6 +198,72 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     static_for<0, NVR>([&](auto S) { Vr[S.value] = gV0[(VL + S.value + koff) * 64]; });
     G0 = gG[0];
     V0 = gV0[0];
+    // FAM state: slot s <-> knot s + koff, like G / V (the arrays GC / GL have V's shape)
+    double GCr[FAM ? NS : 1], GLr[FAM ? NS : 1], LX[FAM ? NS : 1], GC0 = 0.0, GL0 = 0.0;
+    double cn[KT], ct_[KT], ty[KT];
+    int role = 0, nl = 0;
+    double mu = 0.0, inv_mu = 0.0;
+    bool famc = false, faml = false, any_cone = false, any_lin = false;
+    if constexpr (FAM) {
+        const double *const gGC = p.GC + (g0 * v_rows(N) + V_PAD) * 64 + lane, *const gGL = p.GL + (g0 * v_rows(N) + V_PAD) * 64 + lane;
+        static_for<0, NS>([&](auto S) {
+            GCr[S.value] = gGC[(S.value + koff) * 64];
+            GLr[S.value] = gGL[(S.value + koff) * 64];
+            LX[S.value] = 0.0;
+        });
+        GC0 = gGC[0];
+        GL0 = gGL[0];
+        const double *Cn = p.fam + 4 * W + (size_t)r * KT, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            cn[k] = Cn[k];
+            ct_[k] = Ct[k];
+            ty[k] = Ty[k];
+        }
+        role = (int)p.fam[r];
+        mu = p.fam[W + r];
+        inv_mu = (mu != 0.0) ? 1.0 / mu : 0.0;  // (mu = 0: row in no cone)
+        famc = p.fam[2 * W + r] != 0.0;
+        faml = p.fam[3 * W + r] != 0.0;
+        nl = (int)p.fam[4 * W + (size_t)3 * W * KT];
+        any_cone = __ballot(famc) != 0ull;  // the same in every 16-lane row
+        any_lin = __ballot(faml) != 0ull;
+    }
+    // One (row, knot) element of the two extra families, exactly as in k_admm_solve_fam / k_admm_solve_c: returns the element's
+    // contribution to the linear cost and the new duals. All 16 lanes of the instance take part (no EXEC masking in this kernel).
+    auto families = [&](double val, double gc_old, double gl_old, double &gc_new, double &gl_new) -> double {
+        double lxv = 0.0;
+        gc_new = gc_old;
+        gl_new = gl_old;
+        if (any_cone) {
+            const double sv = val + gc_old;
+            const double a2 = group_matvec<W, KT>(cn, sv * sv, 0.0);
+            const double t = group_matvec<W, KT>(ct_, sv, 0.0);
+            const double vc = soc_project_element(sv, a2, t, mu, inv_mu, role);
+            const double gcn = sv - vc;
+            if (famc) {
+                gc_new = gcn;
+                lxv -= p.rho * (vc - gcn);
+            }
+        }
+        if (any_lin) {
+            const double s0 = val + gl_old;
+            double sv = s0;
+#pragma unroll 1
+            for (int k = 0; k < nl; ++k) {  // (uniform trip count)
+                const double a_k = sLin[(3 * k + 0) * W + r], b_k = sLin[(3 * k + 1) * W + r], in_k = sLin[(3 * k + 2) * W + r];
+                const double dot = group_matvec<W, KT>(ty, a_k * sv, 0.0);
+                sv = halfspace_project_element(sv, dot, a_k, b_k, in_k);
+            }
+            const double gln = s0 - sv;
+            if (faml) {
+                gl_new = gln;
+                lxv -= p.rho * (sv - gln);
+            }
+        }
+        return lxv;
+    };
+    const bool row_ok = r < NXU;
 
     const double cf = p.ops[(size_t)2 * W * KT + r];
     const double cb = p.ops[(size_t)2 * W * KT + W + r];
@@ -256,6 +336,18 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                     wV[s * 64] = vn;
                     wS[s * sst] = vn;
                 });
+                if constexpr (FAM) {
+                    double *const wGC = p.GC + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;
+                    double *const wGL = p.GL + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;
+                    static_for<0, NS>([&](auto S) {
+                        wGC[S.value * 64] = GCr[S.value];
+                        wGL[S.value * 64] = GLr[S.value];
+                    });
+                    if (x_o) {
+                        wGC[-64] = GC0;
+                        wGL[-64] = GL0;
+                    }
+                }
                 if (!x_o) {
                     double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
                     for (int i = 0; i < NS; ++i) wD[i * DS] = sDw[i * DS];
@@ -281,6 +373,14 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             pri = is_x ? fabs(x0v - snew) : 0.0;
             dua = is_x ? fabs(V0 - snew) : 0.0;
             V0 = snew;
+        }
+        if constexpr (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
+            double gcn, gln;
+            (void)families(x0v, GC0, GL0, gcn, gln);
+            if (is_x) {
+                GC0 = gcn;
+                GL0 = gln;
+            }
         }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
         // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
@@ -310,6 +410,15 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 double vnew;
                 xcur = Step::fwd_lds(xcur, dcur, m, cf, locur, hicur, G[q], vcur, vnew, pri, dua);
                 lds_write_async<q * 512>(aV, vnew);
+            }
+            if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                double gcn, gln;
+                const double l = families(xcur, GCr[q], GLr[q], gcn, gln);
+                if (row_ok) {
+                    GCr[q] = gcn;
+                    GLr[q] = gln;
+                    LX[q] = l;
+                }
             }
             dcur = dn;
             vcur = vn;
@@ -360,13 +469,17 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         {
             const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
             load_ops(sMb, m);
-            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type)
-                if constexpr (CT) return lr_c;
-                else return sTl[2 * TOFF + (S.value + 1) * W];
+            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type) (+ the families' term)
+                double base;
+                if constexpr (CT) base = lr_c;
+                else base = sTl[2 * TOFF + (S.value + 1) * W];
+                if constexpr (FAM) base += LX[S.value];
+                return base;
             };
             double px, rcur, rnext, acc;
             {   // p_{N-1} (state lanes, admm.cpp:81-82) | r_{N-2} (input lanes) share slot NS-1; then slot NS-2
-                const double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
+                double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
+                if constexpr (FAM) lrT = is_x ? pnref + LX[NS - 1] : lrT;
                 const double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 const double v1 = vget(std::integral_constant<int, NS - 1>{}), v2 = vget(std::integral_constant<int, NS - 2>{});
@@ -462,10 +575,14 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
 #endif
     constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
     constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
-    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ);
+#ifndef TINY_JIT_FAM
+#define TINY_JIT_FAM 0
+#endif
+    constexpr bool FAMJ = TINY_JIT_FAM != 0;  // cone / linear-inequality families
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ, FAMJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ) / sizeof(double)];
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ>(p, smem_jit);
 }
 namespace tinympc {
 #else
