@@ -334,11 +334,24 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             }
         }
         double acc = 0.0;
-        if (is_x) {
+        if constexpr (SESSION) {  // (the resident variants have no registers to spare; a full refresh is their rare path)
+            if (is_x) {
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
+                    if (q < nx) acc += sRef[q + (N - 1) * nx] * p.Pinf[q + (size_t)r * nx];
+                acc = -acc;
+            }
+        } else {
+            // the row's Pinf entries are requested all at once, clamped instead of guarded: with the loads inside `if (q < nx)`
+            // they went out one by one, each behind an s_waitcnt for the previous -- nx serial L2 round trips per tick
+            double pin[CW];
+            const int rr = is_x ? r : 0;
+#pragma unroll
+            for (int q = 0; q < CW; ++q) pin[q] = p.Pinf[(q < nx ? q : 0) + (size_t)rr * nx];
 #pragma unroll
             for (int q = 0; q < CW; ++q)
-                if (q < nx) acc += sRef[q + (N - 1) * nx] * p.Pinf[q + (size_t)r * nx];
-            acc = -acc;
+                if (q < nx) acc += sRef[q + (N - 1) * nx] * pin[q];
+            acc = is_x ? -acc : 0.0;
         }
         pnref = acc;
         if (k0) tab[(size_t)2 * TOFF + (size_t)CW + r] = -(sRef[r] * dg_r);
