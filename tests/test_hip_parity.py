@@ -632,6 +632,49 @@ def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     b.reset()
 
 
+@pytest.mark.parametrize("case", ["varying_tables", "families"])
+def test_first_tick_on_a_layout_d_variant_that_is_decided_late(pkg, kernel_layout, monkeypatch, case):
+    """Layout D's per-knot-table and family variants are specialised when first needed. The batched tick asks "layout D?" before
+    it launches (small batches exchange x0 / u0 through pinned memory on the other layouts only): the answer must not change
+    between that question and the launch, also on the very first tick (TINYMPC_LAYOUT=D forces layout D on a small batch)."""
+    if kernel_layout != "D":
+        pytest.skip("layout D only")
+    P = pkg.problems
+    batch = 64
+    if case == "families":
+        prob = P.rocket(10)
+    else:
+        prob = P.quadrotor(20)
+        rng = np.random.default_rng(4)
+        prob.x_ref = 0.05 * rng.standard_normal((prob.nx, prob.N))
+        prob.u_ref = 0.02 * rng.standard_normal((prob.nu, prob.N - 1))
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=40)
+
+    def build():
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, **settings)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        s.set_x_ref(prob.x_ref)
+        s.set_u_ref(prob.u_ref)
+        if case == "families":
+            s.set_cone_constraints(**prob.cones)
+            s.set_linear_constraints(**prob.linear)
+        return s
+
+    a, b = build(), build()
+    x = np.repeat(prob.x0[:, None], batch, axis=1) * np.linspace(0.6, 1.0, batch)[None, :]
+    f = prob.fdyn[:, None] if prob.fdyn is not None else 0.0
+    for _ in range(3):
+        ua = a.mpc_step(x)
+        b.set_x0_batch(x)
+        b.solve()
+        np.testing.assert_array_equal(ua, b.get_first_controls_batch())
+        assert a.launch_info()["layout"] == "D" and b.launch_info()["layout"] == "D"
+        x = prob.A @ x + prob.B @ ua + f
+    a.reset()
+    b.reset()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_randomized_problems(pkg, seed):
     """Random stable-ish systems: random nx, nu (all W=16 register widths), horizons on both sides of the

@@ -353,12 +353,14 @@ void arm_completion_flag(tinympc_solver *s, SolveParams &p) {
     s->flag_pending = true;
 }
 
-int launch(tinympc_solver *s, bool timed) {
-    int rc;
-    s->flag_pending = false;
-    if (s->layout_d && s->d_varying < 0 && !s->tables_const()) {
-        // first launch with time-varying tables on a layout-D handle: is there a kernel for that (compiled in -- 16-lane
-        // form only -- or specialised now)? Otherwise these launches run on layout B / A, as before.
+// Layout D's variants beyond the constant-table box path are decided when first needed (they may have to be specialised,
+// which takes seconds): time-varying tables and the cone / linear families. Called by everything that asks use_layout_d()
+// before a launch, so that the answer does not change between that question and the launch itself.
+void decide_layout_d_variants(tinympc_solver *s) {
+    if (!s->layout_d) return;
+    if (s->d_varying < 0 && !s->tables_const()) {
+        // is there a kernel for per-knot tables (compiled in -- 16-lane form only -- or specialised now)? Otherwise these launches
+        // run on layout B / A, as before.
         if (s->W == 16 && !s->d_jit && solve_d_supported(s->nx, s->nu, s->N, false)) {
             s->d_varying = 1;
         } else {
@@ -366,13 +368,19 @@ int launch(tinympc_solver *s, bool timed) {
             s->d_varying = s->d_varying_jit ? 1 : 0;
         }
     }
-    const bool fam = s->families_active();
-    const bool adaptive = s->st.adaptive_rho != 0;
-    if (fam && s->layout_d && !adaptive) {
-        // families on a layout-D handle: is there a run-time specialisation (16-lane form, horizons whose five register pairs
-        // per knot fit)? Asked per launch -- the answer is cached inside -- because it also depends on the tables' kind.
+    if (s->families_active() && !s->st.adaptive_rho) {
+        // families: a run-time specialisation (16-lane form, horizons whose five register pairs per knot fit)? Asked every
+        // time -- the answer is cached inside -- because it also depends on the tables' kind.
         s->d_fam = (s->W == 16 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
     }
+}
+
+int launch(tinympc_solver *s, bool timed) {
+    int rc;
+    s->flag_pending = false;
+    decide_layout_d_variants(s);
+    const bool fam = s->families_active();
+    const bool adaptive = s->st.adaptive_rho != 0;
     if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts
         if ((rc = flush_host_refs(s))) return rc;
     }
@@ -940,6 +948,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         s->host_sol_state = 2;
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
+    decide_layout_d_variants(s);
     if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->layout_m) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
