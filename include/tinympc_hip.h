@@ -274,7 +274,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
 
 /* Which solve kernel the handle uses for box-constrained solves: 'A' (all ADMM state in LDS, one wavefront per
  * workgroup), 'B' (V L2-resident in HBM, four wavefronts per workgroup; large batches) or 'C' (one instance per
- * workgroup, horizon swept in 16 concurrent chunks; batches up to 1,024 and every single solve). The
+ * workgroup, horizon swept in 16 concurrent chunks; batches up to 768 and every single solve). The
  * environment variable TINYMPC_LAYOUT=A|B|C overrides the choice at setup. 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
 

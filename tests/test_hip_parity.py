@@ -70,11 +70,11 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     s.reset()
     s = make_solver(pkg, P.quadrotor(50), {}, batch=2048)
     info = s.launch_info()
-    assert info["layout"] == "D" and info["workgroups"] == 64  # large batch of a compiled-in shape: two waves per SIMD
+    assert info["layout"] == "D" and info["workgroups"] == 128  # large batch of a compiled-in shape: workgroups of four wavefronts
     s.reset()
     s = make_solver(pkg, P.quadrotor(40), {}, batch=2048)
     info = s.launch_info()
-    assert info["layout"] == "D" and info["workgroups"] == 64  # other shapes that fit the plan: layout D specialised at run time
+    assert info["layout"] == "D" and info["workgroups"] == 128  # other shapes that fit the plan: layout D specialised at run time
     s.reset()
     monkeypatch.setenv("TINYMPC_JIT", "0")
     s = make_solver(pkg, P.quadrotor(40), {}, batch=2048)

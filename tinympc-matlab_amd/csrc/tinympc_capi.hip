@@ -66,7 +66,8 @@ constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
 // mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
 // GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
-constexpr int kLayoutCBatchMax = 1024;  // above this the batch-oriented layouts win (profiles/r01d_layout_sweep.txt)
+constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
+                                       // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
 
 }  // namespace
 
@@ -1463,7 +1464,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active()) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : solve_d_workgroups(s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active()) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) *lds_bytes = (int)(s->layout_c ? s->lds_bytes_c : s->lds_bytes);
     if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
     return TINYMPC_OK;

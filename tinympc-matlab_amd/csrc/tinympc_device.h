@@ -203,13 +203,15 @@ constexpr int WAVES_PER_GROUP_B = 4;
 // per SIMD. Only for the (nx, nu, N) shapes compiled into the library and time-invariant bounds / references.
 bool solve_d_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream);
-int solve_d_workgroups(int groups);
+int solve_d_workgroups(int nu, int N, bool const_tables, int groups);
 // ... and its 32-lanes-per-instance form for wide systems (16 < nx+nu <= 32), tinympc_solve_dw.hip
 bool solve_dw_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_dw(const SolveParams &p, hipStream_t stream);
+int solve_dw_workgroups(int nu, int N, int groups);
 // ... and with 64 lanes per instance (32 < nx+nu <= 64), tinympc_solve_dx.hip
 bool solve_dx_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_dx(const SolveParams &p, hipStream_t stream);
+int solve_dx_workgroups(int nu, int N, int groups);
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 // Layout C: one instance per 256-thread workgroup, the horizon swept in 16 concurrent chunks (latency kernel

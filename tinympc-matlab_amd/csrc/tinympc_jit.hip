@@ -37,6 +37,7 @@ struct JitPlan {
     bool ok = false;
     int vreg = 0;  // slack knots kept in registers
     int wps = 2;   // wavefronts per SIMD: 2 (256 registers each), or 1 (512 registers) for long horizons
+    int wpg = 8;   // wavefronts per workgroup: 4 where the LDS plan allows it (spreads mid-size batches over the CUs), else 8
     const char *source = nullptr;
 };
 
@@ -59,18 +60,22 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false) {
     const int fam_regs = fam ? 6 * ns + 96 + 24 : 0;  // the workgroup's LDS copy of the per-knot tables
     // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
     // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
-    for (int wps = 2; wps >= 1; --wps) {
+    static const int cand[3][2] = {{2, 4}, {2, 8}, {1, 4}};  // (wavefronts per SIMD, per workgroup), in order of preference
+    for (const auto &c : cand) {
+        const int wps = c[0], wpg = c[1];
         const int budget = 256 * (3 - wps) - (wps == 2 ? 76 : 110) - (ct ? 0 : 8) - mregs - 2 * ns - fam_regs;
         if (budget < 0) continue;
         int vreg = budget / 2;
         if (vreg > ns) vreg = ns;
-        const int wave_doubles = (160 * 1024 / 8 - ops_doubles - tab_doubles) / (4 * wps) - d_doubles;
+        // the workgroup's LDS share: wpg of the 4 * wps wavefronts a CU holds
+        const int wave_doubles = (160 * 1024 / 8 * wpg / (4 * wps) - ops_doubles - tab_doubles) / wpg - d_doubles;
         if (wave_doubles < 0) continue;
         const int vlmax = wave_doubles / 64;
         if (ns - vreg > vlmax) continue;  // the LDS part of the slack does not fit
         pl.ok = true;
         pl.vreg = vreg;
         pl.wps = wps;
+        pl.wpg = wpg;
         return pl;
     }
     return pl;
@@ -157,7 +162,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     for (const char *dep : {"tinympc_device.h", "tinympc_sweep.h", "tinympc_solve_d_chain.h", "tinympc_solve_dw_chain.h", "tinympc_solve_dx_chain.h"})
         h = fnv1a(read_file(sdir + "/" + dep), h);
     char shape[160];
-    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d ct=%d fam=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, (int)ct, (int)fam, arch.c_str());
+    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d wpg=%d ct=%d fam=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, pl.wpg, (int)ct, (int)fam, arch.c_str());
     h = fnv1a(shape, h);
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
@@ -175,7 +180,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     std::vector<std::string> o = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-I" + sdir, "-I" + idir, "-DTINY_JIT=1",
                                   "-DTINY_JIT_NX=" + std::to_string(nx), "-DTINY_JIT_NU=" + std::to_string(nu),
                                   "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg),
-                                  "-DTINY_JIT_WPS=" + std::to_string(pl.wps), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0"),
+                                  "-DTINY_JIT_WPS=" + std::to_string(pl.wps), "-DTINY_JIT_WPG=" + std::to_string(pl.wpg), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0"),
                                   std::string("-DTINY_JIT_FAM=") + (fam ? "1" : "0")};
     std::vector<const char *> opts;
     for (const auto &x : o) opts.push_back(x.c_str());
@@ -244,7 +249,7 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false) {
             k.mod = nullptr;
             k.fn = nullptr;
         }
-        k.wpg = 4 * pl.wps;
+        k.wpg = pl.wpg;
         if (k.failed && why.empty()) why = "loading the compiled module failed";
     }
     if (k.failed && !why.empty() && getenv("TINYMPC_JIT_VERBOSE"))
@@ -263,7 +268,7 @@ bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool f
 }
 
 int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families) {
-    const int wpg = 4 * plan_for(W, nx, nu, N, const_tables, families).wps;
+    const int wpg = plan_for(W, nx, nu, N, const_tables, families).wpg;
     return (groups + wpg - 1) / wpg;
 }
 

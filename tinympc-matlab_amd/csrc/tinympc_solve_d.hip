@@ -568,18 +568,21 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 #ifndef TINY_JIT_WPS
 #define TINY_JIT_WPS 2  // wavefronts per SIMD: 2 (256 registers each), or 1 (512) for horizons whose duals need them
 #endif
-extern "C" __global__ void __launch_bounds__(256 * TINY_JIT_WPS) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
+#ifndef TINY_JIT_WPG
+#define TINY_JIT_WPG (4 * TINY_JIT_WPS)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
 #ifndef TINY_JIT_CT
 #define TINY_JIT_CT 1
 #endif
     constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
-    constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
+    constexpr int WPGJ = TINY_JIT_WPG;  // wavefronts per workgroup (4, or 8 where only that LDS plan fits)
 #ifndef TINY_JIT_FAM
 #define TINY_JIT_FAM 0
 #endif
     constexpr bool FAMJ = TINY_JIT_FAM != 0;  // cone / linear-inequality families
-    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ, FAMJ);
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
     __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ) / sizeof(double)];
     tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ>(p, smem_jit);
@@ -589,21 +592,26 @@ namespace tinympc {
 // ------------------------------------------------------------------------------------------------------------
 // Host side: the instantiation table. A shape runs on layout D only if it was compiled in.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int D_WPG = 8;
+// Wavefronts per workgroup: four where the LDS plan allows it, else eight. Small workgroups spread a batch over the CUs
+// wavefront by wavefront: 4,096 quadrotor instances are 1,024 wavefronts = 256 workgroups of four = ONE wavefront per SIMD on
+// every CU (6.4 us per iteration, 634 M iterations/s), where 128 workgroups of eight filled half the chip with two wavefronts
+// per SIMD (10.1 us, 406 M); full batches gain a few percent from the finer tail (profiles/r02_layout_sweep.txt).
+__host__ __device__ constexpr int d_wpg(int nu, int N, bool ct) { return d_vl(nu, N, ct, 4) >= 0 ? 4 : 8; }
 
 template <int NX, int NU, int N, bool CT>
 static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
-    constexpr int VL = d_vl(NU, N, CT, D_WPG);
+    constexpr int WPG = d_wpg(NU, N, CT);
+    constexpr int VL = d_vl(NU, N, CT, WPG);
     if constexpr (VL < 0) {
         return hipErrorInvalidValue;
     } else {
-        constexpr size_t lds = d_lds_bytes(NU, N, CT, D_WPG, VL);
+        constexpr size_t lds = d_lds_bytes(NU, N, CT, WPG, VL);
         static size_t lds_set[16] = {0};
-        auto fn = &k_admm_solve_d<NX, NU, N, CT, D_WPG, VL>;
+        auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL>;
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
         if (e != hipSuccess) return e;
-        const int wgs = (p.groups + D_WPG - 1) / D_WPG;
-        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * D_WPG), lds, stream, p);
+        const int wgs = (p.groups + WPG - 1) / WPG;
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * WPG), lds, stream, p);
         return hipGetLastError();
     }
 }
@@ -615,7 +623,7 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
 
 bool solve_d_supported(int nx, int nu, int N, bool const_tables) {
 #define X(NX_, NU_, N_) \
-    if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, const_tables, D_WPG) >= 0;
+    if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, const_tables, d_wpg(NU_, N_, const_tables)) >= 0;
     TINY_D_SHAPES(X)
 #undef X
     return false;
@@ -630,7 +638,10 @@ hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
-int solve_d_workgroups(int groups) { return (groups + D_WPG - 1) / D_WPG; }
+int solve_d_workgroups(int nu, int N, bool const_tables, int groups) {
+    const int wpg = d_wpg(nu, N, const_tables);
+    return (groups + wpg - 1) / wpg;
+}
 
 #endif  // TINY_JIT
 

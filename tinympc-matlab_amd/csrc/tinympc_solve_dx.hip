@@ -435,14 +435,17 @@ __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2
 #ifndef TINY_JIT_WPS
 #define TINY_JIT_WPS 2  // wavefronts per SIMD: 2 (256 registers each), or 1 (512) for horizons whose duals need them
 #endif
-extern "C" __global__ void __launch_bounds__(256 * TINY_JIT_WPS) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
+#ifndef TINY_JIT_WPG
+#define TINY_JIT_WPG (4 * TINY_JIT_WPS)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_WPS, TINY_JIT_WPS)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
 #ifndef TINY_JIT_CT
 #define TINY_JIT_CT 1
 #endif
     constexpr bool CTJ = TINY_JIT_CT != 0;  // bounds / references constant over the horizon
-    constexpr int WPGJ = 4 * TINY_JIT_WPS;  // one workgroup per CU
-    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, WPGJ);
+    constexpr int WPGJ = TINY_JIT_WPG;  // wavefronts per workgroup (4, or 8 where only that LDS plan fits)
+    constexpr int VLJ = tinympc::dx_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
     __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::dx_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double)];
     tinympc::k_admm_solve_dx_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ>(p, smem_jit);
@@ -452,21 +455,22 @@ namespace tinympc {
 // ------------------------------------------------------------------------------------------------------------
 // Host side: the instantiation table.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int DX_WPG = 8;
+__host__ __device__ constexpr int dx_wpg(int nu, int N) { return dx_vl(nu, N, true, 4) >= 0 ? 4 : 8; }  // (see d_wpg in tinympc_solve_d.hip)
 
 template <int NX, int NU, int N>
 static hipError_t launch_dx_one(const SolveParams &p, hipStream_t stream) {
-    constexpr int VL = dx_vl(NU, N, true, DX_WPG);
+    constexpr int WPG = dx_wpg(NU, N);
+    constexpr int VL = dx_vl(NU, N, true, WPG);
     if constexpr (VL < 0) {
         return hipErrorInvalidValue;
     } else {
-        constexpr size_t lds = dx_lds_bytes(NU, N, true, DX_WPG, VL);
+        constexpr size_t lds = dx_lds_bytes(NU, N, true, WPG, VL);
         static size_t lds_set[16] = {0};
-        auto fn = &k_admm_solve_dx<NX, NU, N, DX_WPG, VL>;
+        auto fn = &k_admm_solve_dx<NX, NU, N, WPG, VL>;
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
         if (e != hipSuccess) return e;
-        const int wgs = (p.groups + DX_WPG - 1) / DX_WPG;
-        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * DX_WPG), lds, stream, p);
+        const int wgs = (p.groups + WPG - 1) / WPG;
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * WPG), lds, stream, p);
         return hipGetLastError();
     }
 }
@@ -478,10 +482,15 @@ static hipError_t launch_dx_one(const SolveParams &p, hipStream_t stream) {
 bool solve_dx_supported(int nx, int nu, int N, bool const_tables) {
     if (!const_tables) return false;
 #define X(NX_, NU_, N_) \
-    if (nx == NX_ && nu == NU_ && N == N_) return dx_vl(NU_, N_, true, DX_WPG) >= 0;
+    if (nx == NX_ && nu == NU_ && N == N_) return dx_vl(NU_, N_, true, dx_wpg(NU_, N_)) >= 0;
     TINY_DX_SHAPES(X)
 #undef X
     return false;
+}
+
+int solve_dx_workgroups(int nu, int N, int groups) {
+    const int wpg = dx_wpg(nu, N);
+    return (groups + wpg - 1) / wpg;
 }
 
 hipError_t launch_solve_dx(const SolveParams &p, hipStream_t stream) {
