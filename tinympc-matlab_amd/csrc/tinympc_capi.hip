@@ -1464,8 +1464,16 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active()) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
-    if (lds_bytes) *lds_bytes = (int)(s->layout_c ? s->lds_bytes_c : s->lds_bytes);
+    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (lds_bytes) {
+        size_t l = s->layout_c ? s->lds_bytes_c : s->lds_bytes;
+        if (s->layout_m) l = 0;  // (static LDS: see the kernel)
+        else if (s->use_layout_d())
+            l = (s->d_jit || s->families_active() || (!s->tables_const() && s->d_varying_jit))
+                    ? solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, s->tables_const(), s->families_active())
+                    : s->W == 64 ? solve_dx_lds_bytes(s->nu, s->N) : s->W == 32 ? solve_dw_lds_bytes(s->nu, s->N) : solve_d_lds_bytes(s->nu, s->N, s->tables_const());
+        *lds_bytes = (int)l;
+    }
     if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
     return TINYMPC_OK;
 }

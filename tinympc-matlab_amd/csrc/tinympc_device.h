@@ -204,14 +204,17 @@ constexpr int WAVES_PER_GROUP_B = 4;
 bool solve_d_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream);
 int solve_d_workgroups(int nu, int N, bool const_tables, int groups);
+size_t solve_d_lds_bytes(int nu, int N, bool const_tables);  // per workgroup
 // ... and its 32-lanes-per-instance form for wide systems (16 < nx+nu <= 32), tinympc_solve_dw.hip
 bool solve_dw_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_dw(const SolveParams &p, hipStream_t stream);
 int solve_dw_workgroups(int nu, int N, int groups);
+size_t solve_dw_lds_bytes(int nu, int N);
 // ... and with 64 lanes per instance (32 < nx+nu <= 64), tinympc_solve_dx.hip
 bool solve_dx_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_dx(const SolveParams &p, hipStream_t stream);
 int solve_dx_workgroups(int nu, int N, int groups);
+size_t solve_dx_lds_bytes(int nu, int N);
 // Layout A plus the cone / linear slack families (extra duals and the extra linear-cost term in HBM).
 hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 // Layout C: one instance per 256-thread workgroup, the horizon swept in 16 concurrent chunks (latency kernel
@@ -247,7 +250,8 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
 bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families = false);
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream);
-int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false);  // 8 wavefronts per workgroup, 4 on the long-horizon plan
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false);
+size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families = false);  // per workgroup, from the plan  // 8 wavefronts per workgroup, 4 on the long-horizon plan
 #endif  // !__HIPCC_RTC__
 
 // Doubles of working state per group in layout A (G and V with N+2 rows, D with 64 dummy slots).

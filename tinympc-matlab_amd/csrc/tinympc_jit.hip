@@ -38,6 +38,7 @@ struct JitPlan {
     int vreg = 0;  // slack knots kept in registers
     int wps = 2;   // wavefronts per SIMD: 2 (256 registers each), or 1 (512 registers) for long horizons
     int wpg = 8;   // wavefronts per workgroup: 4 where the LDS plan allows it (spreads mid-size batches over the CUs), else 8
+    size_t lds_bytes = 0;  // per workgroup
     const char *source = nullptr;
 };
 
@@ -76,6 +77,7 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false) {
         pl.vreg = vreg;
         pl.wps = wps;
         pl.wpg = wpg;
+        pl.lds_bytes = sizeof(double) * ((size_t)ops_doubles + tab_doubles + (size_t)wpg * ((size_t)(ns - vreg) * 64 + d_doubles));
         return pl;
     }
     return pl;
@@ -265,6 +267,10 @@ bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool f
     if (!plan_for(W, nx, nu, N, const_tables, families).ok) return false;
     // compile now, so that a failure is known before the layout is chosen
     return get_kernel(W, nx, nu, N, const_tables, families) != nullptr;
+}
+
+size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families) {
+    return plan_for(W, nx, nu, N, const_tables, families).lds_bytes;
 }
 
 int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families) {

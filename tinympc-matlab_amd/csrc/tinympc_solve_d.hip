@@ -638,6 +638,11 @@ hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+size_t solve_d_lds_bytes(int nu, int N, bool const_tables) {
+    const int wpg = d_wpg(nu, N, const_tables);
+    return d_lds_bytes(nu, N, const_tables, wpg, d_vl(nu, N, const_tables, wpg));
+}
+
 int solve_d_workgroups(int nu, int N, bool const_tables, int groups) {
     const int wpg = d_wpg(nu, N, const_tables);
     return (groups + wpg - 1) / wpg;

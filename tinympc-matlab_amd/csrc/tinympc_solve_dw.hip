@@ -494,6 +494,11 @@ bool solve_dw_supported(int nx, int nu, int N, bool const_tables) {
     return false;
 }
 
+size_t solve_dw_lds_bytes(int nu, int N) {
+    const int wpg = dw_wpg(nu, N);
+    return dw_lds_bytes(nu, N, true, wpg, dw_vl(nu, N, true, wpg));
+}
+
 int solve_dw_workgroups(int nu, int N, int groups) {
     const int wpg = dw_wpg(nu, N);
     return (groups + wpg - 1) / wpg;

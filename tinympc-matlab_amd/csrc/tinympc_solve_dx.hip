@@ -488,6 +488,11 @@ bool solve_dx_supported(int nx, int nu, int N, bool const_tables) {
     return false;
 }
 
+size_t solve_dx_lds_bytes(int nu, int N) {
+    const int wpg = dx_wpg(nu, N);
+    return dx_lds_bytes(nu, N, true, wpg, dx_vl(nu, N, true, wpg));
+}
+
 int solve_dx_workgroups(int nu, int N, int groups) {
     const int wpg = dx_wpg(nu, N);
     return (groups + wpg - 1) / wpg;
