@@ -218,3 +218,58 @@ def test_adaptive_rho_switching_and_unsupported_combination(pkg):
         r.solve()
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     r.reset()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cartpole20", "quadrotor15", "quadrotor50"])
+def test_device_adaptive_rho_on_layout_d(pkg, monkeypatch, which):
+    """Large batches adapt rho on the run-time specialised layout D (rho, its operator rows and pNref per lane; the KKT norms
+    ride on every fifth forward sweep): every instance against the restatement (iterations, status, final rho, trajectories),
+    cold and warm-started with the adapted rho; then the same on k_admm_solve_adapt (TINYMPC_JIT=0)."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    prob = pkg.problems.cartpole(20, True) if which == "cartpole20" else pkg.problems.quadrotor(int(which[9:]))
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    count = 1301
+    rng = np.random.default_rng(3)
+    x0s = prob.x0[:, None] * rng.uniform(0.2, 1.5, size=(1, count)) * rng.choice([-1.0, 1.0], size=(nx, count))
+    Xref = np.tile((0.05 * rng.normal(size=(nx, 1))), (1, N))
+    settings = dict(max_iter=45, abs_pri_tol=1e-5, abs_dua_tol=1e-5, check_termination=1 if which != "quadrotor15" else 2)
+    got = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("TINYMPC_JIT", jit)
+        s = _solver(pkg, prob, batch=count, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0, **settings)
+        dK, dP, dC1, dC2 = s.compute_sensitivity_autograd()
+        s.set_sensitivity_matrices(dK, dP, dC1, dC2)
+        s.set_x_ref(Xref)
+        out = []
+        for solve in range(2):
+            s.set_x0_batch(x0s * (1.0 - 0.4 * solve))
+            s.solve()
+            out.append((s.get_solution_batch(), s.get_stats_batch(), s.get_rho_batch().copy()))
+        assert (s.launch_info()["layout"] == "D") == (jit == "1")
+        got[jit] = out
+        s.reset()
+    sample = list(range(0, count, 13)) + [count - 2, count - 1]
+    oracles = {}
+    for b in sample:
+        o = O.OraclePort(prob).load_problem(prob, settings)
+        o.set_adaptive_rho(True, 0.2, 40.0, True)
+        o.set_sensitivity(dK, dP)
+        o.set_x_ref(Xref)
+        oracles[b] = o
+    for solve in range(2):
+        sol, st, rho = got["1"][solve]
+        for b, o in oracles.items():
+            o.set_x0(x0s[:, b] * (1.0 - 0.4 * solve))
+            o.solve()
+            assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], (solve, b)
+            assert abs(rho[b] - o.stats()["rho"]) < 1e-9 * rho[b], (solve, b)
+            assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL, (solve, b)
+            assert rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, (solve, b)
+        sol0, st0, rho0 = got["0"][solve]
+        np.testing.assert_array_equal(st["iter"], st0["iter"])
+        np.testing.assert_array_equal(st["status"], st0["status"])
+        np.testing.assert_allclose(rho, rho0, rtol=1e-9)
+        assert rel_err(sol["controls"], sol0["controls"]) < TOL
+        np.testing.assert_allclose(st["residuals"], st0["residuals"], rtol=1e-6, atol=1e-12)  # (the dual norms carry the rho of the last check)
+    assert np.unique(np.round(got["1"][1][2], 6)).size > 1  # instances really ended on different rho

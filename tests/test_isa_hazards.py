@@ -87,17 +87,19 @@ def test_run_time_specialisations_have_no_dpp_hazard(source, nx, nu, N, vreg, wp
         assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"
 
 
-@pytest.mark.parametrize("nx,nu,N,vreg,ct", [(6, 3, 10, 9, 0), (6, 3, 20, 19, 1), (12, 4, 15, 14, 0)])
-def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, ct, tmp_path):
-    """Layout D with the cone / linear families (-DTINY_JIT_FAM=1, one wavefront per SIMD): the family code adds masked
-    mat-vecs (the same fused DPP chain) between the sweep blocks -- lint what hiprtc will build on the GPU box."""
+@pytest.mark.parametrize("nx,nu,N,vreg,ct,variant", [(6, 3, 10, 9, 0, "FAM"), (6, 3, 20, 19, 1, "FAM"), (12, 4, 15, 14, 0, "FAM"),
+                                                     (12, 4, 50, 49, 1, "ADAPT"), (4, 1, 20, 19, 0, "ADAPT"), (12, 4, 15, 14, 1, "ADAPT")])
+def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, ct, variant, tmp_path):
+    """Layout D with the cone / linear families (-DTINY_JIT_FAM=1) or adaptive rho (-DTINY_JIT_ADAPT=1), one wavefront per
+    SIMD: their code adds mat-vecs (the same fused DPP chain) between the sweep blocks -- lint what hiprtc will build on
+    the GPU box."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = tmp_path / "jit_fam.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                     "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_VREG={vreg}",
-                    "-DTINY_JIT_WPS=1", f"-DTINY_JIT_CT={ct}", "-DTINY_JIT_FAM=1", "-S", "--cuda-device-only", "-o", str(out),
+                    "-DTINY_JIT_WPS=1", f"-DTINY_JIT_CT={ct}", f"-DTINY_JIT_{variant}=1", "-S", "--cuda-device-only", "-o", str(out),
                     os.path.join(CSRC, "tinympc_solve_d.hip")], check=True, timeout=900)
     text = out.read_text()
     checked, bad = _lint(text)

@@ -111,6 +111,7 @@ struct tinympc_solver {
     // adaptive rho / session.
     bool layout_m = false;
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
+    int d_adapt = -1;       // ... and with adaptive rho
     int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
     int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
@@ -162,7 +163,7 @@ struct tinympc_solver {
     bool tables_in_lds_a = false;
 
     bool use_layout_d() const {
-        return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && !st.adaptive_rho;
+        return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
     }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
@@ -369,6 +370,8 @@ void decide_layout_d_variants(tinympc_solver *s) {
             s->d_varying = s->d_varying_jit ? 1 : 0;
         }
     }
+    if (s->st.adaptive_rho && !s->families_active())
+        s->d_adapt = (s->W == 16 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), false, true)) ? 1 : 0;
     if (s->families_active() && !s->st.adaptive_rho) {
         // families: a run-time specialisation (16-lane form, horizons whose five register pairs per knot fit)? Asked every
         // time -- the answer is cached inside -- because it also depends on the tables' kind.
@@ -436,6 +439,9 @@ int launch(tinympc_solver *s, bool timed) {
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     if (s->layout_m) {
         HIP_TRY(launch_solve_m(p, s->stream));
+    } else if (adaptive && s->use_layout_d()) {
+        p.adaptive = 1;
+        HIP_TRY(launch_solve_jit(p, s->W, s->stream));
     } else if (adaptive) {
         // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
@@ -1464,13 +1470,13 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active()) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active(), s->st.adaptive_rho != 0) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) {
         size_t l = s->layout_c ? s->lds_bytes_c : s->lds_bytes;
         if (s->layout_m) l = 0;  // (static LDS: see the kernel)
         else if (s->use_layout_d())
-            l = (s->d_jit || s->families_active() || (!s->tables_const() && s->d_varying_jit))
-                    ? solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, s->tables_const(), s->families_active())
+            l = (s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit))
+                    ? solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, s->tables_const(), s->families_active(), s->st.adaptive_rho != 0)
                     : s->W == 64 ? solve_dx_lds_bytes(s->nu, s->N) : s->W == 32 ? solve_dw_lds_bytes(s->nu, s->N) : solve_d_lds_bytes(s->nu, s->N, s->tables_const());
         *lds_bytes = (int)l;
     }

@@ -119,7 +119,8 @@ struct SolveParams {
     // Layout C (k_admm_solve_c): horizon cut into chunk_count chunks of chunk_len steps, see chunk_plan()
     const double *ctab;   // PhiS_l | PsiS_l (l < chunk_levels), each [16][chunk_ks(nx)]: powers S*2^l of the sweeps' state blocks
     int chunk_len, chunk_count, chunk_levels;
-    int families;         // layout C: run the cone / linear families too (the other layouts use k_admm_solve_fam)
+    int families;         // layout C / the specialised layout D: run the cone / linear families too (the other layouts use k_admm_solve_fam)
+    int adaptive;         // the specialised layout D: adaptive rho (the other layouts use k_admm_solve_adapt)
     int const_tables;     // bounds and references are the same at every knot (layout B keeps them in registers)
     // Zero-copy closed-loop tick (tinympc_mpc_step_batch, small batches): x0 points into pinned host memory and is
     // mirrored into the device copy; the first controls are also written straight into pinned host memory.
@@ -248,10 +249,10 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
-bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families = false);
+bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families = false, bool adaptive = false);
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream);
-int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false);
-size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families = false);  // per workgroup, from the plan  // 8 wavefronts per workgroup, 4 on the long-horizon plan
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false, bool adaptive = false);
+size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families = false, bool adaptive = false);  // per workgroup, from the plan  // 8 wavefronts per workgroup, 4 on the long-horizon plan
 #endif  // !__HIPCC_RTC__
 
 // Doubles of working state per group in layout A (G and V with N+2 rows, D with 64 dummy slots).

@@ -46,7 +46,7 @@ struct JitPlan {
 //   VGPRs  2*(N-1) for the duals + 2*vreg for the register part of the slack + the operator row + ~76 for everything else
 //          must stay <= 256 (two wavefronts per SIMD);
 //   LDS    per wave (N-1-vreg) slack rows of 512 B + the feed-forward d, eight waves + the operators <= 160 KB.
-JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false) {
+JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false, bool adapt = false) {
     JitPlan pl;
     const int nxu = nx + nu, ns = N - 1;
     if (N < 4 || nx < 1 || nu < 1) return pl;
@@ -55,10 +55,13 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false) {
     else if (W == 32 && nxu > 16 && nxu <= 32) { mregs = 64; ops_doubles = 2 * 32 * 32; d_doubles = ((ns * 2 * nu) + 1) & ~1; pl.source = "tinympc_solve_dw.hip"; }
     else if (W == 64 && nxu > 32 && nxu <= 64) { mregs = 128; ops_doubles = 2 * 64 * 64; d_doubles = ((ns * nu) + 1) & ~1; pl.source = "tinympc_solve_dx.hip"; }
     else return pl;
-    if (fam && W != 16) return pl;  // cone / linear families: 16-lane form only
+    if ((fam || adapt) && W != 16) return pl;  // cone / linear families, adaptive rho: 16-lane form only
+    if (fam && adapt) return pl;
+    if (adapt) ops_doubles += 5 * 16 * 16;  // derivative rows of the two operators, [A'; B'], Pinf and its derivative
     const int tab_doubles = (ct ? 0 : 3 * (N + 2) * W + W) + (fam ? 3 * MAX_LIN_ROWS * 16 : 0);
     // families: three more register pairs per knot (gc, gl, lx), the three mask rows (3 x 16 doubles) and their scalars
-    const int fam_regs = fam ? 6 * ns + 96 + 24 : 0;  // the workgroup's LDS copy of the per-knot tables
+    // adaptive rho: the [A'; B'] row during an adaptation sweep, the lane's rho / pNref and the four norms
+    const int fam_regs = (fam ? 6 * ns + 96 + 24 : 0) + (adapt ? 32 + 28 : 0);  // the workgroup's LDS copy of the per-knot tables
     // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
     // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
     static const int cand[3][2] = {{2, 4}, {2, 8}, {1, 4}};  // (wavefronts per SIMD, per workgroup), in order of preference
@@ -140,7 +143,7 @@ struct JitKernel {
     int wpg = 8;  // wavefronts per workgroup
     std::vector<char> image;  // the code object stays alive as long as the module does
 };
-using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables + 2 * families
+using Key = std::tuple<int, int, int, int, int, int>;  // device, W, nx, nu, N, constant tables + 2 * families + 4 * adaptive rho
 std::map<Key, JitKernel> &cache() {
     static std::map<Key, JitKernel> c;
     return c;
@@ -151,7 +154,7 @@ std::mutex &cache_mutex() {
 }
 
 // Compile (or fetch from the disk cache) the code object of one shape. Empty on failure; `why` says why.
-std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, bool fam, const std::string &arch, bool use_disk_cache, std::string &why) {
+std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bool ct, bool fam, bool adapt, const std::string &arch, bool use_disk_cache, std::string &why) {
     const std::string sdir = source_dir(), idir = include_dir();
     const std::string spath = sdir + "/" + pl.source;
     if (!file_exists(spath) || !file_exists(sdir + "/tinympc_device.h")) {
@@ -164,7 +167,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     for (const char *dep : {"tinympc_device.h", "tinympc_sweep.h", "tinympc_solve_d_chain.h", "tinympc_solve_dw_chain.h", "tinympc_solve_dx_chain.h"})
         h = fnv1a(read_file(sdir + "/" + dep), h);
     char shape[160];
-    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d wpg=%d ct=%d fam=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, pl.wpg, (int)ct, (int)fam, arch.c_str());
+    snprintf(shape, sizeof(shape), "%s nx=%d nu=%d N=%d vreg=%d wps=%d wpg=%d ct=%d fam=%d adapt=%d %s", pl.source, nx, nu, N, pl.vreg, pl.wps, pl.wpg, (int)ct, (int)fam, (int)adapt, arch.c_str());
     h = fnv1a(shape, h);
     char name[64];
     snprintf(name, sizeof(name), "/jit_%016llx.hsaco", h);
@@ -183,7 +186,7 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
                                   "-DTINY_JIT_NX=" + std::to_string(nx), "-DTINY_JIT_NU=" + std::to_string(nu),
                                   "-DTINY_JIT_N=" + std::to_string(N), "-DTINY_JIT_VREG=" + std::to_string(pl.vreg),
                                   "-DTINY_JIT_WPS=" + std::to_string(pl.wps), "-DTINY_JIT_WPG=" + std::to_string(pl.wpg), std::string("-DTINY_JIT_CT=") + (ct ? "1" : "0"),
-                                  std::string("-DTINY_JIT_FAM=") + (fam ? "1" : "0")};
+                                  std::string("-DTINY_JIT_FAM=") + (fam ? "1" : "0"), std::string("-DTINY_JIT_ADAPT=") + (adapt ? "1" : "0")};
     std::vector<const char *> opts;
     for (const auto &x : o) opts.push_back(x.c_str());
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -220,15 +223,15 @@ std::vector<char> build_code_object(const JitPlan &pl, int nx, int nu, int N, bo
     return code;
 }
 
-JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false) {
+JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false, bool adapt = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(cache_mutex());
-    const Key key{dev, W, nx, nu, N, (int)ct + 2 * (int)fam};
+    const Key key{dev, W, nx, nu, N, (int)ct + 2 * (int)fam + 4 * (int)adapt};
     auto it = cache().find(key);
     if (it != cache().end()) return it->second.failed ? nullptr : &it->second;
     JitKernel k;
-    const JitPlan pl = plan_for(W, nx, nu, N, ct, fam);
+    const JitPlan pl = plan_for(W, nx, nu, N, ct, fam, adapt);
     std::string why;
     if (!pl.ok) {
         k.failed = true;
@@ -242,7 +245,7 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false) {
         }
         // first the disk cache; an image from there that does not load (truncated file, other driver) is compiled again
         for (int attempt = 0; attempt < 2; ++attempt) {
-            k.image = build_code_object(pl, nx, nu, N, ct, fam, arch, attempt == 0, why);
+            k.image = build_code_object(pl, nx, nu, N, ct, fam, adapt, arch, attempt == 0, why);
             k.failed = k.image.empty() || hipModuleLoadData(&k.mod, k.image.data()) != hipSuccess ||
                        hipModuleGetFunction(&k.fn, k.mod, "tinympc_jit_solve") != hipSuccess;
             if (!k.failed || k.image.empty()) break;
@@ -262,24 +265,24 @@ JitKernel *get_kernel(int W, int nx, int nu, int N, bool ct, bool fam = false) {
 
 }  // namespace
 
-bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families) {
+bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families, bool adaptive) {
     if (!jit_enabled()) return false;
-    if (!plan_for(W, nx, nu, N, const_tables, families).ok) return false;
+    if (!plan_for(W, nx, nu, N, const_tables, families, adaptive).ok) return false;
     // compile now, so that a failure is known before the layout is chosen
-    return get_kernel(W, nx, nu, N, const_tables, families) != nullptr;
+    return get_kernel(W, nx, nu, N, const_tables, families, adaptive) != nullptr;
 }
 
-size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families) {
-    return plan_for(W, nx, nu, N, const_tables, families).lds_bytes;
+size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families, bool adaptive) {
+    return plan_for(W, nx, nu, N, const_tables, families, adaptive).lds_bytes;
 }
 
-int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families) {
-    const int wpg = plan_for(W, nx, nu, N, const_tables, families).wpg;
+int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families, bool adaptive) {
+    const int wpg = plan_for(W, nx, nu, N, const_tables, families, adaptive).wpg;
     return (groups + wpg - 1) / wpg;
 }
 
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream) {
-    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0, p.families != 0);
+    JitKernel *k = get_kernel(W, p.nx, p.nu, p.N, p.const_tables != 0, p.families != 0, p.adaptive != 0);
     if (!k) return hipErrorInvalidValue;
     SolveParams arg = p;
     void *args[] = {&arg};

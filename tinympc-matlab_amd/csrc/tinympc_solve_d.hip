@@ -74,19 +74,21 @@ constexpr int D_LDS_PER_CU = 160 * 1024;
 __host__ __device__ constexpr int d_d_doubles(int nu, int N) { return ((N - 1) * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int d_tab_doubles(int N) { return 3 * (N + 2) * 16 + 16; }
 constexpr int D_FAM_DOUBLES = 3 * MAX_LIN_ROWS * 16;  // FAM: a_k | b_k | 1/||a_k||^2 of the linear rows, per lane row
+constexpr int D_ADAPT_DOUBLES = 5 * 16 * 16;         // ADAPT: dMf | dMb | [A'; B'] | Pinf | dPinf, transposed like the operators
 // number of slack slots in LDS; -1 if the shape does not fit the plan (cu_waves wavefronts per CU: 8, or 4 for the
 // long-horizon plan with one wavefront per SIMD and 512 registers)
-__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8, bool fam = false) {
+__host__ __device__ constexpr int d_vl(int nu, int N, bool ct, int wpg, int cu_waves = 8, bool fam = false, bool adapt = false) {
     const int ns = N - 1;
-    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / cu_waves - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N)) - (fam ? D_FAM_DOUBLES : 0);
+    const int wg_doubles = D_LDS_PER_CU / 8 * wpg / cu_waves - D_OPS_DOUBLES - (ct ? 0 : d_tab_doubles(N)) - (fam ? D_FAM_DOUBLES : 0) - (adapt ? D_ADAPT_DOUBLES : 0);
     const int wave_doubles = wg_doubles / wpg - d_d_doubles(nu, N);
     if (wave_doubles < 0) return -1;
     const int vlmax = wave_doubles / 64;
     const int want = ns > D_VREG_MAX ? ns - D_VREG_MAX : 0;
     return want <= vlmax ? want : -1;
 }
-__host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg, int vl, bool fam = false) {
-    return sizeof(double) * ((size_t)D_OPS_DOUBLES + (ct ? 0 : d_tab_doubles(N)) + (fam ? D_FAM_DOUBLES : 0) + (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
+__host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg, int vl, bool fam = false, bool adapt = false) {
+    return sizeof(double) * ((size_t)D_OPS_DOUBLES + (ct ? 0 : d_tab_doubles(N)) + (fam ? D_FAM_DOUBLES : 0) + (adapt ? D_ADAPT_DOUBLES : 0) +
+                             (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
 }
 
 // LDS traffic of the sweeps goes through asm volatile so that WHERE a read is issued is this file's decision, not the
@@ -137,8 +139,13 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // the forward step exactly as in the latency kernel (tinympc_solve_c.hip): every knot carries two more duals gc|yc, gl|yl
 // (persistent: the HBM arrays GC / GL) and the families' linear-cost term lx (forward -> backward), all in registers.
 // Run-time specialised only (tinympc_jit.hip, -DTINY_JIT_FAM=1): 10 VGPRs per knot instead of 4, so short horizons.
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false>
+// ADAPT: adaptive rho (admm.cpp:117-174, rho_benchmark.cpp) exactly as in k_admm_solve_adapt -- rho is PER INSTANCE (a lane
+// variable, persistent in p.rho_inst), the lane's operator rows are (base row) + (rho - rho0) * (derivative row) rebuilt from
+// LDS at every sweep, and every fifth iteration the four norms of the reference's dense KKT system ride on the forward sweep
+// (one extra mat-vec per step). Run-time specialised only (-DTINY_JIT_ADAPT=1), not together with the families.
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false>
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
+    static_assert(!(FAM && ADAPT), "adaptive rho and the constraint families exclude each other (as in the C ABI)");
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
     constexpr int TOFF = (N + 2) * W;
@@ -159,7 +166,8 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double *sOps = smem;
     double *sT = smem + D_OPS_DOUBLES;
     double *sLin = sT + (CT ? 0 : d_tab_doubles(N));  // FAM
-    double *sV = sLin + (FAM ? D_FAM_DOUBLES : 0) + (size_t)wv * (VL * 64 + d_d_doubles(NU, N));
+    double *sAd = sLin + (FAM ? D_FAM_DOUBLES : 0);   // ADAPT: [5][16 k][16 r]
+    double *sV = sAd + (ADAPT ? D_ADAPT_DOUBLES : 0) + (size_t)wv * (VL * 64 + d_d_doubles(NU, N));
     double *sD = sV + VL * 64;
 
     // ---- workgroup-shared: the two sweep operators, transposed to [k][r] (conflict-free row reads), and the tables
@@ -169,6 +177,13 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     }
     if constexpr (!CT)
         for (int i = threadIdx.x; i < d_tab_doubles(N); i += 64 * WPG) sT[i] = p.tables[i];
+    if constexpr (ADAPT) {  // k_build_adapt's tables: mt | pinf | dpinf | dmf | dmb, each [W][KT]; here: dmf | dmb | mt | pinf | dpinf
+        for (int i = threadIdx.x; i < D_ADAPT_DOUBLES; i += 64 * WPG) {
+            const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
+            const int tbl = which == 0 ? 3 : which == 1 ? 4 : which - 2;
+            sAd[i] = (k < KT) ? p.adapt[(size_t)tbl * W * KT + (size_t)rr * KT + k] : 0.0;
+        }
+    }
     if constexpr (FAM) {  // layout of fam_doubles(): ... | nl | per linear row k: a_k[W] b_k[W] ||a_k||^2[W]
         const double *lin_rows = p.fam + 4 * W + (size_t)3 * W * KT;
         for (int i = threadIdx.x; i < D_FAM_DOUBLES; i += 64 * WPG) {
@@ -267,10 +282,21 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
     const double cf = p.ops[(size_t)2 * W * KT + r];
     const double cb = p.ops[(size_t)2 * W * KT + W + r];
-    const double pnref = p.tables[(size_t)3 * TOFF + r];
-    const double rho = p.rho, nrho = -p.rho;
+    const double pnref0 = p.tables[(size_t)3 * TOFF + r];
+    // (ADAPT: rho, its negative and pNref are lane variables that change every fifth iteration; otherwise they never change and
+    // stay in scalar registers)
+    const double rho0 = p.rho;
+    double rho = p.rho, pnref = pnref0;
+    double dpnref = 0.0, dgr = 0.0;
+    if constexpr (ADAPT) {
+        rho = inst_ok ? p.rho_inst[inst] : rho0;  // persists across solves like cache->rho
+        dpnref = p.adapt[(size_t)5 * W * KT + r];
+        dgr = p.ops[(size_t)2 * W * KT + 2 * W + r];  // Q + rho0 / R + rho0 diagonal of this row (tiny_api.cpp:90-91)
+        pnref = fma(rho - rho0, dpnref, pnref0);
+    }
+    double nrho = -rho;
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
-    const double rhom = is_x ? nrho : 0.0;
+    double rhom = is_x ? nrho : 0.0;
     const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
     const int dIdx = j * NU + (is_u ? r - NX : 0);
     const double *const sDr = sD + dIdx;
@@ -290,10 +316,18 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     int it_done = 0;
     int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
     bool res_valid = false;
-    double snap_pri = 0.0, snap_dua = 0.0;
+    double snap_pri = 0.0, snap_dua = 0.0, snap_rho = p.rho;
 
-    auto load_ops = [&](const double *src, double (&m)[16]) {
-        static_for<0, 16>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * 16]; });
+    auto load_ops = [&](const double *src, double (&m)[16]) {  // (src: sMf / sMb; ADAPT: the derivative rows sit 512 doubles behind)
+        if constexpr (ADAPT) {
+            const double delta = rho - rho0;
+            static_for<0, 16>([&](auto K) {
+                constexpr int o = (K.value < NXU ? K.value : 0) * 16;
+                m[K.value] = fma(delta, src[o + (sAd - sOps)], src[o]);
+            });
+        } else {
+            static_for<0, 16>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * 16]; });
+        }
     };
     auto vget = [&](auto S) -> double {
         if constexpr (decltype(S)::value >= VL) return Vr[decltype(S)::value - VL];
@@ -363,6 +397,14 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
         double m[16];
         load_ops(sMf, m);
+        // ADAPT: every fifth iteration (admm.cpp:155) the norms of the reference's KKT residuals ride on the forward sweep
+        const bool adapt = ADAPT && __builtin_amdgcn_readfirstlane((int)((it0 > 0) && (it0 % 5 == 0))) != 0;
+        double a_pr = 0.0, a_pn = 0.0, a_dr = 0.0, a_dn = 0.0;  // primal residual / norm, dual residual / norm
+        double gprev = 0.0;  // g_i of the state rows; the x_0 column has no -g_0 term (y_vector starts at g_1)
+        double mtr[16];      // this lane's row of [A'; B']
+        if constexpr (ADAPT) {
+            if (adapt) static_for<0, 16>([&](auto K) { mtr[K.value] = K.value < NXU ? sAd[2 * 256 + K.value * 16 + r] : 0.0; });
+        }
         // ---------------- knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
         {
             const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
@@ -404,12 +446,30 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 lon = lds_read_async<(q + 2) * W * 8>(aT);
                 hin = lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
             }
+            const double xprev = xcur;
+            double snew_q;
             if constexpr (q >= VL) {
                 xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], Vr[q - VL], pri, dua);
+                snew_q = Vr[q - VL];
             } else {
                 double vnew;
                 xcur = Step::fwd_lds(xcur, dcur, m, cf, locur, hicur, G[q], vcur, vnew, pri, dua);
                 lds_write_async<q * 512>(aV, vnew);
+                snew_q = vnew;
+            }
+            if constexpr (ADAPT) {
+                if (adapt) {
+                    // state lanes: column x_q (xprev, gprev) and row vnew_{q+1} (snew); input lanes: column / row u_q
+                    const double gnew = G[q], out = xcur;
+                    const double t = group_matvec<W, 16>(mtr, is_x ? gnew : 0.0, 0.0);  // [A'; B'] g_{q+1}
+                    const double dgx = dgr * (is_x ? xprev : out);                       // Q.*x_q | R.*u_q
+                    const double aty = is_x ? (t - gprev) : (gnew + t);
+                    a_dn = fmax(fmax(a_dn, fabs(dgx)), fabs(aty));
+                    a_dr = fmax(a_dr, fabs(2.0 * dgx + aty));
+                    a_pr = fmax(a_pr, fabs(is_x ? snew_q : (out - snew_q)));
+                    a_pn = fmax(fmax(a_pn, fabs(snew_q)), is_x ? 0.0 : fabs(out));
+                    gprev = gnew;
+                }
             }
             if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                 double gcn, gln;
@@ -434,9 +494,13 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
                 // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does
                 // not keep one pointer per slot alive across the iteration loop.
+                // (ADAPT: the check after an adaptation scales the dual residual with the NEW rho, which this sweep does not
+                // know yet -- no early "cannot converge" verdict in those iterations)
                 if constexpr (s0 > 0) {
-                    const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
-                    may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+                    if (!adapt) {
+                        const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                        may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+                    }
                 }
                 if (may) {
                     unsigned vo = voff;
@@ -449,6 +513,41 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         });
         if (active) it_done = it1;  // admm.cpp:143
 
+        // ---------------- adaptive rho (admm.cpp:147-174), as in k_admm_solve_adapt
+        const double nrho_lin = nrho, rhom_lin = rhom, pnref_lin = pnref;  // what update_linear_cost used this iteration
+        if constexpr (ADAPT) {
+            if (adapt) {
+                const double x_last = xcur, g_last = gprev;  // x_{N-1}, g_{N-1} on state lanes
+                // column block x_{N-1}: Pinf x + Q.*x - g_{N-1} with the CURRENT (adapted) Pinf (rho_benchmark.cpp:112)
+                double pr[16];
+                const double delta = rho - rho0;
+                static_for<0, 16>([&](auto K) {
+                    constexpr int o = K.value * 16;
+                    pr[K.value] = K.value < NXU ? fma(delta, sAd[4 * 256 + o + r], sAd[3 * 256 + o + r]) : 0.0;
+                });
+                const double pxl = group_matvec<W, 16>(pr, is_x ? x_last : 0.0, 0.0);
+                if (is_x) {
+                    const double qv = dgr * x_last;
+                    a_dn = fmax(fmax(fmax(a_dn, fabs(pxl)), fabs(qv)), fabs(g_last));
+                    a_dr = fmax(a_dr, fabs(pxl + qv - g_last));
+                }
+                const double pri_res = group_max<W>(a_pr), pri_norm = group_max<W>(a_pn);
+                const double dual_res = group_max<W>(a_dr), dual_norm = group_max<W>(a_dn);
+                const double eps = 1e-10;  // rho_benchmark.cpp:190-197
+                const double normalized_pri = pri_res / (pri_norm + eps);
+                const double normalized_dual = dual_res / (dual_norm + eps);
+                const double ratio = normalized_pri / (normalized_dual + eps);
+                double new_rho = rho * sqrt(ratio);
+                if (p.rho_clip) new_rho = fmin(fmax(new_rho, p.rho_min), p.rho_max);
+                if (active) {  // (rho is unchanged for instances that are no longer iterating)
+                    rho = new_rho;
+                    nrho = -new_rho;
+                    rhom = is_x ? nrho : 0.0;
+                    pnref = fma(rho - rho0, dpnref, pnref0);
+                }
+            }
+        }
+
         // ---------------- R1: termination (admm.cpp:93-101), decided element-wise: one ballot, no reductions
         if (check) {
             const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
@@ -456,6 +555,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             if (active) {
                 snap_pri = pri;
                 snap_dua = dua;
+                if constexpr (ADAPT) snap_rho = rho;  // cache->rho AFTER the adaptation (admm.cpp:95-96)
                 res_valid = true;
                 if (conv) {
                     status = 1;  // TINY_SOLVED: this instance stops before the backward pass (admm.cpp:181-192)
@@ -478,20 +578,33 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             };
             double px, rcur, rnext, acc;
             {   // p_{N-1} (state lanes, admm.cpp:81-82) | r_{N-2} (input lanes) share slot NS-1; then slot NS-2
-                double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
-                if constexpr (FAM) lrT = is_x ? pnref + LX[NS - 1] : lrT;
+                // (ADAPT: the linear cost of this iteration was formed BEFORE the adaptation -- rho / pNref of update_linear_cost --,
+                // the operators loaded above carry the new Kinf)
+                double lrT = is_x ? pnref_lin : lr_of(std::integral_constant<int, NS - 1>{});
+                if constexpr (FAM) lrT = is_x ? pnref_lin + LX[NS - 1] : lrT;
                 const double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 const double v1 = vget(std::integral_constant<int, NS - 1>{}), v2 = vget(std::integral_constant<int, NS - 2>{});
                 double t;
-                asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
-                    "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
-                    "v_add_f64 %[t], %[v2], -%[g2]\n\t"
-                    "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
-                    "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
-                    : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
-                    : [v1] "v"(v1), [g1] "v"(G[NS - 1]), [v2] "v"(v2), [g2] "v"(G[NS - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
-                      [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                if constexpr (ADAPT) {  // (rho is a lane variable here: vector operand)
+                    asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
+                        "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
+                        "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                        "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
+                        "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
+                        : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
+                        : [v1] "v"(v1), [g1] "v"(G[NS - 1]), [v2] "v"(v2), [g2] "v"(G[NS - 2]), [nrho] "v"(nrho_lin), [lrT] "v"(lrT),
+                          [rhom] "v"(rhom_lin), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                } else {
+                    asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
+                        "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
+                        "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                        "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
+                        "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
+                        : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
+                        : [v1] "v"(v1), [g1] "v"(G[NS - 1]), [v2] "v"(v2), [g2] "v"(G[NS - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
+                          [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                }
                 rcur = px;
             }
             // slack operand of a block's tail: a register, or an LDS read issued one block ahead
@@ -512,7 +625,8 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 const double lr2 = lr_of(std::integral_constant<int, s2>{});
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 double a = acc, an, rn;
-                Step::bwd(a, px, rcur, m, v2cur, G[s2], rhom, lrmc2, nrho, lr2, an, rn);
+                if constexpr (ADAPT) Step::bwd_v(a, px, rcur, m, v2cur, G[s2], rhom_lin, lrmc2, nrho_lin, lr2, an, rn);
+                else Step::bwd(a, px, rcur, m, v2cur, G[s2], rhom, lrmc2, nrho, lr2, an, rn);
                 lds_write_masked<s * DS * 8>(aD, a, wr_d);  // d_s
                 px = a;
                 rcur = rnext;
@@ -540,9 +654,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     }
 
     const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
-    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
+    const double rho_res = ADAPT ? snap_rho : rho;
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho_res, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho_res;
 
     if (inst_ok && r == 0) {
+        if constexpr (ADAPT) p.rho_inst[inst] = rho;
         p.istats[inst * 2 + 0] = it_done;
         p.istats[inst * 2 + 1] = status;
         if (res_valid) {
@@ -582,10 +698,14 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
 #define TINY_JIT_FAM 0
 #endif
     constexpr bool FAMJ = TINY_JIT_FAM != 0;  // cone / linear-inequality families
-    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ);
+#ifndef TINY_JIT_ADAPT
+#define TINY_JIT_ADAPT 0
+#endif
+    constexpr bool ADJ = TINY_JIT_ADAPT != 0;  // adaptive rho
+    constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ, ADJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ>(p, smem_jit);
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ) / sizeof(double)];
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ>(p, smem_jit);
 }
 namespace tinympc {
 #else

@@ -194,6 +194,17 @@ struct DStep<D_NX, D_NU> {
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
     }
+    // ... the same with -rho as a vector operand (adaptive rho: rho is per instance)
+    static __device__ __forceinline__ void bwd_v(double &a, double x, double d, const double (&m)[16], double v2, double g2,
+                                                 double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
+        double t;
+        asm volatile(D_CHAIN
+                     "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                     "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
+                     : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
+                     : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "v"(nrho), [lr] "v"(lr), D_MOPS);
+    }
     // Last backward step (slot 0): nothing left to prepare.
     static __device__ __forceinline__ void bwd_last(double &a, double x, double d, const double (&m)[16]) {
         asm volatile(D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
