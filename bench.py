@@ -409,6 +409,46 @@ def main() -> int:
                                       "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
                                       "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None}
             one.reset()
+            # ... and batches of it: N=100 (BASELINE config 4's horizon: the latency kernel, one workgroup per instance) and
+            # N=10 (the horizon of examples/rocket_landing_constraints.m:14: layout D with the families in registers)
+            rb = {}
+            for rN in (100, 10):
+                rkb = P.rocket(rN)
+                rB, rit = 4096, 100
+                many = pkg.TinyMPC()
+                many.setup(rkb.A, rkb.B, rkb.Q, rkb.R, rkb.N, batch=rB, device=local_rank, rho=rkb.rho, fdyn=rkb.fdyn,
+                           abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=rit, check_termination=1)
+                many.set_bound_constraints(rkb.x_min, rkb.x_max, rkb.u_min, rkb.u_max)
+                many.set_x_ref(rkb.x_ref)
+                many.set_u_ref(rkb.u_ref)
+                many.set_cone_constraints(**rkb.cones)
+                many.set_linear_constraints(**rkb.linear)
+                many.set_x0_batch(np.asfortranarray(rkb.x0[:, None] * np.linspace(0.6, 1.2, rB)[None, :]))
+                ms = []
+                for k in range(5):
+                    many.reset_workspace()
+                    ms.append(many.solve_timed())
+                med = sorted(ms[1:])[len(ms[1:]) // 2]
+                rb["N=%d" % rN] = {"iters_per_s": rB * rit / (med * 1e-3), "kernel_ms": med, "layout": many.launch_info()["layout"]}
+                many.reset()
+            out["rocket_batch"] = dict(workload="4096 rocket-landing instances (cones + linear row + fdyn) x 100 forced iterations", **rb)
+            # Adaptive rho (admm.cpp:117-174) on a batch: rho, its operator rows and pNref per instance, layout D's ADAPT variant
+            ad = pkg.TinyMPC()
+            aB, ait = 8192, 100
+            ad.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=aB, device=local_rank, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0,
+                     max_iter=ait, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0)
+            ad.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            ad.set_sensitivity_matrices(*ad.compute_sensitivity_autograd())
+            ad.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(aB)))
+            ms = []
+            for k in range(5):
+                ad.reset_workspace()
+                ms.append(ad.solve_timed())
+            med = sorted(ms[1:])[len(ms[1:]) // 2]
+            out["adaptive_rho_batch"] = {"workload": "quadrotor N=%d, %d instances x %d forced iterations, rho adapted every 5th" % (prob.N, aB, ait),
+                                         "iters_per_s": aB * ait / (med * 1e-3), "kernel_ms": med, "layout": ad.launch_info()["layout"],
+                                         "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))]}
+            ad.reset()
         if not args.no_single:
             # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
             # cross-row swaps + fused DPP chain. Synthetic stable system, box constraints, 100 forced iterations.

@@ -1484,7 +1484,15 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     return TINYMPC_OK;
 }
 
-int tinympc_get_layout(tinympc_solver *s) { return s ? (s->layout_m ? 'M' : s->use_layout_d() ? 'D' : s->layout_c ? 'C' : s->layout_b ? 'B' : 'A') : 0; }
+int tinympc_get_layout(tinympc_solver *s) {
+    if (!s) return 0;
+    if (s->layout_m) return 'M';
+    if (s->use_layout_d()) return 'D';
+    // the families and adaptive rho have kernels of their own on layout A's plan (the families also in the latency kernel)
+    if (s->families_active()) return s->fam_c ? 'C' : 'A';
+    if (s->st.adaptive_rho) return 'A';
+    return s->layout_c ? 'C' : s->layout_b ? 'B' : 'A';
+}
 
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 
