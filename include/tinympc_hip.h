@@ -278,6 +278,12 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
  * environment variable TINYMPC_LAYOUT=A|B|C overrides the choice at setup. 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
 
+/* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:
+ * bounds / references that vary over the horizon, cone / linear families and adaptive rho select variants that are otherwise
+ * built at the first launch that needs them. Call it once after the constraints and settings are in place to keep that
+ * one-off cost out of the first real-time tick. No reference counterpart (the reference has one code path). */
+int tinympc_prepare(tinympc_solver *s);
+
 /* The HIP stream of the handle as an opaque pointer (hipStream_t). */
 void *tinympc_get_stream(tinympc_solver *s);
 

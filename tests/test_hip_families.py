@@ -228,3 +228,20 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
         np.testing.assert_array_equal(st["iter"], st0["iter"])
         assert rel_err(sol["controls"], sol0["controls"]) < TOL and rel_err(sol["states"], sol0["states"]) < TOL
     assert (results["1"][0][1]["status"] == 1).any() and (results["1"][1][1]["iter"] < results["1"][0][1]["iter"]).any()
+
+
+def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypatch):
+    """tinympc_prepare: the variant decision (here: families on layout D) is taken -- and the kernel built -- before the first
+    solve, so that launch_info already names it and the first tick does not pay for it."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    rk = pkg.problems.rocket(10)
+    s = make(pkg, rk, dict(max_iter=30, abs_pri_tol=1e-3, abs_dua_tol=1e-3), batch=1500)
+    assert s.launch_info()["layout"] != "D"  # not decided yet: k_admm_solve_fam would run
+    s.prepare()
+    assert s.launch_info()["layout"] == "D"
+    s.set_x0_batch(np.repeat(rk.x0[:, None], 1500, axis=1))
+    s.solve()
+    assert s.launch_info()["layout"] == "D" and np.all(s.get_stats_batch()["iter"] > 0)
+    s.reset()

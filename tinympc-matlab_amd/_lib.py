@@ -91,6 +91,7 @@ SIGNATURES = {
     "tinympc_session_end": (C.c_int, [Handle]),
     "tinympc_get_launch_info": (C.c_int, [Handle, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "tinympc_get_layout": (C.c_int, [Handle]),
+    "tinympc_prepare": (C.c_int, [Handle]),
     "tinympc_get_stream": (C.c_void_p, [Handle]),
 }
 

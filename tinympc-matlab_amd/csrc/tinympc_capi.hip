@@ -1494,6 +1494,14 @@ int tinympc_get_layout(tinympc_solver *s) {
     return s->layout_c ? 'C' : s->layout_b ? 'B' : 'A';
 }
 
+int tinympc_prepare(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    decide_layout_d_variants(s);
+    return TINYMPC_OK;
+}
+
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 
 }  // extern "C"

@@ -395,6 +395,13 @@ class TinyMPC:
         _lib.check(self._L.tinympc_get_rho_batch(self._h, _p(rho), first, count))
         return rho
 
+    def prepare(self):
+        """Choose (and, if needed, specialise) the solve kernel for the current constraints / settings now, instead of at the
+        first solve that needs it (seconds the first time a shape is seen)."""
+        self._check_setup()
+        self._push_settings()
+        _lib.check(self._L.tinympc_prepare(self._h))
+
     def launch_info(self) -> dict:
         self._check_setup()
         v = [C.c_int() for _ in range(5)]
