@@ -229,6 +229,13 @@ classdef TinyMPC < handle
         %   solver.set_x0(x); solver.solve(); sol = solver.get_solution(); u = sol.controls(:,1);
         % as   u = solver.session_step(x);   between session_begin() and session_end(). get_solution / get_stats
         % keep working inside a session; any other verb ends it.
+        function prepare(obj)
+            % Choose (and, if needed, specialise) the solve kernel for the current constraints / settings now
+            % instead of at the first solve that needs it.
+            obj.require_setup();
+            tinympc_matlab('prepare');
+        end
+
         function session_begin(obj)
             obj.require_setup();
             tinympc_matlab('session_begin');

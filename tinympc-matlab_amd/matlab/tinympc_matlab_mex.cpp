@@ -139,7 +139,14 @@ void verb_solve(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     plhs[0] = mxCreateDoubleScalar(0);  // the reference always returns 0 here (bindings.cpp:230)
 }
 
+// Extension (include/tinympc_hip.h): take the kernel-variant decision before the first solve.
+void verb_prepare(int, mxArray *[], int, const mxArray *[]) {
+    need_solver();
+    check(tinympc_prepare(g_handle));
+}
+
 // Closed-loop session (extension, include/tinympc_hip.h): the solve kernel stays resident between ticks.
+
 void verb_session_begin(int, mxArray *[], int, const mxArray *[]) {
     need_solver();
     check(tinympc_session_begin(g_handle));
@@ -303,7 +310,7 @@ const Verb kVerbs[] = {
     {"set_cone_constraints", verb_set_cone_constraints},
     {"compute_cache_terms", verb_compute_cache_terms}, {"solve_lqr", verb_solve_lqr},
     {"compute_sensitivity", verb_compute_sensitivity},
-    {"session_begin", verb_session_begin}, {"session_step", verb_session_step}, {"session_end", verb_session_end},
+    {"prepare", verb_prepare}, {"session_begin", verb_session_begin}, {"session_step", verb_session_step}, {"session_end", verb_session_end},
 };
 
 }  // namespace
