@@ -250,6 +250,28 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         double lxv = 0.0;
         gc_new = gc_old;
         gl_new = gl_old;
+        if (any_cone && any_lin && nl == 1) {
+            // Both families and a single linear row (the rocket-landing case): the same operations as below, in ONE basic block, so
+            // that the scheduler interleaves the three independent mat-vec chains and the two projection sequences -- a lone
+            // wavefront issues a dependent FP64 instruction every ~7 cycles, an independent one every ~5.
+            const double svc = val + gc_old, s0 = val + gl_old;
+            const double a_k = sLin[r], b_k = sLin[W + r], in_k = sLin[2 * W + r];
+            const double a2 = group_matvec<W, KT>(cn, svc * svc, 0.0);
+            const double t = group_matvec<W, KT>(ct_, svc, 0.0);
+            const double dot = group_matvec<W, KT>(ty, a_k * s0, 0.0);
+            const double vc = soc_project_element(svc, a2, t, mu, inv_mu, role);
+            const double svl = halfspace_project_element(s0, dot, a_k, b_k, in_k);
+            const double gcn = svc - vc, gln = s0 - svl;
+            if (famc) {
+                gc_new = gcn;
+                lxv -= p.rho * (vc - gcn);
+            }
+            if (faml) {
+                gl_new = gln;
+                lxv -= p.rho * (svl - gln);
+            }
+            return lxv;
+        }
         if (any_cone) {
             const double sv = val + gc_old;
             const double a2 = group_matvec<W, KT>(cn, sv * sv, 0.0);
