@@ -181,7 +181,7 @@ def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
     s.reset()
 
 
-@pytest.mark.parametrize("variant", ["cones", "linear", "both"])
+@pytest.mark.parametrize("variant", ["cones", "linear", "both", "both_constant_references"])
 @pytest.mark.parametrize("N", [10, 20, 28])
 def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
     """Short horizons, large batches: the families ride on the run-time specialised layout D (gc, gl, lx in registers next to
@@ -191,9 +191,11 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
         pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
-    rk = P.rocket(N, with_linear=variant in ("linear", "both"))
+    rk = P.rocket(N, with_linear=variant != "cones")
     if variant == "linear":
         rk.cones = {}
+    if variant == "both_constant_references":  # (the kernel variant that keeps bounds / references in registers)
+        rk.x_ref = np.repeat(rk.x_ref[:, :1], N, axis=1)
     settings = dict(max_iter=150, abs_pri_tol=2e-3, abs_dua_tol=1e-4)
     batch = 1301  # beyond the latency kernel's range; ragged last wavefront and workgroup
     rng = np.random.default_rng(N)
