@@ -545,6 +545,14 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }
     for (int it = 0; it < p.max_iter; ++it) {
         const bool check = (ct > 0) && (((it + 1) % ct) == 0);
+#if TINY_EXP == 9  // timing experiment: cycle stamps of one iteration's phases (tools/c_breakdown.py prints them)
+        unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool stamp = it == 7 && blockIdx.x == 0;
+#define TSTAMP(n, dep) if (stamp) { asm volatile("s_nop 0" :: "v"(dep)); ts[n] = __builtin_readcyclecounter(); }
+#else
+#define TSTAMP(n, dep)
+#endif
+        TSTAMP(0, x0v)
         // ================= forward sweep =================
         double out[SMAX];
         {   // pass 1: end state of the chunk from a zero incoming state (chunk 0: from x_0)
@@ -557,7 +565,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     xt = step[i] ? o : xt;
                 }
 #endif
+            TSTAMP(1, xt)
             const double xin = carry_scan(-1, PH, (is_x && c < C) ? xt : 0.0);
+            TSTAMP(2, xin)
             // pass 2: the real sweep, from the true state entering the chunk
             xt = (c >= 1) ? xin : x0v;
 #pragma unroll
@@ -570,6 +580,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             }
         }
 
+        TSTAMP(3, out[0])
         // ================= row-local phases (S1, D1, R1) =================
         double pri = 0.0, dua = 0.0;
         if (k0) {
@@ -647,6 +658,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         }
 
         // ================= backward sweep =================
+        TSTAMP(4, pri)
         {
             double pterm = 0.0;
 #pragma unroll
@@ -664,7 +676,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     pcur = step[i] ? (qk + o) : pcur;
                 }
 #endif
+            TSTAMP(5, pcur)
             const double pin = carry_scan(+1, PS, (is_x && c < C) ? pcur : 0.0);
+            TSTAMP(6, pin)
             // pass 2: the real sweep, from the true p entering the chunk; only d_k is kept
             pcur = (c < C - 1) ? pin : pend;
 #pragma unroll
@@ -675,7 +689,13 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     dd[i] = (step[i] && is_u) ? o : dd[i];
                     pcur = step[i] ? (qk + o) : pcur;
                 }
+            TSTAMP(7, pcur)
         }
+#if TINY_EXP == 9
+        if (stamp && (tid & 63) == 0)
+            printf("wave %d: fwd pass 1 %llu | scan %llu | pass 2 %llu | row-local + linear cost + flags barrier %llu | bwd pass 1 %llu | scan %llu | pass 2 %llu | total %llu cycles\n",
+                   tid >> 6, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[7] - ts[0]);
+#endif
     }
 
 
