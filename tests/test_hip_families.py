@@ -247,3 +247,57 @@ def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypa
     s.solve()
     assert s.launch_info()["layout"] == "D" and np.all(s.get_stats_batch()["iter"] > 0)
     s.reset()
+
+
+@pytest.mark.parametrize("what", ["box", "families", "adaptive_rho"])
+def test_layout_d_variants_share_the_persistent_state_with_the_other_kernels(pkg, kernel_layout, monkeypatch, what):
+    """One handle, four warm-started solves, the kernel switched between them (TINYMPC_JIT on / off / on / off): layout D and its
+    FAM / ADAPT variants keep g, v, d, gc, gl and the per-instance rho in the same HBM arrays as layouts A / B,
+    k_admm_solve_fam and k_admm_solve_adapt, so the sequence must equal the restatement's four consecutive solves."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    P = pkg.problems
+    batch = 1100
+    rng = np.random.default_rng(8)
+    if what == "families":
+        prob = P.rocket(12)
+        settings = dict(max_iter=40, abs_pri_tol=2e-3, abs_dua_tol=1e-4)
+        s = make(pkg, prob, settings, batch=batch)
+    else:
+        prob = P.quadrotor(18)
+        settings = dict(max_iter=25, abs_pri_tol=1e-4, abs_dua_tol=1e-4)
+        s = pkg.TinyMPC()
+        extra = dict(adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0) if what == "adaptive_rho" else {}
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, **settings, **extra)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if what == "adaptive_rho":
+            dK, dP, dC1, dC2 = s.compute_sensitivity_autograd()
+            s.set_sensitivity_matrices(dK, dP, dC1, dC2)
+    sample = [0, 1, 2, 3, 550, 1098, 1099]
+    orcs = {}
+    for b in sample:
+        o = oracle(prob, settings)
+        if what == "adaptive_rho":
+            o.set_adaptive_rho(True, 0.2, 40.0, True)
+            o.set_sensitivity(dK, dP)
+        orcs[b] = o
+    x = prob.x0[:, None] * rng.uniform(0.5, 1.2, (1, batch)) + 0.05 * rng.standard_normal((prob.nx, batch))
+    seen = []
+    for k, jit in enumerate(("1", "0", "1", "0")):
+        monkeypatch.setenv("TINYMPC_JIT", jit)
+        xs = x * (1.0 - 0.15 * k)
+        s.set_x0_batch(xs)
+        s.solve()
+        seen.append(s.launch_info()["layout"])
+        sol, st = s.get_solution_batch(), s.get_stats_batch()
+        for b, o in orcs.items():
+            o.set_x0(xs[:, b])
+            o.solve()
+            assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], (k, b)
+            assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, (k, b)
+    if what == "box":  # (the box kernel is chosen at setup; only the variants are decided per launch)
+        assert seen == ["D"] * 4, seen
+    else:
+        assert seen[0] == "D" and seen[2] == "D" and seen[1] != "D" and seen[3] != "D", seen
+    s.reset()
