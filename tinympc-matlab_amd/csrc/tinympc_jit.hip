@@ -44,8 +44,9 @@ struct JitPlan {
 
 // The register / LDS plan of tinympc_solve_d*.hip, re-derived here (the kernels static_assert the LDS side):
 //   VGPRs  2*(N-1) for the duals + 2*vreg for the register part of the slack + the operator row + ~76 for everything else
-//          must stay <= 256 (two wavefronts per SIMD);
-//   LDS    per wave (N-1-vreg) slack rows of 512 B + the feed-forward d, eight waves + the operators <= 160 KB.
+//          (+ the families' / adaptive rho's registers) must stay <= 256 (two wavefronts per SIMD) or <= 512 (one);
+//   LDS    per wave (N-1-vreg) slack rows of 512 B + the feed-forward d; the workgroup's waves + the operators + tables must fit
+//          its share of the CU's 160 KB.
 JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false, bool adapt = false) {
     JitPlan pl;
     const int nxu = nx + nu, ns = N - 1;
@@ -58,12 +59,13 @@ JitPlan plan_for(int W, int nx, int nu, int N, bool ct, bool fam = false, bool a
     if ((fam || adapt) && W != 16) return pl;  // cone / linear families, adaptive rho: 16-lane form only
     if (fam && adapt) return pl;
     if (adapt) ops_doubles += 5 * 16 * 16;  // derivative rows of the two operators, [A'; B'], Pinf and its derivative
+    // the workgroup's LDS copy of the per-knot tables (+ the linear rows' coefficients of the families)
     const int tab_doubles = (ct ? 0 : 3 * (N + 2) * W + W) + (fam ? 3 * MAX_LIN_ROWS * 16 : 0);
     // families: three more register pairs per knot (gc, gl, lx), the three mask rows (3 x 16 doubles) and their scalars
     // adaptive rho: the [A'; B'] row during an adaptation sweep, the lane's rho / pNref and the four norms
-    const int fam_regs = (fam ? 6 * ns + 96 + 24 : 0) + (adapt ? 32 + 28 : 0);  // the workgroup's LDS copy of the per-knot tables
-    // two wavefronts per SIMD first; a horizon that does not fit gets one wavefront with all 512 registers and half of the
-    // CU's LDS per wavefront pair -- the chain latency is then exposed (about layout B's rate), but nothing spills to L2
+    const int fam_regs = (fam ? 6 * ns + 96 + 24 : 0) + (adapt ? 32 + 28 : 0);
+    // two wavefronts per SIMD first (workgroups of four, else eight); a horizon that does not fit gets one wavefront per SIMD with
+    // all 512 registers and a quarter of the CU's LDS -- the chain latency is then exposed, but nothing of the state leaves the chip
     static const int cand[3][2] = {{2, 4}, {2, 8}, {1, 4}};  // (wavefronts per SIMD, per workgroup), in order of preference
     for (const auto &c : cand) {
         const int wps = c[0], wpg = c[1];
