@@ -11,6 +11,9 @@
 //              holds only the feed-forward d (compact), part of v|z and one copy of the sweep operators per workgroup.
 //              <= 256 VGPRs and <= 20 KB of LDS per wave -> 8 waves per CU = TWO per SIMD, whose FP64 chains
 //              interleave. HBM is touched at entry and exit only (plus the conditional stale copy, below).
+//              Horizons whose duals outgrow 256 registers run ONE wavefront per SIMD with all 512 (run-time specialised,
+//              tinympc_jit.hip); a workgroup is four wavefronts where the LDS plan allows it, so that mid-size batches
+//              spread over the CUs wavefront by wavefront (d_wpg below).
 //
 // Per sweep step the instruction stream is one asm block (tinympc_solve_d_chain.h): mov + (nx+nu) fused DPP FMAs +
 // the 8-instruction row-local block going forward, (nx+nu) FMAs + 3 going backward; no address arithmetic (LDS
@@ -19,8 +22,10 @@
 //     (two different DPP sources), so [x_i; d_i] / [p_{i+1}; r_i] are never merged into one register;
 //   * going backward every lane uses the SAME slot: slot s holds knot s+1 on state lanes and knot s on input lanes,
 //     q_s is folded into the accumulator's start value (state lanes) instead of being added after the mat-vec;
-//   * a converged instance is frozen by EXEC (its 16 lanes are one DPP row, so row_newbcast never crosses the mask),
-//     not by redirecting stores.
+//   * a converged instance keeps iterating as a zombie (no EXEC-masked region around the unrolled body); its state was
+//     written back before the sweeps touch it again (see the control comment in the body).
+// Run-time specialised variants (C++ between the asm blocks): FAM -- the cone / linear-inequality families --, and ADAPT --
+// adaptive rho with rho per lane; see k_admm_solve_d_body.
 // The sweep operators' rows (16 doubles per lane each) are re-read from LDS at the start of every sweep: holding both
 // for the whole solve would cost 32 more VGPRs than the budget has.
 //
