@@ -17,7 +17,7 @@
 // every per-lane array; two wavefronts share a SIMD.) The MFMA layouts (MI355X_MICROARCH.md) make the
 // data flow closed: a result register D_t[reg] holds out[16t + (lane>>4) + 4 reg][instance lane&15], and the B operand of
 // k-block kb = 4t + reg wants x[4kb + (lane>>4)][instance lane&15] -- the same lane, the same value. So the operand vector
-// of the next step is the result of this one, exchanged between the four wavefronts through a double-buffered LDS array
+// of the next step is the result of this one, exchanged between the wavefronts of the tile through a double-buffered LDS array
 // Xb[kb][lane] behind ONE barrier per step; nothing is ever transposed.
 // Everything row-local (slack projection, dual ascent, residual maxima, linear cost) happens on the result registers, 4
 // (row, instance) entries per lane. The ADMM state does not fit on chip at these sizes (16 instances x 128 rows x N knots x
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
-        // ================= R1: termination (admm.cpp:93-101), per instance over all rows and all four waves =================
+        // ================= R1: termination (admm.cpp:93-101), per instance over all rows and all wavefronts of the tile =================
         bool conv = false;
         if (check) {
             const bool below = (pri_x < p.abs_pri_tol) && (pri_u < p.abs_pri_tol) && (dua_x * rho < p.abs_dua_tol) && (dua_u * rho < p.abs_dua_tol);
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             }
         }
     }
-    // residual norms of the last check: max over this instance's lanes in the wave, then over the four waves
+    // residual norms of the last check: max over this instance's lanes in the wave, then over the wavefronts of the tile
     __syncthreads();
     double *sR = &sX[0][0][0];  // reuse: [8 waves][4 norms][16 instances]
     {
