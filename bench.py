@@ -59,7 +59,20 @@ def parse_args():
     return ap.parse_args()
 
 
+def rccl_environment() -> None:
+    """Everything the multi-process GPU path needs in the environment, set before anything initialises HIP (and inherited
+    by the torchrun children):
+      HSA_ENABLE_IPC_MODE_LEGACY=0  the host driver of this pool only supports dmabuf IPC; without it RCCL's
+                                    hipIpcGetMemHandle fails with `invalid argument` as soon as two ranks exchange buffers
+      MASTER_ADDR=127.0.0.1         single-node rendezvous; the container's hostname may not resolve
+    Values already present are respected."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+
 def relaunch_under_torchrun(args) -> int:
+    rccl_environment()
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -145,16 +158,61 @@ def library_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def usable_cpus():
+    """What this process may actually run on: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() ignores both).
+    Returns (sorted list of CPU ids, quota in CPUs or None, where the quota was read)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    quota, src = None, None
+    try:  # cgroup v2
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            quota, src = float(q) / float(per), "/sys/fs/cgroup/cpu.max"
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota, src = q / per, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"
+        except (OSError, ValueError):
+            pass
+    return cpus, quota, src
+
+
 def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
-    """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host
-    cores: one PROCESS per logical CPU (Eigen's per-operation malloc makes threads of one process contend),
-    each running seeded cold-started solves for `seconds`. Runs before this process initialises the GPU."""
-    cores = os.cpu_count() or 1
+    """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host cores this
+    process may use: one PROCESS per usable CPU (Eigen's per-operation malloc makes threads of one process contend), each
+    pinned to its own CPU of the affinity mask, the count capped by the cgroup quota, each running seeded cold-started
+    solves for `seconds`. `cores` is the number of workers that ran; `effective_parallelism` = summed rate / the rate of one
+    process alone says what the box really gave them. Runs before this process initialises the GPU."""
+    cpus, quota, quota_src = usable_cpus()
+    nworkers = len(cpus)
+    if quota is not None:
+        nworkers = max(1, min(nworkers, int(quota + 0.5)))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-seconds", str(seconds),
            "--iters", str(iters), "--horizon", str(horizon)]
+
+    def pin(cpu):
+        def f():
+            try:
+                os.sched_setaffinity(0, {cpu})
+            except (AttributeError, OSError):
+                pass
+        return f
+
+    # one process alone first, for the per-core anchor (SURVEY.md section 6) -- on an otherwise idle host
+    one = subprocess.run(cmd + ["--worker-index", "0", "--cpu-seconds", "2"], stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.split()
+    single = int(one[-2]) / float(one[-1]) if len(one) >= 3 else float("nan")
     t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd + ["--worker-index", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-             for i in range(cores)]
+    procs = [subprocess.Popen(cmd + ["--worker-index", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              preexec_fn=pin(cpus[i % len(cpus)]))
+             for i in range(nworkers)]
     total, kind, rates = 0, "port", []
     for pr in procs:
         out, _ = pr.communicate()
@@ -165,10 +223,6 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
         except (ValueError, IndexError):
             pass
     wall = time.perf_counter() - t0
-    # one process alone, for the per-core anchor
-    one = subprocess.run(cmd + ["--worker-index", "0", "--cpu-seconds", "2"], stdout=subprocess.PIPE,
-                         stderr=subprocess.DEVNULL, text=True).stdout.split()
-    single = int(one[-2]) / float(one[-1]) if len(one) >= 3 else float("nan")
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -180,15 +234,23 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
         pass
     value = sum(rates)
     physical = physical_cores()
+    eff = value / single if single == single and single > 0 else None
+    note = None
+    if eff is not None and len(rates) > 1.2 * eff:
+        note = ("%d pinned workers delivered the throughput of %.1f undisturbed single processes: SMT siblings share a core's FP units "
+                "(%s physical cores) and %.0f s of work took %.1f s of wall clock" % (len(rates), eff, physical, seconds, wall))
     rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
-                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.split()
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.split()
     rocket_us = 1e6 * float(rocket[-1]) / int(rocket[-2]) if len(rocket) >= 2 and int(rocket[-2]) > 0 else None
-    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates), "cores_logical": cores,
-            "cores_physical": physical, "kind": kind,
+    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates),
+            "effective_parallelism": eff, "affinity_cpus": len(cpus), "cgroup_quota": quota, "cgroup_quota_source": quota_src,
+            "cores_logical": os.cpu_count(), "cores_physical": physical, "kind": kind,
             "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={horizon} solves, {len(rates)} single-threaded "
-                      f"processes x {seconds:.0f} s each ({wall:.1f} s wall; seeded x0, same settings as the GPU run)",
+                      f"processes, each pinned to one CPU of the affinity mask, x {seconds:.0f} s each ({wall:.1f} s wall; seeded x0, "
+                      f"same settings as the GPU run)",
             "single_process_iters_per_s": single, "us_per_iter_single_process": 1e6 / single if single == single else None,
-            "cpu_model": cpu_model}
+            "physical_cores_x_single_process": (physical * single) if physical and single == single else None,
+            "note": note, "cpu_model": cpu_model}
 
 
 def main() -> int:
@@ -197,6 +259,7 @@ def main() -> int:
         return cpu_worker(args.cpu_seconds, args.iters, args.horizon, args.worker_index)
     if args.cpu_worker_rocket:
         return cpu_worker_rocket(args.cpu_seconds, args.iters)
+    rccl_environment()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         return relaunch_under_torchrun(args)  # nothing has touched the GPU yet
@@ -229,10 +292,9 @@ def main() -> int:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     prob = P.quadrotor(args.horizon)
-    strong = args.global_batch > 0
-    total_instances = args.global_batch if strong else args.batch_per_gpu * world
+    total_instances, first, count, scaling = pkg.batch.job_shard(rank, world, args.batch_per_gpu, args.global_batch)
+    strong = scaling == "strong"
     B = total_instances // world if strong else args.batch_per_gpu  # nominal per-GPU share (reports only)
-    first, count = pkg.batch.shard_range(total_instances, rank, world)
     x0_host = P.quadrotor_batch_x0(count, offset=first)              # (12, count), seeded per global instance index
     x0_dev = torch.from_numpy(np.ascontiguousarray(x0_host.T)).to(dev)  # [count][nx] == nx x count column-major
 
@@ -264,6 +326,15 @@ def main() -> int:
     t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # every rank's own numbers, so that a straggler shows (the headline uses the MAX, as the contract asks)
+    mine = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1), float(count), float(first)], dtype=torch.float64, device=dev)
+    if use_dist:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    else:
+        gathered = [mine]
+    per_rank = [{"rank": i, "elapsed_s": float(g[0]), "kernel_ms_avg": float(g[1]), "instances": int(g[2]), "first_instance": int(g[3]),
+                 "iters_per_s": float(g[2]) * args.iters * args.steps / float(g[0])} for i, g in enumerate(gathered)]
     elapsed, kernel_ms_avg = float(t[0]), float(t[1])
 
     # after the timed region: the one collective of the batched mode (summary statistics)
@@ -318,7 +389,8 @@ def main() -> int:
             "metric": "ADMM iterations/s, batched quadrotor nx=12 nu=4 N=%d (instance-iterations/s, whole job)" % prob.N,
             "value": value, "unit": "ADMM iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "vs_baseline_note": "BASELINE.md section 1: the reference publishes no number for this metric",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": "quadrotor hover nx=12 nu=4 N=%d, box x in [-5,5] u in [-0.5,0.5], rho=5, cold start, "
                                    "%d forced ADMM iterations per solve (tol 0, check_termination 1), %d instances per GPU "
                                    "(BASELINE config 5 = 65,536 instances at 8 GPUs)" % (prob.N, args.iters, B),
@@ -341,6 +413,7 @@ def main() -> int:
                          "hbm_measured_frac_of_peak": (traffic / kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None},
             "parity_check": parity,
             "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if use_dist else None),
+            "per_rank": per_rank,
             "launch": info,
             "summary": summary,
         }

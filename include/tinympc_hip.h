@@ -238,9 +238,14 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
  *                           (tinympc_set_x_ref / _set_u_ref: picked up by the next step)
  *   tinympc_session_step    x0 in (nx), first controls out (nu); tinympc_get_solution / _get_stats work as usual
  *   tinympc_session_end     stops the kernel; the handle continues with ordinary solves from the same ADMM state.
- * Any other verb that needs the device ends the session implicitly. The resident kernel leaves on its own after 2 s
- * without a command (a crashed host does not leave it spinning); the next step restarts it transparently. Results are
- * identical, bit for bit, to the same ticks issued as tinympc_mpc_step_batch calls. */
+ * Any other verb that needs the device ends the session implicitly, and so do tinympc_update_settings,
+ * tinympc_set_cone_constraints and tinympc_set_linear_constraints (the resident kernel carries the settings and
+ * families it was launched with): call tinympc_session_begin again afterwards. The resident kernel leaves on its own
+ * after 2 s without a command (a crashed host does not leave it spinning); the next step restarts it transparently.
+ * While the resident kernel spins, calls that synchronise the whole DEVICE (hipFree / hipMalloc of another handle's
+ * setup or reset, hipDeviceSynchronize, torch.cuda.synchronize) wait for it -- up to the 2 s idle time-out: end the
+ * session before such calls. Results are identical, bit for bit, to the same ticks issued as tinympc_mpc_step_batch
+ * calls. */
 int tinympc_session_begin(tinympc_solver *s);
 int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out);
 int tinympc_session_end(tinympc_solver *s);

@@ -21,13 +21,18 @@ import pyoracle as O  # noqa: E402
 
 def main():
     out_path, total = sys.argv[1], int(sys.argv[2])
+    strong = len(sys.argv) > 3 and sys.argv[3] == "strong"  # bench.py --global-batch: the total is fixed, shards may be ragged
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = ge.load_package()
     P, B = pkg.problems, pkg.batch
     prob = P.quadrotor(20)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=120, check_termination=1)
-    first, count = B.shard_range(total, rank, world)
+    if strong:
+        total_, first, count, kind = B.job_shard(rank, world, batch_per_gpu=4096, global_batch=total)
+        assert (total_, kind) == (total, "strong")
+    else:
+        first, count = B.shard_range(total, rank, world)
     x0s = P.quadrotor_batch_x0(count, offset=first)
     orc = O.OraclePort(prob).load_problem(prob, settings)
     sx, su, iters, status, res = orc.solve_batch(x0s)

@@ -21,12 +21,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("total", [10, 7])
-def test_two_rank_sharded_batch_matches_unsharded(pkg, tmp_path, total):
+@pytest.mark.parametrize("total,mode", [(10, "weak"), (7, "weak"), (9, "strong")])
+def test_two_rank_sharded_batch_matches_unsharded(pkg, tmp_path, total, mode):
     out = tmp_path / "result.json"
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(total)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(total), mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = json.loads(out.read_text())
@@ -50,3 +50,19 @@ def test_summary_without_process_group(pkg):
     B = pkg.batch
     s = B.allreduce_summary(B.local_summary(np.array([3, 5]), np.array([1, 11]), np.array([[1e-3, 2e-3], [3e-3, 1e-3], [5e-4, 1e-4], [2e-3, 9e-3]])))
     assert s == dict(instances=2, converged=1, total_iterations=8, max_primal_residual=2e-3, max_dual_residual=9e-3)
+
+
+def test_job_shard_weak_and_strong(pkg):
+    """bench.py's split: --batch-per-gpu fixes the shard (weak), --global-batch the total (strong, ragged where it does not divide)."""
+    B = pkg.batch
+    for world in (1, 2, 3, 8):
+        shards = [B.job_shard(r, world, batch_per_gpu=8192) for r in range(world)]
+        assert all(s[0] == 8192 * world and s[2] == 8192 and s[3] == "weak" for s in shards)
+        assert [s[1] for s in shards] == [8192 * r for r in range(world)]
+        for total in (65536, 1001, world):
+            shards = [B.job_shard(r, world, batch_per_gpu=8192, global_batch=total) for r in range(world)]
+            assert all(s[0] == total and s[3] == "strong" for s in shards)
+            assert sum(s[2] for s in shards) == total and max(s[2] for s in shards) - min(s[2] for s in shards) <= 1
+            assert [s[1] for s in shards] == [sum(t[2] for t in shards[:r]) for r in range(world)]  # contiguous, in rank order
+    with pytest.raises(ValueError):
+        B.job_shard(0, 8, global_batch=5)

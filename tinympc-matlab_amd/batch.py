@@ -21,6 +21,17 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
     return first, count
 
 
+def job_shard(rank: int, world: int, batch_per_gpu: int = 0, global_batch: int = 0) -> tuple[int, int, int, str]:
+    """The split bench.py runs: weak scaling (`batch_per_gpu` instances on every rank) unless `global_batch` > 0 fixes
+    the TOTAL (strong scaling; ragged shards when it does not divide). Returns (total, first, count, "weak"|"strong")."""
+    strong = global_batch > 0
+    total = int(global_batch) if strong else int(batch_per_gpu) * int(world)
+    if total < world:
+        raise ValueError(f"{total} instances cannot be split over {world} ranks")
+    first, count = shard_range(total, rank, world)
+    return total, first, count, "strong" if strong else "weak"
+
+
 def local_summary(iters: np.ndarray, status: np.ndarray, residuals: np.ndarray) -> dict:
     """Per-shard summary: instances, converged, sum of iterations, max primal / dual residual."""
     res = np.asarray(residuals, dtype=np.float64).reshape(4, -1)

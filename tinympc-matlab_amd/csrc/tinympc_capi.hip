@@ -1002,6 +1002,7 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
     if (rc) return rc;
     if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
     if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
+    HIP_TRY(hipSetDevice(s->device));  // (the restart path below launches; a multi-GPU caller may have another device current)
     int flags = 0;
     if (s->refs_on_host) flags = 2;  // full re-read (covers any pending shift: the pinned copies are current)
     else flags = (s->xref_shift ? 4 : 0) | (s->uref_shift ? 8 : 0);
@@ -1214,6 +1215,7 @@ int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, cons
     if (nlx < 0 || nlu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative constraint count");
     if ((nlx > 0 && (!Alin_x || !blin_x)) || (nlu > 0 && (!Alin_u || !blin_u)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_linear_constraints: NULL matrix for a non-empty side");
+    if (s->session_active && (rc = bind_device(s))) return rc;  // the resident kernel was started with the old families
     if (nlx > MAX_LIN_ROWS || nlu > MAX_LIN_ROWS)
         return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d linear rows per side are supported by the HIP kernel (got %d state, %d input)",
                     MAX_LIN_ROWS, nlx, nlu);
@@ -1245,6 +1247,7 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
     if (ncx < 0 || ncu < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "negative cone count");
     if ((ncx > 0 && (!Acx || !qcx || !cx)) || (ncu > 0 && (!Acu || !qcu || !cu)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_cone_constraints: NULL array for a non-empty side");
+    if (s->session_active && (rc = bind_device(s))) return rc;  // the resident kernel was started with the old families
     // Each cone must lie inside its vector and cones of one side must not share rows: the kernel projects
     // all cones of a knot at once (upstream applies them one after another, which only differs if they overlap).
     auto check_side = [&](const int *Ac, const int *qc, const double *c, int n, int dim, const char *side) -> int {
@@ -1288,6 +1291,10 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
     int rc = check_handle(s);
     if (rc) return rc;
     if (max_iter < 0) return fail(TINYMPC_ERR_INVALID_INPUT, "max_iter must be >= 0");
+    // A resident session kernel carries the settings it was launched with (max_iter, tolerances, family flags): end it, so
+    // that nothing switches behaviour in the middle of a session or bypasses the checks of tinympc_session_begin on a
+    // restart after the idle time-out. The next tinympc_session_begin starts one with the new settings.
+    if (s->session_active && (rc = bind_device(s))) return rc;
     const bool bounds_changed = (s->st.en_state_bound != en_state_bound) || (s->st.en_input_bound != en_input_bound);
     s->st.abs_pri_tol = abs_pri_tol; s->st.abs_dua_tol = abs_dua_tol;
     s->st.max_iter = max_iter; s->st.check_termination = check_termination;
