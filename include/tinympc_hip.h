@@ -277,11 +277,19 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
 int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave,
                             int *workgroups, int *lds_bytes, int *tables_in_lds);
 
-/* Which solve kernel the handle uses for box-constrained solves: 'A' (all ADMM state in LDS, one wavefront per
- * workgroup), 'B' (V L2-resident in HBM, four wavefronts per workgroup; large batches) or 'C' (one instance per
- * workgroup, horizon swept in 16 concurrent chunks; batches up to 768 and every single solve). The
- * environment variable TINYMPC_LAYOUT=A|B|C overrides the choice at setup. 0 for a NULL handle. */
+/* Which solve kernel the handle's next launch uses: 'A' (all ADMM state in LDS, one wavefront per workgroup), 'B' (V
+ * L2-resident in HBM, four wavefronts per workgroup), 'C' (one instance per workgroup, horizon swept in 16 concurrent
+ * chunks; batches up to 768 and every single solve), 'D' (horizon unrolled at compile time, state in registers; large
+ * batches), 'E' (as D with the horizon cut across the wavefronts of a workgroup: cone / linear families at long horizons),
+ * 'M' (64 < nx+nu <= 128 on the FP64 matrix cores). The environment variable TINYMPC_LAYOUT=A|B|C|D|E overrides the choice.
+ * 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
+
+/* Where the kernel of the handle's CURRENT configuration comes from, as text: "compiled-in layout=X", or for the run-time
+ * specialised kernels (layouts D and E) "compiled ..." / "disk-cache ..." with the code object's register count, scratch and LDS
+ * bytes, or "refused(<reason>)" when the specialiser declined (plan overflow, spills, compile error, TINYMPC_JIT=0) and the
+ * launch falls back to a generic kernel. Refusals are also printed once to stderr (TINYMPC_JIT_QUIET=1 silences them). */
+int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len);
 
 /* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:
  * bounds / references that vary over the horizon, cone / linear families and adaptive rho select variants that are otherwise

@@ -232,6 +232,87 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
     assert (results["1"][0][1]["status"] == 1).any() and (results["1"][1][1]["iter"] < results["1"][0][1]["iter"]).any()
 
 
+@pytest.mark.parametrize("variant", ["cones", "linear", "both", "both_constant_references", "input_cone_only"])
+@pytest.mark.parametrize("N", [100, 44, 10])
+def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
+    """Long horizons, batches: the families on layout E (tinympc_solve_e.hip: the horizon cut across the eight wavefronts of
+    a workgroup, run-time specialised on the cone list and the linear rows per side). Cold start and a warm start against the
+    restatement for every instance -- iteration counts and statuses exact --, and against the latency kernel on the same handle
+    (the two share the persistent HBM state). N=100: eight chunks of 13, the last one 8; N=44: eight chunks would leave the last
+    wavefront one slot, so the plan is four wavefronts (one per SIMD, 512 registers) with chunks of 11 and 10; N=10: no plan at all
+    (chunks of at least three slots) -- the refusal path: the handle says so and runs on another kernel."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.setenv("TINYMPC_LAYOUT", "E")
+    P = pkg.problems
+    rk = P.rocket(N, with_linear=variant in ("linear", "both", "both_constant_references"))
+    if variant == "linear":
+        rk.cones = {}
+    if variant == "input_cone_only":
+        rk.cones = dict(Acx=[], qcx=[], cx=[], Acu=[0], qcu=[3], cu=[0.25])
+    if variant == "both_constant_references":
+        rk.x_ref = np.repeat(rk.x_ref[:, :1], N, axis=1)
+    settings = dict(max_iter=150, abs_pri_tol=2e-3, abs_dua_tol=1e-4)
+    batch = 203  # ragged last group of four
+    rng = np.random.default_rng(N)
+    x0a = rk.x0[:, None] * rng.uniform(0.6, 1.2, (1, batch)) + 0.1 * rng.standard_normal((6, batch))
+    x0b = x0a + 0.05 * rng.standard_normal((6, batch))
+    s = make(pkg, rk, settings, batch=batch)
+    s.prepare()
+    info = s.jit_info()
+    if N == 10:
+        assert s.launch_info()["layout"] != "E" and info.startswith("refused("), info
+        s.set_x0_batch(x0a)
+        s.solve()  # (on the fallback kernel)
+        assert np.all(s.get_stats_batch()["iter"] > 0)
+        s.reset()
+        return
+    assert s.launch_info()["layout"] == "E" and (info.startswith("compiled ") or info.startswith("disk-cache ")) and "scratch=0" in info, info
+    out = []
+    for x0s in (x0a, x0b):
+        s.set_x0_batch(x0s)
+        s.solve()
+        out.append((s.get_solution_batch(), s.get_stats_batch()))
+    orc = [oracle(rk, settings) for _ in range(batch)]
+    for rnd, x0s in enumerate((x0a, x0b)):
+        sol, st = out[rnd]
+        for b in range(batch):
+            orc[b].set_x0(x0s[:, b])
+            orc[b].solve()
+        np.testing.assert_array_equal(st["iter"], np.array([o.stats()["iter"] for o in orc]))
+        np.testing.assert_array_equal(st["status"], np.array([o.stats()["status"] for o in orc]))
+        for b in range(batch):
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL, (rnd, b)
+            assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+        res = np.array([[o.stats()[k] for k in ("pri_x", "dua_x", "pri_u", "dua_u")] if "pri_x" in o.stats() else [np.nan] * 4 for o in orc]).T
+        if not np.isnan(res).any():
+            assert rel_err(st["residuals"], res) < 1e-6
+    assert (out[0][1]["status"] == 1).any() and (out[1][1]["iter"] < out[0][1]["iter"]).any()
+    # a third solve on the latency kernel from the state layout E left behind, against the restatement's third solve
+    monkeypatch.setenv("TINYMPC_LAYOUT", "C")
+    x0c = x0b * 0.97
+    s.set_x0_batch(x0c)
+    s.solve()
+    assert s.launch_info()["layout"] == "C"
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    for b in range(0, batch, 5):
+        orc[b].set_x0(x0c[:, b])
+        orc[b].solve()
+        assert st["iter"][b] == orc[b].stats()["iter"] and rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, b
+    # ... and back
+    monkeypatch.setenv("TINYMPC_LAYOUT", "E")
+    x0d = x0c * 1.02
+    s.set_x0_batch(x0d)
+    s.solve()
+    assert s.launch_info()["layout"] == "E"
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    for b in range(0, batch, 5):
+        orc[b].set_x0(x0d[:, b])
+        orc[b].solve()
+        assert st["iter"][b] == orc[b].stats()["iter"] and rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, b
+    s.reset()
+
+
 def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypatch):
     """tinympc_prepare: the variant decision (here: families on layout D) is taken -- and the kernel built -- before the first
     solve, so that launch_info already names it and the first tick does not pay for it."""

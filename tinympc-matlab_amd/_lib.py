@@ -92,6 +92,7 @@ SIGNATURES = {
     "tinympc_get_launch_info": (C.c_int, [Handle, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "tinympc_get_layout": (C.c_int, [Handle]),
     "tinympc_prepare": (C.c_int, [Handle]),
+    "tinympc_get_jit_info": (C.c_int, [Handle, C.c_char_p, C.c_int]),
     "tinympc_get_stream": (C.c_void_p, [Handle]),
 }
 

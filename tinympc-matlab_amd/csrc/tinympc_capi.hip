@@ -66,6 +66,8 @@ constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
 // mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
 // GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
+constexpr int kLayoutEBatchMin = 384;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
+                                        // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
 constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
                                        // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
 
@@ -114,6 +116,16 @@ struct tinympc_solver {
     int d_adapt = -1;       // ... and with adaptive rho
     int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
     int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
+    // Layout E (tinympc_solve_e.hip, run-time specialised on the families' STRUCTURE): the horizon cut across the wavefronts of a
+    // workgroup -- the throughput kernel for the families at horizons layout D cannot hold. Decided per launch
+    // (decide_layout_variants): `e_sig` is the structure / table kind the answer `e_ok` belongs to.
+    FamilyStructure fs;
+    std::string e_sig;
+    bool e_ok = false;
+    int e_chunk_len = 0, e_wpg = 0;
+    size_t e_lds = 0;
+    double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
+    int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
     bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
     bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
@@ -165,6 +177,7 @@ struct tinympc_solver {
     bool use_layout_d() const {
         return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
     }
+    bool use_layout_e() const { return e_ok && families_active() && !st.adaptive_rho && !use_layout_d(); }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
@@ -267,8 +280,16 @@ int refresh_derived(tinympc_solver *s) {
             c.ops = s->dops; c.out = s->dctab;
             HIP_TRY(launch_build_chunk_tables(c, s->stream));
         }
+        s->dctab_e_len = 0;  // (layout E's carry matrices are rebuilt on demand, below)
         s->ops_dirty = false;
         s->tables_dirty = true;
+    }
+    if (s->e_ok && s->dctab_e && s->dctab_e_len != s->e_chunk_len) {  // Phi^S, Psi^S for layout E's chunk length
+        ChunkTableParams c{};
+        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->e_chunk_len; c.Lc = 1;
+        c.ops = s->dops; c.out = s->dctab_e;
+        HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        s->dctab_e_len = s->e_chunk_len;
     }
     if (s->tables_dirty) {
         TableParams p{};
@@ -280,6 +301,38 @@ int refresh_derived(tinympc_solver *s) {
         s->tables_dirty = false;
     }
     return TINYMPC_OK;
+}
+
+// The ACTIVE cones in list order (state cones, then input cones) with their rounds, and the linear rows per side: what layout E
+// is specialised on (FamilyStructure, tinympc_device.h). `mu` receives the slopes in the same order.
+FamilyStructure family_structure(const tinympc_solver *s, double *mu = nullptr) {
+    FamilyStructure fs;
+    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
+    unsigned used = 0;  // lanes taken by the cones of the current round
+    auto add = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
+        if (!on) return;
+        for (size_t k = 0; k < Ac.size() && fs.ncone < MAX_CONES; ++k) {
+            const int first = base + Ac[k], last = first + qc[k] - 1;
+            unsigned lanes = 0;
+            for (int r = first; r <= last; ++r) lanes |= 1u << r;
+            if (fs.ncone == 0) fs.nround = 1;
+            if (lanes & used) {  // overlaps an earlier cone of this round: upstream projects one after the other
+                fs.nround += 1;
+                used = 0;
+            }
+            used |= lanes;
+            fs.cone[fs.ncone][0] = fs.nround - 1;
+            fs.cone[fs.ncone][1] = first;
+            fs.cone[fs.ncone][2] = last;
+            if (mu) mu[fs.ncone] = c[k];
+            fs.ncone += 1;
+        }
+    };
+    add(cone_x, s->Acx, s->qcx, s->cx, 0);
+    add(cone_u, s->Acu, s->qcu, s->cu, s->nx);
+    fs.nlx = (s->st.en_state_linear && s->n_lin_x > 0) ? s->n_lin_x : 0;
+    fs.nlu = (s->st.en_input_linear && s->n_lin_u > 0) ? s->n_lin_u : 0;
+    return fs;
 }
 
 // Per-lane description of the cone / linear families for k_admm_solve_fam (layout: fam_doubles()).
@@ -339,6 +392,7 @@ int refresh_families(tinympc_solver *s) {
             if (r >= nx && r < nxu && k < nlu) { ak[r] = s->Alin_u[k + (size_t)(r - nx) * s->n_lin_u]; bk[r] = s->blin_u[k]; nk[r] = nrm_u; }
         }
     }
+    (void)family_structure(s, f.data() + fam_cone_mu_offset(W, KT));  // slopes of the active cones, in list order (layout E)
     int rc = upload(s, s->dfam, f.data(), f.size());
     if (rc) return rc;
     s->fam_dirty = false;
@@ -379,10 +433,38 @@ void decide_layout_d_variants(tinympc_solver *s) {
     }
 }
 
+// Layout E for the families where layout D has no kernel (long horizons): asked whenever the structure of the families or the
+// kind of the tables changed (the kernel is specialised on both; compiling takes seconds the first time, the answer is cached
+// inside tinympc_jit.hip). TINYMPC_LAYOUT=E forces it at any batch size (tests), any other value excludes it.
+int decide_layout_e(tinympc_solver *s) {
+    bool want = s->W == 16 && !s->layout_m && s->families_active() && !s->st.adaptive_rho && !s->use_layout_d() && s->batch >= kLayoutEBatchMin;
+    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'E' || env[0] == 'e') && s->W == 16 && !s->layout_m && s->families_active() && !s->st.adaptive_rho;
+    if (!want) {
+        s->e_ok = false;
+        s->e_sig.clear();
+        return TINYMPC_OK;
+    }
+    const FamilyStructure fs = family_structure(s);
+    std::string sig = s->tables_const() ? "ct|" : "var|";
+    for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
+    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu);
+    if (sig == s->e_sig) return TINYMPC_OK;
+    s->e_sig = sig;
+    s->fs = fs;
+    s->e_ok = solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), true, fs) &&
+              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), true, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds);
+    if (s->e_ok && !s->dctab_e) {
+        int rc = dalloc(s, &s->dctab_e, chunk_table_doubles(s->nx, 1));
+        if (rc) return rc;
+    }
+    return TINYMPC_OK;
+}
+
 int launch(tinympc_solver *s, bool timed) {
     int rc;
     s->flag_pending = false;
     decide_layout_d_variants(s);
+    if ((rc = decide_layout_e(s))) return rc;
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
     if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts
@@ -449,6 +531,10 @@ int launch(tinympc_solver *s, bool timed) {
     } else if (fam && s->use_layout_d()) {
         p.families = 1;
         HIP_TRY(launch_solve_jit(p, s->W, s->stream));
+    } else if (fam && s->use_layout_e()) {
+        p.families = 1;
+        p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
+        HIP_TRY(launch_solve_e(p, s->fs, s->stream));
     } else if (fam && s->fam_c) {
         // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
@@ -1477,10 +1563,12 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active(), s->st.adaptive_rho != 0) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
+    if (workgroups && s->use_layout_e()) *workgroups = s->groups;
+    else if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active(), s->st.adaptive_rho != 0) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) {
         size_t l = s->layout_c ? s->lds_bytes_c : s->lds_bytes;
         if (s->layout_m) l = 0;  // (static LDS: see the kernel)
+        else if (s->use_layout_e()) l = s->e_lds;
         else if (s->use_layout_d())
             l = (s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit))
                     ? solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, s->tables_const(), s->families_active(), s->st.adaptive_rho != 0)
@@ -1495,6 +1583,7 @@ int tinympc_get_layout(tinympc_solver *s) {
     if (!s) return 0;
     if (s->layout_m) return 'M';
     if (s->use_layout_d()) return 'D';
+    if (s->use_layout_e()) return 'E';
     // the families and adaptive rho have kernels of their own on layout A's plan (the families also in the latency kernel)
     if (s->families_active()) return s->fam_c ? 'C' : 'A';
     if (s->st.adaptive_rho) return 'A';
@@ -1506,6 +1595,22 @@ int tinympc_prepare(tinympc_solver *s) {
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
     decide_layout_d_variants(s);
+    return decide_layout_e(s);
+}
+
+int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!buf || len < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "get_jit_info: buffer required");
+    buf[0] = '\0';
+    const bool fam = s->families_active(), adaptive = s->st.adaptive_rho != 0;
+    if (s->layout_m) snprintf(buf, (size_t)len, "compiled-in layout=M");
+    else if (!s->e_sig.empty() && fam && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), true, s->fs, buf, (size_t)len);
+    else if (s->use_layout_d() && !(s->d_jit || fam || adaptive || (!s->tables_const() && s->d_varying_jit))) snprintf(buf, (size_t)len, "compiled-in layout=D");
+    else if (s->layout_d || s->d_jit) {
+        if ((rc = bind_device(s))) return rc;
+        solve_jit_describe(s->W, s->nx, s->nu, s->N, s->tables_const(), fam && !adaptive, adaptive && !fam, buf, (size_t)len);
+    } else snprintf(buf, (size_t)len, "compiled-in layout=%c", (char)tinympc_get_layout(s));
     return TINYMPC_OK;
 }
 

@@ -180,10 +180,47 @@ struct AdaptTableParams {
 //   Ty[W][KT] 0/1: columns = rows of the same side                   (dot = Ty * (a_k .* s))
 //   nl        number of linear rows in use (max over the two sides), then for k < MAX_LIN_ROWS:
 //   ak[W], bk[W], nk[W]   coefficient of the row in constraint k, its bound (+inf if absent), ||a_k||^2
+//   ... and, for layout E (which walks the cones one by one, in list order): cone_mu[MAX_CONES], the slope of cone c of the
+//   active list (state cones first, then input cones)
 constexpr int MAX_LIN_ROWS = 8;
-__host__ __device__ inline size_t fam_doubles(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
+constexpr int MAX_CONES = 16;
+__host__ __device__ inline size_t fam_cone_mu_offset(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
+__host__ __device__ inline size_t fam_doubles(int W, int KT) { return fam_cone_mu_offset(W, KT) + MAX_CONES; }
+
+// ---- layout E (tinympc_solve_e.hip): the horizon cut across the `wpg` wavefronts of a workgroup, S slots each (the last
+// wavefront: what is left). LDS plan per workgroup, in doubles:
+//   operators [2][16 k][16 r] | tables (!ct) | linear rows (fam) | carry matrices Phi^S, Psi^S [2][16 k][16 r] |
+//   carries fwd / bwd [2][wpg][64] | termination flags [16] | residual partials [wpg][16] |
+//   knot-0 state of the bottom wavefront + per-lane scalars [6][64] |
+//   per wavefront: the families' arrays that live in LDS -- gc, gl, lx, each [S][e_fam_row(nx+nu)], the four instances' real
+//   rows packed (`lds_arrays` of them) -- | d[S * 4 nu]
+__host__ __device__ constexpr int e_d_doubles(int nu, int S) { return (S * 4 * nu + 1) & ~1; }
+__host__ __device__ constexpr int e_fam_row(int nxu) { return (4 * nxu + 1) & ~1; }
+__host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl) {
+    return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 512 + 2 * wpg * 64 + 16 + wpg * 16 + 6 * 64;
+}
+__host__ __device__ constexpr int e_wave_doubles(int nxu, int nu, int S, int lds_arrays) {
+    return lds_arrays * S * e_fam_row(nxu) + e_d_doubles(nu, S);
+}
+__host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays) {
+    return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl) + (size_t)wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));
+}
 
 #ifndef __HIPCC_RTC__  // host side only
+// Structure of the cone / linear families, as layout E is specialised on it: the ACTIVE cones in list order (state cones, then
+// input cones) as {round, first lane, last lane} -- lane = row for a state row, nx + row for an input row; cones of one round
+// are pairwise disjoint, a cone that overlaps an earlier cone of the current round opens the next one -- and the number of
+// linear rows per side.
+struct FamilyStructure {
+    int ncone = 0, nround = 0, nlx = 0, nlu = 0;
+    int cone[MAX_CONES][3] = {};
+};
+// Layout E (tinympc_solve_e.hip, run-time specialised only): the horizon cut across the wavefronts of a workgroup
+bool solve_e_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *wpg, size_t *lds_bytes);
+bool solve_e_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
+hipError_t launch_solve_e(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
+void solve_e_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
+void solve_jit_describe(int W, int nx, int nu, int N, bool const_tables, bool families, bool adaptive, char *buf, size_t len);
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);

@@ -24,6 +24,15 @@
 #error "layout D: 1 <= nx, 1 <= nu, nx + nu <= 16"
 #endif
 
+// Run-time specialisations (TINY_JIT; tinympc_jit.hip) are compiled by hiprtc ON THE GPU BOX, where nothing can lint the
+// generated code: there every chain block opens with its own `s_nop 1`, whatever the compiler may have placed in front of it
+// (a register copy or v_accvgpr_read of `x` / `d` on the 512-register plan). The compiled-in instantiations keep the bare
+// blocks and are linted by the build (tools/isa_lint.py; the nop costs 1-2 % there).
+#if defined(TINY_JIT) || defined(TINY_CHAIN_NOP)
+#define D_HAZ "s_nop 1\n\t"
+#else
+#define D_HAZ ""
+#endif
 #define D_FM_(src, i) "v_fmac_f64_dpp %[a], " src ", %[m" #i "] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
 // column i of the chain: state operand, input operand, or nothing.
 // (The preprocessor cannot index, so each column is resolved by its own #if ladder.)
@@ -165,7 +174,7 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_reg(double x, double d, const double (&m)[16], double cf, double lo, double hi,
                                                      double &g, double &v, double &pri, double &dua) {
         double a, s, t, sn;
-        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_CHAIN D_PROJECT "v_mov_b64 %[v], %[sn]\n\t" D_WAIT
+        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT "v_mov_b64 %[v], %[sn]\n\t" D_WAIT
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), D_MOPS);
         return a;
@@ -174,9 +183,20 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_lds(double x, double d, const double (&m)[16], double cf, double lo, double hi,
                                                      double &g, double v, double &vnew, double &pri, double &dua) {
         double a, s, t;
-        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_CHAIN D_PROJECT D_WAIT
+        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT D_WAIT
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), D_MOPS);
+        return a;
+    }
+    // The bare sweep step a = c + M * [x; d] -- no row-local block behind it (layout E: pass 1 of a chunk and the carry
+    // recurrences, tinympc_solve_e.hip). Back to back, `x` is the `a` the previous block's last FMA wrote: the block's own
+    // s_waitcnt, the accumulator's start and an `s_nop 1` are the wait states in front of the first DPP read.
+    static __device__ __forceinline__ double fwd_plain(double x, double d, const double (&m)[16], double c) {
+        double a;
+        asm volatile("v_mov_b64 %[a], %[c]\n\t"
+                     "s_nop 1\n\t" D_CHAIN D_WAIT
+                     : [a] "=&v"(a)
+                     : [x] "v"(x), [d] "v"(d), [c] "v"(c), D_MOPS);
         return a;
     }
     // Backward step for slot s: a (in: accumulator start = q_s + cb on state lanes, cb on input lanes; out: p_s | d_s)
@@ -187,7 +207,7 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ void bwd(double &a, double x, double d, const double (&m)[16], double v2, double g2,
                                                double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
         double t;
-        asm volatile(D_CHAIN
+        asm volatile(D_HAZ D_CHAIN
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
                      "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
@@ -198,7 +218,7 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ void bwd_v(double &a, double x, double d, const double (&m)[16], double v2, double g2,
                                                  double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
         double t;
-        asm volatile(D_CHAIN
+        asm volatile(D_HAZ D_CHAIN
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
                      "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
@@ -207,13 +227,14 @@ struct DStep<D_NX, D_NU> {
     }
     // Last backward step (slot 0): nothing left to prepare.
     static __device__ __forceinline__ void bwd_last(double &a, double x, double d, const double (&m)[16]) {
-        asm volatile(D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
+        asm volatile(D_HAZ D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
     }
 };
 
 }  // namespace tinympc
 
 #undef D_FM_
+#undef D_HAZ
 #undef D_C0
 #undef D_C1
 #undef D_C2

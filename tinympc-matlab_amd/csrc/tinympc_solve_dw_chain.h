@@ -15,6 +15,13 @@
 #error "wide layout D: 16 < nx + nu <= 32"
 #endif
 #define DW_NXU (DW_NX + DW_NU)
+// (run-time specialisations cannot be linted where they are compiled: there the second block of a step is guarded too,
+// see tinympc_solve_d_chain.h)
+#ifdef TINY_JIT
+#define DW_HAZ "s_nop 1\n\t"
+#else
+#define DW_HAZ ""
+#endif
 #define DW_FE_(i) "v_fmac_f64_dpp %[a], %[e], %[m" #i "] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
 #define DW_FO_(i, b) "v_fmac_f64_dpp %[a], %[o], %[m" #i "] row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
 #define DW_LO DW_FE_(0) DW_FE_(1) DW_FE_(2) DW_FE_(3) DW_FE_(4) DW_FE_(5) DW_FE_(6) DW_FE_(7) DW_FE_(8) DW_FE_(9) DW_FE_(10) DW_FE_(11) DW_FE_(12) DW_FE_(13) DW_FE_(14) DW_FE_(15)
@@ -130,7 +137,7 @@ struct DWStep<DW_NX, DW_NU> {
     static __device__ __forceinline__ void hi_fwd_reg(double &a, double o, const double (&m)[32], double lo, double hi, double &g, double &v,
                                                       double &pri, double &dua) {
         double s, t, sn;
-        asm volatile(DW_HI DW_PROJECT "v_mov_b64 %[v], %[sn]\n\t" DW_WAIT
+        asm volatile(DW_HAZ DW_HI DW_PROJECT "v_mov_b64 %[v], %[sn]\n\t" DW_WAIT
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [o] "v"(o), [lo] "v"(lo), [hi] "v"(hi), DW_MHI);
     }
@@ -138,7 +145,7 @@ struct DWStep<DW_NX, DW_NU> {
     static __device__ __forceinline__ void hi_fwd_lds(double &a, double o, const double (&m)[32], double lo, double hi, double &g, double v,
                                                       double &vnew, double &pri, double &dua) {
         double s, t;
-        asm volatile(DW_HI DW_PROJECT DW_WAIT
+        asm volatile(DW_HAZ DW_HI DW_PROJECT DW_WAIT
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [o] "v"(o), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), DW_MHI);
     }
@@ -147,7 +154,7 @@ struct DWStep<DW_NX, DW_NU> {
     static __device__ __forceinline__ void hi_bwd(double &a, double o, const double (&m)[32], double v2, double g2, double rhom, double lrmc,
                                                   double nrho, double lr, double &an, double &rn) {
         double t;
-        asm volatile(DW_HI
+        asm volatile(DW_HAZ DW_HI
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
                      "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" DW_WAIT
@@ -155,7 +162,7 @@ struct DWStep<DW_NX, DW_NU> {
                      : [o] "v"(o), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), DW_MHI);
     }
     static __device__ __forceinline__ void hi_bwd_last(double &a, double o, const double (&m)[32]) {
-        asm volatile(DW_HI DW_WAIT : [a] "+v"(a) : [o] "v"(o), DW_MHI);
+        asm volatile(DW_HAZ DW_HI DW_WAIT : [a] "+v"(a) : [o] "v"(o), DW_MHI);
     }
 };
 

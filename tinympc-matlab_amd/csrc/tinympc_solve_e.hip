@@ -1,0 +1,746 @@
+// tinympc_solve_e.hip -- k_admm_solve_e ("layout E"): layout D's register-resident sweeps with the HORIZON CUT ACROSS THE
+// WAVEFRONTS OF A WORKGROUP. The throughput kernel for what no single wavefront can hold on chip: long horizons, and above all
+// the cone / linear-inequality families at long horizons (BASELINE config 4: rocket landing N=100 -- five arrays per knot).
+//
+// Layout D gives a wavefront (4 instances x 16 lanes) the whole horizon: 2 register pairs per knot for the box path, 5 with the
+// families -- N=100 with families is 990 VGPRs, and layout D ends at N ~ 30 there. Both sweeps are linear time-invariant
+// recurrences (the observation behind the latency kernel, tinympc_solve_c.hip), so the horizon can be cut:
+//     workgroup = 4 instances = WPG wavefronts; wavefront w owns the S consecutive slots [w S, (w+1) S) of all four instances
+//     (the last wavefront: the S_LAST that are left), every array of its slots in REGISTERS (or its own LDS region) for the
+//     whole solve, two wavefronts per SIMD as in layout D.
+//   forward    pass 1: the chunk's S steps from a ZERO incoming state (wavefront 0: from x_0), bare mat-vec chains, only the
+//              end value e_w is kept -> LDS -> ONE barrier -> every wavefront forms the true state entering its chunk by
+//              Horner over the chunks before it, X_w = Phi^S X_(w-1) + e_(w-1) (at most WPG-1 short mat-vecs; Phi^S from
+//              k_build_chunk_tables) -> pass 2: the real sweep with the row-local phases fused in, exactly layout D's step.
+//   backward   the same from the top. The cut is placed so that no wavefront needs a neighbour's linear-cost entry: the chain of
+//              chunk w starts from q~ + c_in, q~ = the q (p_{N-1} for the last chunk) of its OWN last state slot, and leaves out
+//              the q of its first knot, which the chunk below adds from its own registers. The termination ballots cross with the
+//              backward carries: TWO barriers per ADMM iteration.
+// Given exact carries pass 2 IS the sequential sweep; results differ from layouts A/B/D through the rounding of the carries
+// (~1e-14 relative), iteration counts match the restatement in every test.
+//
+// The families (PARITY UNPINNED upstream semantics, see tinympc_solve_fam.hip) are specialised on their STRUCTURE, which is a
+// compile-time input here (the kernel exists only as a run-time specialisation, tinympc_jit.hip): the cone list (in list order,
+// grouped into rounds of pairwise-disjoint cones; overlapping cones land in successive rounds = upstream's one-after-the-other
+// projection) and the number of linear rows per side. Cross-lane sums then need no mask rows (72 VGPRs in the other kernels):
+// a cone's ||w||^2 and t are gathered by dim DPP instructions under an EXEC mask of the cone's lanes, a linear row's dot
+// product by one DPP instruction per row of its side -- 6 + 9 instead of 36 instructions per knot for the rocket.
+//
+// Reference semantics that need care are layout D's (tinympc_solve_d.hip): per-instance termination, zombies, the stale copy
+// for converged solves (admm.cpp:181-197).
+#include <type_traits>
+
+#include "tinympc_device.h"
+#include "tinympc_sweep.h"
+
+#ifndef TINY_JIT  // build-time instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
+#define TINY_CHAIN_NOP 1  // the chain blocks as the run-time specialisations get them (tinympc_solve_d_chain.h)
+#define TINY_JIT_NX 6
+#define TINY_JIT_NU 3
+#define TINY_JIT_N 100
+#define TINY_JIT_CT 0
+#define TINY_JIT_FAM 1
+#define TINY_JIT_E_WPG 8
+#define TINY_JIT_E_S 13
+#define TINY_JIT_E_NROUND 1
+#define TINY_JIT_E_NCONE 2
+#define TINY_JIT_E_CONES {0, 0, 2}, {0, 6, 8}
+#define TINY_JIT_E_NLX 1
+#define TINY_JIT_E_NLU 0
+#define TINY_JIT_E_GC_LDS 1
+#define TINY_JIT_E_GL_LDS 1
+#define TINY_JIT_E_LX_LDS 1
+#endif
+
+namespace tinympc {
+template <int NX, int NU>
+struct DStep;  // tinympc_solve_d_chain.h
+}  // namespace tinympc
+#define D_NX TINY_JIT_NX
+#define D_NU TINY_JIT_NU
+#include "tinympc_solve_d_chain.h"
+
+namespace tinympc {
+
+template <int I, int E, class F>
+__device__ __forceinline__ void e_static_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        e_static_for<I + 1, E>(f);
+    }
+}
+
+constexpr int E_GROUP = 8;  // forward steps between two "can this sweep still converge" tests
+
+typedef __attribute__((address_space(3))) double e_lds_double_t;
+__device__ __forceinline__ unsigned e_lds_addr(const double *p) { return (unsigned)(size_t)(const e_lds_double_t *)p; }
+template <int OFF>
+__device__ __forceinline__ double e_lds_read_async(unsigned addr) {  // valid after the next s_waitcnt lgkmcnt(0)
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void e_lds_write_async(unsigned addr, double v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void e_lds_write_masked(unsigned addr, double v, unsigned long long mask) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "ds_write_b64 %[a], %[v] offset:%[o]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved)
+                 : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ void e_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// workgroup barrier that waits for this wavefront's LDS traffic only (not for its global stores, as __syncthreads() would)
+__device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ bool e_wave_may_converge(unsigned long long bad, unsigned long long live) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long b = (bad >> (j * 16)) & 0xffffull, l = (live >> (j * 16)) & 0xffffull;
+        any = any || (l != 0ull && b == 0ull);
+    }
+    return any;
+}
+
+// ---- cross-lane sums of the families under an EXEC mask --------------------------------------------------------------------
+// acc (lanes of `mask` only) = sum of w over the CNT lanes F .. F+CNT-1 of the lane's own DPP row; with HAS_T also
+// t = s of lane TL. Every source lane belongs to the mask itself (a cone's members and its t row; the rows of one side), so no
+// DPP read crosses into a disabled lane. ONE asm statement: nothing the compiler schedules may run under the narrowed EXEC.
+// Hazards: `w` / `s` are fresh VALU results (2 wait states before a DPP read) -- s_and_saveexec + `s_nop 1` in front.
+#define TINY_EG_HEAD "s_and_saveexec_b64 %[sx], %[mk]\n\ts_nop 1\n\t"
+#define TINY_EG_MOV "v_mov_b64_dpp %[acc], %[w] row_newbcast:%[c0] row_mask:0xf bank_mask:0xf\n\t"
+#define TINY_EG_FM(j) "v_fmac_f64_dpp %[acc], %[w], %[one] row_newbcast:%[c" #j "] row_mask:0xf bank_mask:0xf\n\t"
+#define TINY_EG_T "v_mov_b64_dpp %[t], %[s] row_newbcast:%[tl] row_mask:0xf bank_mask:0xf\n\t"
+#define TINY_EG_TAIL "s_mov_b64 exec, %[sx]"
+#define TINY_EG_1 TINY_EG_MOV
+#define TINY_EG_2 TINY_EG_1 TINY_EG_FM(1)
+#define TINY_EG_3 TINY_EG_2 TINY_EG_FM(2)
+#define TINY_EG_4 TINY_EG_3 TINY_EG_FM(3)
+#define TINY_EG_5 TINY_EG_4 TINY_EG_FM(4)
+#define TINY_EG_6 TINY_EG_5 TINY_EG_FM(5)
+#define TINY_EG_7 TINY_EG_6 TINY_EG_FM(6)
+#define TINY_EG_8 TINY_EG_7 TINY_EG_FM(7)
+#define TINY_EG_9 TINY_EG_8 TINY_EG_FM(8)
+#define TINY_EG_10 TINY_EG_9 TINY_EG_FM(9)
+#define TINY_EG_11 TINY_EG_10 TINY_EG_FM(10)
+#define TINY_EG_12 TINY_EG_11 TINY_EG_FM(11)
+#define TINY_EG_13 TINY_EG_12 TINY_EG_FM(12)
+#define TINY_EG_14 TINY_EG_13 TINY_EG_FM(13)
+#define TINY_EG_15 TINY_EG_14 TINY_EG_FM(14)
+#define TINY_EG_OPS(F)                                                                                                             \
+    [c0] "n"(F), [c1] "n"((F + 1) & 15), [c2] "n"((F + 2) & 15), [c3] "n"((F + 3) & 15), [c4] "n"((F + 4) & 15), [c5] "n"((F + 5) & 15), \
+        [c6] "n"((F + 6) & 15), [c7] "n"((F + 7) & 15), [c8] "n"((F + 8) & 15), [c9] "n"((F + 9) & 15), [c10] "n"((F + 10) & 15),        \
+        [c11] "n"((F + 11) & 15), [c12] "n"((F + 12) & 15), [c13] "n"((F + 13) & 15), [c14] "n"((F + 14) & 15)
+template <int F, int CNT, bool HAS_T, int TL>
+__device__ __forceinline__ void e_masked_gather(unsigned long long mask, double w, double s, double one, double &acc, double &t) {
+    static_assert(F >= 0 && CNT >= 0 && CNT <= 15 && F + CNT <= 16 && TL >= 0 && TL < 16, "lanes of one DPP row");
+    unsigned long long sx;
+#define TINY_EG_CASE(N_, BODY)                                                                                         \
+    else if constexpr (CNT == N_ && HAS_T) asm volatile(TINY_EG_HEAD BODY TINY_EG_T TINY_EG_TAIL                        \
+                                                        : [acc] "+v"(acc), [t] "+v"(t), [sx] "=&s"(sx)                \
+                                                        : [mk] "s"(mask), [w] "v"(w), [s] "v"(s), [one] "v"(one), [tl] "n"(TL), TINY_EG_OPS(F) \
+                                                        : "scc");                                                     \
+    else if constexpr (CNT == N_ && !HAS_T) asm volatile(TINY_EG_HEAD BODY TINY_EG_TAIL                                 \
+                                                         : [acc] "+v"(acc), [sx] "=&s"(sx)                            \
+                                                         : [mk] "s"(mask), [w] "v"(w), [one] "v"(one), TINY_EG_OPS(F)  \
+                                                         : "scc");
+    if constexpr (CNT == 0 && HAS_T)  // a one-row cone: no norm members (acc keeps its 0), only t
+        asm volatile(TINY_EG_HEAD TINY_EG_T TINY_EG_TAIL : [t] "+v"(t), [sx] "=&s"(sx) : [mk] "s"(mask), [s] "v"(s), [tl] "n"(TL) : "scc");
+    else if constexpr (CNT == 0) {}
+    TINY_EG_CASE(1, TINY_EG_1) TINY_EG_CASE(2, TINY_EG_2) TINY_EG_CASE(3, TINY_EG_3) TINY_EG_CASE(4, TINY_EG_4) TINY_EG_CASE(5, TINY_EG_5)
+    TINY_EG_CASE(6, TINY_EG_6) TINY_EG_CASE(7, TINY_EG_7) TINY_EG_CASE(8, TINY_EG_8) TINY_EG_CASE(9, TINY_EG_9) TINY_EG_CASE(10, TINY_EG_10)
+    TINY_EG_CASE(11, TINY_EG_11) TINY_EG_CASE(12, TINY_EG_12) TINY_EG_CASE(13, TINY_EG_13) TINY_EG_CASE(14, TINY_EG_14) TINY_EG_CASE(15, TINY_EG_15)
+#undef TINY_EG_CASE
+}
+
+// The cone list of the specialisation: {round, first lane, last lane (the cone's t row)}, in list order (state cones, then
+// input cones -- lane = row for state rows, NX + row for input rows). Rounds: cones of one round are pairwise disjoint and are
+// projected together; a cone that overlaps an earlier one of its round opens the next round (built by the host).
+struct EConeDesc {
+    int round, first, last;
+};
+#if TINY_JIT_E_NCONE > 0
+constexpr EConeDesc E_CONES[] = {TINY_JIT_E_CONES};
+#else
+constexpr EConeDesc E_CONES[] = {{-1, 0, 0}};
+#endif
+constexpr int E_NCONE = TINY_JIT_E_NCONE, E_NROUND = TINY_JIT_E_NROUND, E_NLX = TINY_JIT_E_NLX, E_NLU = TINY_JIT_E_NLU;
+constexpr int E_NL = E_NLX > E_NLU ? E_NLX : E_NLU;
+static_assert(E_NCONE <= MAX_CONES && E_NROUND <= (E_NCONE > 0 ? E_NCONE : 1), "cone list");
+
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS>
+__device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double *smem) {
+    constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU;
+    constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
+    constexpr int KS = NX <= 8 ? 8 : NX <= 12 ? 12 : 16;    // row stride of the carry matrices (chunk_ks)
+    constexpr int TOFF = (N + 2) * W;
+    constexpr int S_LAST = NS - (WPG - 1) * S;              // slots of the last wavefront
+    static_assert(WPG >= 2 && S >= 3 && S_LAST >= 3 && S_LAST <= S, "layout E: every chunk holds at least three slots");
+    constexpr bool GCL = FAM && GC_LDS, GLL = FAM && GL_LDS, LXL = FAM && LX_LDS;
+    constexpr int NLDS = (GCL ? 1 : 0) + (GLL ? 1 : 0) + (LXL ? 1 : 0);
+    constexpr int RS = e_fam_row(NXU);  // doubles per slot of a families' array in LDS: the four instances' real rows, packed
+    using Step = DStep<NX, NU>;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane >> 4, r = lane & 15;
+    const long grp = blockIdx.x;  // one workgroup = one group of four instances
+    const long inst = grp * IPW + j;
+    const bool is_x = r < NX;
+    const bool is_u = (r >= NX) && (r < NXU);
+    const bool inst_ok = inst < p.batch;
+    const int koff = is_x ? 1 : 0;  // slot s = knot s+1 on state lanes, knot s on input lanes
+    const bool top = wv == WPG - 1;
+    const bool bottom = wv == 0;
+    const int s0 = wv * S;          // first slot of this wavefront
+
+    // ---- LDS
+    double *sOps = smem;                                          // [2][16 k][16 r]
+    double *sT = sOps + 512;                                      // tables (!CT)
+    double *sLin = sT + (CT ? 0 : 3 * (N + 2) * 16 + 16);         // [E_NL][3][16]  a_k | b_k | 1/||a_k||^2 (FAM)
+    double *sPow = sLin + (FAM ? 3 * E_NL * 16 : 0);              // Phi^S | Psi^S, [16 k][16 r] each
+    double *sE = sPow + 512;                                      // [WPG][64] forward carries
+    double *sB = sE + WPG * 64;                                   // [WPG][64] backward carries
+    int *sFlag = reinterpret_cast<int *>(sB + WPG * 64);          // [WPG] per-instance "below tolerance" bits (16 doubles)
+    double *sRes = sB + WPG * 64 + 16;                            // [WPG][4 instances][4]
+    double *sK0 = sRes + WPG * 16;                                // [6][64] knot 0 of the state rows (g, v, gc, gl) and x0: the bottom wavefront's
+    double *sWave = sK0 + 6 * 64 + (size_t)wv * e_wave_doubles(NXU, NU, S, NLDS);
+    double *sGC = sWave;                                          // [S][RS] each, where the plan puts them into LDS
+    double *sGL = sGC + (GCL ? S * RS : 0);
+    double *sLX = sGL + (GLL ? S * RS : 0);
+    double *sD = sLX + (LXL ? S * RS : 0);
+    // this lane's entry of a packed families' row; lanes beyond the system's rows read their instance's last real entry and
+    // never write (EXEC mask of the real lanes)
+    const int famIdx = j * NXU + (r < NXU ? r : NXU - 1);
+    const unsigned long long mask_real = __ballot(r < NXU);
+
+    for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
+        const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
+        sOps[i] = (k < KT) ? p.ops[(size_t)which * W * KT + (size_t)rr * KT + k] : 0.0;
+        sPow[i] = (k < NX && rr < NX) ? p.ctab[(size_t)which * W * KS + (size_t)rr * KS + k] : 0.0;
+    }
+    if constexpr (!CT)
+        for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
+    if constexpr (FAM && E_NL > 0) {  // layout of fam_doubles(): ... | nl | per linear row k: a_k[W] b_k[W] ||a_k||^2[W]
+        const double *lin_rows = p.fam + 4 * W + (size_t)3 * W * KT;
+        for (int i = threadIdx.x; i < 3 * E_NL * 16; i += 64 * WPG) {
+            const int k3 = i / W, rr = i % W;
+            const double v = lin_rows[1 + (size_t)k3 * W + rr];
+            sLin[i] = (k3 % 3 == 2) ? 1.0 / v : v;  // 1 / ||a_k||^2
+        }
+    }
+
+    // canonical HBM layout, shared with every other kernel
+    const size_t vbase = ((size_t)grp * v_rows(N) + V_PAD) * 64;
+    double *const gG = p.G + (size_t)grp * (N + 1) * 64 + lane;  // row kn = knot kn
+    double *const gD = p.D + (size_t)grp * (size_t)(NS * DS);
+    double *const gV0 = p.V + vbase + lane;                       // canonical v|z, knot 0
+    double *const gV1u = p.V2 + vbase;                            // stale copy, knot 0 (wave-uniform)
+    const unsigned voff = (unsigned)(lane + koff * 64);
+    // slot i of this wavefront is real (compile-time i; the last wavefront owns S_LAST slots)
+    auto real = [&](int i) -> bool { return (i < S_LAST) || !top; };
+    // rows of the persistent arrays: knot s0 + i + koff; slots that do not exist read the per-lane dummy rows
+    auto g_row = [&](int i) -> int { return real(i) ? (s0 + i + koff) : N; };
+    auto v_row = [&](int i) -> int { return real(i) ? (s0 + i + koff) : N; };
+
+    for (int i = lane; i < S * DS; i += 64) {
+        const int row = i / DS;
+        sD[i] = (s0 + row < NS) ? gD[(size_t)(s0 + row) * DS + i % DS] : 0.0;
+    }
+    if constexpr (FAM) {
+        const double *const gGC = p.GC + vbase + lane, *const gGL = p.GL + vbase + lane;
+        if (r < NXU) {
+            e_static_for<0, S>([&](auto I) {
+                if constexpr (GCL) sGC[I.value * RS + famIdx] = gGC[(size_t)v_row(I.value) * 64];
+                if constexpr (GLL) sGL[I.value * RS + famIdx] = gGL[(size_t)v_row(I.value) * 64];
+                if constexpr (LXL) sLX[I.value * RS + famIdx] = 0.0;
+            });
+        }
+    }
+    if (bottom) {  // knot 0 of the state rows and x0
+        sK0[lane] = gG[0];
+        sK0[64 + lane] = gV0[0];
+        sK0[2 * 64 + lane] = FAM ? (p.GC + vbase)[lane] : 0.0;
+        sK0[3 * 64 + lane] = FAM ? (p.GL + vbase)[lane] : 0.0;
+        sK0[4 * 64 + lane] = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+    }
+    __syncthreads();  // (the only barrier that also waits for global loads)
+
+    // ---- register-resident state of this wavefront's slots
+    double G[S], V[S];
+    e_static_for<0, S>([&](auto I) {
+        G[I.value] = gG[(size_t)g_row(I.value) * 64];
+        V[I.value] = gV0[(size_t)v_row(I.value) * 64];
+    });
+    double GC[(FAM && !GC_LDS) ? S : 1], GLr[(FAM && !GL_LDS) ? S : 1], LX[(FAM && !LX_LDS) ? S : 1];
+    // families: per-lane data of the rounds, cone masks, side masks
+    int role_r[E_NROUND > 0 ? E_NROUND : 1];
+    double mu_r[E_NROUND > 0 ? E_NROUND : 1], imu_r[E_NROUND > 0 ? E_NROUND : 1];
+    unsigned long long cmask[E_NCONE > 0 ? E_NCONE : 1];
+    bool famc = false, faml = false;
+    const double one = 1.0;
+    const unsigned long long mask_x = __ballot(is_x), mask_u = __ballot(is_u);
+    if constexpr (FAM) {
+        const double *const gGC = p.GC + vbase + lane, *const gGL = p.GL + vbase + lane;
+        e_static_for<0, S>([&](auto I) {
+            if constexpr (!GC_LDS) GC[I.value] = gGC[(size_t)v_row(I.value) * 64];
+            if constexpr (!GL_LDS) GLr[I.value] = gGL[(size_t)v_row(I.value) * 64];
+            if constexpr (!LX_LDS) LX[I.value] = 0.0;
+        });
+        famc = p.fam[2 * W + r] != 0.0;
+        faml = p.fam[3 * W + r] != 0.0;
+#pragma unroll
+        for (int q = 0; q < (E_NROUND > 0 ? E_NROUND : 1); ++q) {
+            role_r[q] = 0;
+            mu_r[q] = 0.0;
+            imu_r[q] = 0.0;
+        }
+        const double *cone_mu = p.fam + fam_cone_mu_offset(W, KT);
+        e_static_for<0, E_NCONE>([&](auto Cc) {
+            constexpr EConeDesc cd = E_CONES[Cc.value];
+            const bool in = (r >= cd.first) && (r <= cd.last);
+            cmask[Cc.value] = __ballot(in);
+            const double mu = cone_mu[Cc.value];  // (uniform)
+            if (in) {
+                role_r[cd.round] = (r == cd.last) ? 2 : 1;
+                mu_r[cd.round] = mu;
+                imu_r[cd.round] = 1.0 / mu;
+            }
+        });
+    }
+    const double rho_s = p.rho;
+    // One (row, knot) element of the two extra families (admm.cpp's update_slack / update_dual / update_linear_cost pattern on
+    // the families' own slack and dual): returns the element's contribution to the linear cost and the new duals. Every lane takes
+    // part; lanes outside every cone / of a side without linear rows fall through unchanged.
+    auto families = [&](double val, double gc_old, double gl_old, double &gc_new, double &gl_new) -> double {
+        double lxv = 0.0;
+        gc_new = gc_old;
+        gl_new = gl_old;
+        if constexpr (E_NCONE > 0) {
+            const double s_in = val + gc_old;
+            double sv = s_in;
+            e_static_for<0, E_NROUND>([&](auto R) {
+                const double w = sv * sv;
+                double a2 = 0.0, t = 0.0;
+                e_static_for<0, E_NCONE>([&](auto Cc) {
+                    constexpr EConeDesc cd = E_CONES[Cc.value];
+                    if constexpr (cd.round == R.value)
+                        e_masked_gather<cd.first, cd.last - cd.first, true, cd.last>(cmask[Cc.value], w, sv, one, a2, t);
+                });
+                sv = soc_project_element(sv, a2, t, mu_r[R.value], imu_r[R.value], role_r[R.value]);
+            });
+            const double gcn = s_in - sv;
+            if (famc) {
+                gc_new = gcn;
+                lxv -= rho_s * (sv - gcn);
+            }
+        }
+        if constexpr (E_NL > 0) {
+            const double s_in = val + gl_old;
+            double sv = s_in;
+            e_static_for<0, E_NL>([&](auto K) {
+                constexpr int k = K.value;
+                const double a_k = sLin[(3 * k + 0) * W + r], b_k = sLin[(3 * k + 1) * W + r], in_k = sLin[(3 * k + 2) * W + r];
+                const double w = a_k * sv;
+                double dot = 0.0, unused = 0.0;
+                if constexpr (k < E_NLX) e_masked_gather<0, NX, false, 0>(mask_x, w, w, one, dot, unused);
+                if constexpr (k < E_NLU) e_masked_gather<NX, NU, false, 0>(mask_u, w, w, one, dot, unused);
+                sv = halfspace_project_element(sv, dot, a_k, b_k, in_k);
+            });
+            const double gln = s_in - sv;
+            if (faml) {
+                gl_new = gln;
+                lxv -= rho_s * (sv - gln);
+            }
+        }
+        return lxv;
+    };
+
+    const double cf = p.ops[(size_t)2 * W * KT + r];
+    const double cb = p.ops[(size_t)2 * W * KT + W + r];
+    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    const double nrho = -p.rho;
+    const double rhom = is_x ? nrho : 0.0;
+    const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
+    const int dIdx = j * NU + (is_u ? r - NX : 0);
+    const double *const sTl = sT + (size_t)(s0 + koff) * W + r;  // (!CT) row of local slot i: sTl[(i + 1) * W]
+    const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
+    const unsigned aD = e_lds_addr(sD + dIdx), aT = e_lds_addr(sTl);
+    const unsigned aGC = e_lds_addr(sGC + famIdx), aGL = e_lds_addr(sGL + famIdx), aLX = e_lds_addr(sLX + famIdx);
+    const int ct = p.check_termination;
+
+    bool active = inst_ok;
+    bool pending = false;  // converged in the previous round: state not yet written back
+    int it_done = 0;
+    int status = 11;       // TINY_UNSOLVED (admm.cpp:114)
+    bool res_valid = false;
+    double snap_pri = 0.0, snap_dua = 0.0;
+
+    auto load_ops = [&](const double *src, double (&m)[16]) {
+        e_static_for<0, 16>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * 16]; });
+    };
+    auto load_pow = [&](const double *src, double (&m)[16]) {  // a carry matrix row: state columns only
+        e_static_for<0, 16>([&](auto K) { m[K.value] = (K.value < NX) ? src[K.value * 16] : 0.0; });
+    };
+    auto lr_of = [&](auto I) -> double {  // linref of local slot I (+ the families' term)
+        double base;
+        if constexpr (CT) base = lr_c;
+        else base = sTl[2 * TOFF + (I.value + 1) * W];
+        if constexpr (FAM) {
+            if constexpr (LX_LDS) base += sLX[I.value * RS + famIdx];
+            else base += LX[I.value];
+        }
+        return base;
+    };
+
+    const int max_iter = p.max_iter;
+    for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129
+        const int it0 = __builtin_amdgcn_readfirstlane(it);
+        const bool final_round = it0 >= max_iter;
+        // ---- write-back of this wavefront's slots: G, D, the canonical v|z, the solution (see tinympc_solve_d.hip)
+        const bool wb = pending || (final_round && active);
+        if (__ballot(wb) != 0ull) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int r_o = lane_o & 15, j_o = lane_o >> 4;
+            const bool x_o = r_o < NX;
+            if (wb && r_o < NXU) {
+                const int ko = x_o ? 1 : 0;
+                const size_t inst_o = (size_t)grp * IPW + j_o;
+                double *const wG = p.G + (size_t)grp * (N + 1) * 64 + lane_o;
+                double *const wV = p.V + vbase + lane_o;
+                double *const wS = x_o ? p.sol_x + inst_o * N * NX + r_o : p.sol_u + inst_o * NS * NU + (r_o - NX);
+                const int sst = x_o ? NX : NU;
+                if (x_o && bottom) {  // knot 0
+                    wG[0] = sK0[lane_o];
+                    wV[0] = sK0[64 + lane_o];
+                    wS[0] = sK0[64 + lane_o];
+                }
+                e_static_for<0, S>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if (real(i)) {
+                        const size_t kn = (size_t)(s0 + i + ko);
+                        wG[kn * 64] = G[i];
+                        wV[kn * 64] = V[i];
+                        wS[kn * sst] = V[i];
+                    }
+                });
+                if constexpr (FAM) {
+                    double *const wGC = p.GC + vbase + lane_o, *const wGL = p.GL + vbase + lane_o;
+                    e_static_for<0, S>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        if (real(i)) {
+                            const size_t kn = (size_t)(s0 + i + ko);
+                            if constexpr (GC_LDS) wGC[kn * 64] = sGC[i * RS + famIdx];
+                            else wGC[kn * 64] = GC[i];
+                            if constexpr (GL_LDS) wGL[kn * 64] = sGL[i * RS + famIdx];
+                            else wGL[kn * 64] = GLr[i];
+                        }
+                    });
+                    if (x_o && bottom) {
+                        wGC[0] = sK0[2 * 64 + lane_o];
+                        wGL[0] = sK0[3 * 64 + lane_o];
+                    }
+                }
+                if (!x_o) {
+                    double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
+                    for (int i = 0; i < S; ++i)
+                        if (s0 + i < NS) wD[(size_t)(s0 + i) * DS] = sD[i * DS + dIdx];
+                }
+            }
+            pending = false;
+        }
+        if (final_round || __ballot(active) == 0ull) break;  // (uniform over the workgroup: termination is decided jointly)
+        const int it1 = it0 + 1;
+        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91
+
+        // One ADMM iteration of this wavefront's chunk of n slots (n = S, or S_LAST in the last wavefront)
+        auto iteration = [&](auto NT) {
+            constexpr int n = decltype(NT)::value;
+            double m[16];
+            load_ops(sMf, m);
+            // ================= forward, pass 1: the chunk's end state from a zero incoming state =================
+            {
+                double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
+                double dcur = e_lds_read_async<0>(aD);
+                e_lds_wait();
+                e_static_for<0, n>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    double dn = 0.0;
+                    if constexpr (i + 1 < n) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
+                    xt = Step::fwd_plain(xt, dcur, m, cf);
+                    dcur = dn;
+                });
+                sE[wv * 64 + lane] = xt;
+            }
+            e_barrier();
+            // the true state entering the chunk: X_w = Phi^S X_(w-1) + e_(w-1), X_1 = e_0
+            double xin = 0.0;
+            if (!bottom) {
+                double ph[16];
+                load_pow(sPow + r, ph);
+                xin = sE[lane];
+#pragma unroll 1
+                for (int q = 1; q < wv; ++q) xin = Step::fwd_plain(xin, 0.0, ph, sE[q * 64 + lane]);
+            }
+            // ================= forward, pass 2: the real sweep (F1) with S1 + D1 + R1 fused in =================
+            double pri = 0.0, dua = 0.0;
+            bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
+            if (bottom) {      // knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
+                const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
+                const double x0v = sK0[4 * 64 + lane], G0 = sK0[lane], V0 = sK0[64 + lane];
+                if (may && is_x) gV1u[(unsigned)lane] = V0;
+                const double s = x0v + G0;
+                const double snew = fmin(hi0, fmax(lo0, s));
+                sK0[lane] = s - snew;
+                pri = is_x ? fabs(x0v - snew) : 0.0;
+                dua = is_x ? fabs(V0 - snew) : 0.0;
+                sK0[64 + lane] = snew;
+                if constexpr (FAM) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
+                    double gcn, gln;
+                    (void)families(x0v, sK0[2 * 64 + lane], sK0[3 * 64 + lane], gcn, gln);
+                    if (is_x) {
+                        sK0[2 * 64 + lane] = gcn;
+                        sK0[3 * 64 + lane] = gln;
+                    }
+                }
+                xin = x0v;
+            }
+            double xcur = xin;
+            {
+                double dcur = e_lds_read_async<0>(aD);
+                double locur = lo_c, hicur = hi_c, glcur = 0.0, gccur = 0.0;
+                if constexpr (!CT) {
+                    locur = e_lds_read_async<W * 8>(aT);
+                    hicur = e_lds_read_async<(TOFF + W) * 8>(aT);
+                }
+                if constexpr (GCL) gccur = e_lds_read_async<0>(aGC);
+                if constexpr (GLL) glcur = e_lds_read_async<0>(aGL);
+                e_lds_wait();
+                auto fstep = [&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    double dn = 0.0, lon = lo_c, hin = hi_c, gln_next = 0.0, gcn_next = 0.0;
+                    if constexpr (q + 1 < n) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
+                    if constexpr (!CT && q + 1 < n) {
+                        lon = e_lds_read_async<(q + 2) * W * 8>(aT);
+                        hin = e_lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
+                    }
+                    if constexpr (GCL && q + 1 < n) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
+                    if constexpr (GLL && q + 1 < n) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
+                    xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);
+                    if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                        double gcn, gln;
+                        double gl_old, gc_old;
+                        if constexpr (GC_LDS) gc_old = gccur;
+                        else gc_old = GC[q];
+                        if constexpr (GL_LDS) gl_old = glcur;
+                        else gl_old = GLr[q];
+                        const double l = families(xcur, gc_old, gl_old, gcn, gln);
+                        if constexpr (GC_LDS) e_lds_write_masked<q * RS * 8>(aGC, gcn, mask_real);
+                        else GC[q] = gcn;
+                        if constexpr (GL_LDS) e_lds_write_masked<q * RS * 8>(aGL, gln, mask_real);
+                        else GLr[q] = gln;
+                        if constexpr (LX_LDS) e_lds_write_masked<q * RS * 8>(aLX, l, mask_real);
+                        else LX[q] = l;
+                    }
+                    dcur = dn;
+                    glcur = gln_next;
+                    gccur = gcn_next;
+                    if constexpr (!CT) {
+                        locur = lon;
+                        hicur = hin;
+                    }
+                };
+                constexpr int NG = (n + E_GROUP - 1) / E_GROUP;
+                e_static_for<0, NG>([&](auto Gi) {
+                    constexpr int g0 = Gi.value * E_GROUP, g1 = (g0 + E_GROUP < n) ? g0 + E_GROUP : n;
+                    if (may) {
+                        // stale copy of the group's slots (still the previous iterate) before the blocks overwrite them -- only
+                        // while some instance of this wavefront can still converge in this sweep (exact: the maxima only grow)
+                        if constexpr (g0 > 0) {
+                            const bool bad = !((pri < p.abs_pri_tol) && (dua * p.rho < p.abs_dua_tol));
+                            may = __builtin_amdgcn_readfirstlane((int)e_wave_may_converge(__ballot(bad), __ballot(active))) != 0;
+                        }
+                        if (may) {
+                            unsigned vo = voff + (unsigned)(s0 * 64);
+                            double *base = gV1u;
+                            asm volatile("" : "+v"(vo), "+s"(base));
+                            e_static_for<g0, g1>([&](auto Q) { (base + Q.value * 64)[vo] = V[Q.value]; });
+                        }
+                    }
+                    e_static_for<g0, g1>([&](auto Q) { fstep(Q); });
+                });
+            }
+            if (active) it_done = it1;  // admm.cpp:143
+
+            // ---- R1 (admm.cpp:93-101), this wavefront's share: which of its four instances have every lane below tolerance
+            if (check) {
+                const bool below = (pri < p.abs_pri_tol) && (dua * p.rho < p.abs_dua_tol);
+                const unsigned long long b = __ballot(below);
+                int bits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bits |= (((b >> (q * 16)) & 0xffffull) == 0xffffull) ? (1 << q) : 0;
+                if (lane == 0) sFlag[wv] = bits;
+            }
+
+            // ================= backward (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G =================
+            // chain of the chunk: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
+            // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
+            // which the chunk below owns.
+            load_ops(sMb, m);
+            auto bwd_chain = [&](double cin, auto STORE) -> double {
+                constexpr bool store = decltype(STORE)::value;
+                const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
+                double px, rcur, rnext, acc;
+                {
+                    // state lanes: q~ of the last slot (the last wavefront: p_{N-1}, admm.cpp:81-82); input lanes: r of the last slot
+                    const double lr1 = lr_of(std::integral_constant<int, n - 1>{});
+                    double lrT = lr1;
+                    if (top) {
+                        double pT = pnref;
+                        if constexpr (FAM) {
+                            if constexpr (LX_LDS) pT += sLX[(n - 1) * RS + famIdx];
+                            else pT += LX[n - 1];
+                        }
+                        lrT = is_x ? pT : lr1;
+                    }
+                    const double lr2 = lr_of(std::integral_constant<int, n - 2>{});
+                    const double lrmc2 = is_x ? lr2 + cb : cb;
+                    double t;
+                    asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
+                        "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
+                        "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                        "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
+                        "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
+                        : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
+                        : [v1] "v"(V[n - 1]), [g1] "v"(G[n - 1]), [v2] "v"(V[n - 2]), [g2] "v"(G[n - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
+                          [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                    rcur = px;                   // (input lanes: r_(n-1))
+                    px = is_x ? px + cin : px;   // (state lanes: + the carry entering from above)
+                }
+                e_static_for<0, n - 1>([&](auto I) {
+                    constexpr int s = n - 1 - I.value;      // n-1 .. 1
+                    constexpr int s2 = s >= 2 ? s - 2 : 0;  // slot feeding the tail
+                    const double lr2 = lr_of(std::integral_constant<int, s2>{});
+                    // tail: accumulator start of step s-1 (state lanes: q_(s-2 slot) + cb; step 0 takes NO q: its knot belongs to the
+                    // chunk below) and the input-row operand of step s-2
+                    const double lrmc2 = (s >= 2) ? (is_x ? lr2 + cb : cb) : cb;
+                    const double rh = (s >= 2) ? rhom : 0.0;
+                    double a = acc, an, rn;
+                    Step::bwd(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
+                    if constexpr (store) e_lds_write_masked<s * DS * 8>(aD, a, wr_d);  // d_s
+                    px = a;
+                    rcur = rnext;
+                    rnext = rn;
+                    acc = an;
+                });
+                double a = acc;
+                Step::bwd_last(a, px, rcur, m);
+                if constexpr (store) e_lds_write_masked<0>(aD, a, wr_d);  // d of the chunk's first slot
+                return a;
+            };
+            // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
+            {
+                const double e2 = bwd_chain(0.0, std::false_type{});
+                sB[wv * 64 + lane] = e2;
+            }
+            e_barrier();
+            // ---- termination, decided jointly: an instance converged iff every wavefront saw all of its lanes below tolerance
+            if (check) {
+                int all = 0xf;
+#pragma unroll
+                for (int q = 0; q < WPG; ++q) all &= sFlag[q];
+                const bool conv = ((all >> j) & 1) != 0;
+                if (active) {
+                    snap_pri = pri;
+                    snap_dua = dua;
+                    res_valid = true;
+                    if (conv) {
+                        status = 1;  // TINY_SOLVED: this instance stops before the backward pass (admm.cpp:181-192)
+                        active = false;
+                        pending = true;
+                    }
+                }
+            }
+            // the carry entering from above: c_w = e''_(w+1) + Psi^S c_(w+1), c of the last wavefront = 0
+            double cin = 0.0;
+            if (!top) {
+                double ps[16];
+                load_pow(sPow + 256 + r, ps);
+                cin = sB[(WPG - 1) * 64 + lane];
+#pragma unroll 1
+                for (int q = WPG - 2; q > wv; --q) cin = Step::fwd_plain(cin, 0.0, ps, sB[q * 64 + lane]);
+                load_ops(sMb, m);
+            }
+            // pass 2: the real sweep; only d is kept
+            (void)bwd_chain(is_x ? cin : 0.0, std::true_type{});
+        };
+        if constexpr (S_LAST != S) {
+            if (top) iteration(std::integral_constant<int, S_LAST>{});
+            else iteration(std::integral_constant<int, S>{});
+        } else {
+            iteration(std::integral_constant<int, S>{});
+        }
+    }
+    e_lds_wait();
+
+    // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
+    // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
+    if (inst_ok && status == 1 && r < NXU) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        double *const wV = p.V + vbase + lane;
+        const double *const wV2 = p.V2 + vbase + lane;
+        if (bottom && is_x) wV[0] = wV2[0];
+        for (int i = 0; i < S; ++i) {
+            const int kn = s0 + i + koff;
+            if (s0 + i < NS) wV[(size_t)kn * 64] = wV2[(size_t)kn * 64];
+        }
+    }
+
+    // the four residual norms of the last check: rows, then wavefronts through LDS
+    const double gpx = group_max<W>(is_x ? snap_pri : 0.0), gpu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double gdx = group_max<W>(is_x ? snap_dua : 0.0), gdu = group_max<W>(is_u ? snap_dua : 0.0);
+    e_barrier();  // (sRes shares nothing, but every wavefront has left the iteration loop's LDS traffic behind)
+    if (r < 4) sRes[(wv * 4 + j) * 4 + r] = (r == 0) ? gpx : (r == 1) ? gdx : (r == 2) ? gpu : gdu;
+    e_barrier();
+    if (bottom && inst_ok && r == 0) {
+        double res[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < WPG; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) res[c] = fmax(res[c], sRes[(q * 4 + j) * 4 + c]);
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            p.dstats[inst * 4 + 0] = res[0];
+            p.dstats[inst * 4 + 1] = res[1] * p.rho;
+            p.dstats[inst * 4 + 2] = res[2];
+            p.dstats[inst * 4 + 3] = res[3] * p.rho;
+        }
+    }
+}
+
+}  // namespace tinympc
+
+#ifndef TINY_JIT_E_WPS
+#define TINY_JIT_E_WPS (TINY_JIT_E_WPG / 4)  // wavefronts per SIMD: a workgroup of 8 shares a CU two by two (256 registers each)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
+tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
+    constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0;
+    constexpr int nlds = FAMJ ? (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0) : 0;
+    constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds);
+    static_assert(bytes <= 160 * 1024, "layout E: the workgroup's LDS plan exceeds a CU");
+    __shared__ __attribute__((aligned(16))) double smem_e[bytes / sizeof(double)];
+    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ>(p, smem_e);
+}

@@ -409,6 +409,15 @@ class TinyMPC:
         return dict(lanes_per_instance=v[0].value, instances_per_wave=v[1].value, workgroups=v[2].value,
                     lds_bytes=v[3].value, tables_in_lds=bool(v[4].value), layout=chr(self._L.tinympc_get_layout(self._h)))
 
+    def jit_info(self) -> str:
+        """Origin of the kernel of the current configuration: 'compiled-in ...', 'compiled ...', 'disk-cache ...' or
+        'refused(<reason>)' (tinympc_get_jit_info)."""
+        self._check_setup()
+        self._push_settings()
+        buf = C.create_string_buffer(1024)
+        _lib.check(self._L.tinympc_get_jit_info(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     # ------------------------------------------------------------------ private helpers
     def _check_setup(self):
         if not self.is_setup:
