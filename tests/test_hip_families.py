@@ -210,7 +210,9 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
             s.set_x0_batch(x0s)
             s.solve()
             out.append((s.get_solution_batch(), s.get_stats_batch()))
-        assert (s.launch_info()["layout"] == "D") == (jit == "1")  # (without it: k_admm_solve_fam, whatever the box path's layout)
+        # (without the specialiser: k_admm_solve_fam, whatever the box path's layout; N = 28 is beyond what layout D holds in
+        # registers with the families -- layout E takes it, four wavefronts per workgroup on the 512-register plan)
+        assert s.launch_info()["layout"] == ("A" if jit == "0" else "D" if N <= 22 else "E"), s.jit_info()
         results[jit] = out
         s.reset()
     orc = [oracle(rk, settings) for _ in range(batch)]

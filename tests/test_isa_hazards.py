@@ -30,6 +30,10 @@ def test_lint_catches_a_planted_hazard():
     n, bad = _lint(".LBB0_1:\n v_fmac_f64_dpp v[2:3], v[4:5], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
     assert len(bad) == 1
     assert _lint("v_mov_b32_e32 v4, v9\n v_add_u32_e32 v1, v1, v1\n v_add_u32_e32 v1, v1, v1\n" + good.split("\n")[1] + "\n")[1] == []
+    # the 64-bit DPP move (layout E's masked gathers) reads its source through the crossbar too
+    n, bad = _lint("v_mul_f64 v[4:5], v[8:9], v[8:9]\n v_mov_b64_dpp v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n")
+    assert n == 1 and len(bad) == 1
+    assert _lint("v_mul_f64 v[4:5], v[8:9], v[8:9]\n s_and_saveexec_b64 s[0:1], s[2:3]\n s_nop 1\n v_mov_b64_dpp v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n") == (1, [])
 
 
 def test_every_solve_source_is_linted_by_the_build():
@@ -37,7 +41,9 @@ def test_every_solve_source_is_linted_by_the_build():
     assert set(SOURCES) <= set(ge.HIP_LINTED), "a solve kernel source is missing from the build's ISA lint"
     on_disk = {f for f in os.listdir(CSRC) if f.startswith("tinympc_solve") and f.endswith(".hip")}
     no_dpp_chain = {"tinympc_solve_m.hip"}  # the matrix-core kernel: no DPP operand anywhere
-    assert on_disk - no_dpp_chain == set(SOURCES), "new solve kernel source: add it to SOURCES here and to HIP_LINTED in __graft_entry__.py"
+    run_time_only = set(ge.HIP_LINT_ONLY)   # exist as run-time specialisations only; the build lints their default instance
+    assert run_time_only == {"tinympc_solve_e.hip"}
+    assert on_disk - no_dpp_chain - run_time_only == set(SOURCES), "new solve kernel source: add it to SOURCES here and to HIP_LINTED in __graft_entry__.py"
     for f in no_dpp_chain:
         assert "_dpp" not in open(os.path.join(CSRC, f)).read()
 
@@ -105,3 +111,51 @@ def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, 
     checked, bad = _lint(text)
     assert checked > 200 and not bad, bad[:3]
     assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"
+
+
+E_ROCKET = dict(nround=1, ncone=2, cones="{0,0,2},{0,6,8}", nlx=1, nlu=0)
+@pytest.mark.parametrize("nx,nu,N,ct,wpg,S,fam,lds", [
+    (6, 3, 100, 0, 8, 13, E_ROCKET, (1, 1, 1)),   # BASELINE config 4 as bench.py runs it (the build lints the same instance)
+    (6, 3, 100, 1, 8, 13, E_ROCKET, (1, 1, 1)),   # ... with constant tables
+    (6, 3, 44, 0, 4, 11, E_ROCKET, (0, 0, 0)),    # one wavefront per SIMD, everything in registers
+    (12, 4, 60, 1, 8, 8, dict(nround=2, ncone=3, cones="{0,0,2},{0,12,15},{1,1,4}", nlx=2, nlu=1), (0, 1, 1)),  # overlapping cones, rows on both sides
+    (12, 4, 200, 1, 8, 25, None, (0, 0, 0)),      # box path only, a horizon beyond layout D's plans
+])
+def test_layout_e_specialisations_have_no_dpp_hazard_and_no_scratch(nx, nu, N, ct, wpg, S, fam, lds, tmp_path):
+    """tinympc_solve_e.hip exists only as run-time specialisations (tinympc_jit.hip -> hiprtc on the GPU box); the same
+    specialisations compiled here with hipcc: DPP hazards (the sweep chains AND the EXEC-masked gathers of the families),
+    no scratch, register count within the plan."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    f = fam or dict(nround=0, ncone=0, cones="{-1,0,0}", nlx=0, nlu=0)
+    out = tmp_path / "jit_e.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_CT={ct}", f"-DTINY_JIT_FAM={1 if fam else 0}",
+                    f"-DTINY_JIT_E_WPG={wpg}", f"-DTINY_JIT_E_WPS={wpg // 4}", f"-DTINY_JIT_E_S={S}", f"-DTINY_JIT_E_NROUND={f['nround']}", f"-DTINY_JIT_E_NCONE={f['ncone']}",
+                    f"-DTINY_JIT_E_CONES={f['cones']}", f"-DTINY_JIT_E_NLX={f['nlx']}", f"-DTINY_JIT_E_NLU={f['nlu']}",
+                    f"-DTINY_JIT_E_GC_LDS={lds[0]}", f"-DTINY_JIT_E_GL_LDS={lds[1]}", f"-DTINY_JIT_E_LX_LDS={lds[2]}",
+                    "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "tinympc_solve_e.hip")], check=True, timeout=900)
+    text = out.read_text()
+    checked, bad = _lint(text)
+    assert checked > 200 and not bad, bad[:3]
+    assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"
+    if wpg == 8:
+        assert "vgpr_spill_count: 0" in text
+
+
+def test_embedded_kernel_sources_are_the_sources_on_disk():
+    """libtinympc_hip.so specialises the sources embedded at build time (build/hip/tinympc_jit_embedded.inc): what build() wrote
+    must be the files of csrc/, byte for byte, and every file the run-time translation units include must be on the list."""
+    import re
+    import __graft_entry__ as ge
+    inc = ge.write_embedded_sources()
+    text = open(inc).read()
+    chunks = re.split(r"static const char kEmbeddedText\d+\[\] =\n", text)[1:]
+    assert len(chunks) == len(ge.JIT_EMBEDDED)
+    for name, chunk in zip(ge.JIT_EMBEDDED, chunks):
+        src = open(os.path.join(CSRC, name)).read()
+        body = "".join(re.findall(r'R"TINYSRC\((.*?)\)TINYSRC"', chunk, re.S))
+        assert body == src, name
+        for inc_name in re.findall(r'#include "([^"]+)"', src):
+            assert inc_name in ge.JIT_EMBEDDED, f"{name} includes {inc_name}, which is not embedded"

@@ -463,9 +463,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         const int it1 = it0 + 1;
         const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91
 
-        // One ADMM iteration of this wavefront's chunk of n slots (n = S, or S_LAST in the last wavefront)
-        auto iteration = [&](auto NT) {
-            constexpr int n = decltype(NT)::value;
+        // One ADMM iteration of this wavefront's chunk: S slots, of which the last wavefront owns only the first S_LAST -- ONE copy of
+        // the code, the steps beyond S_LAST behind a scalar branch (two instantiations, one per chunk length, cost ~60 VGPRs).
+        {
             double m[16];
             load_ops(sMf, m);
             // ================= forward, pass 1: the chunk's end state from a zero incoming state =================
@@ -473,11 +473,12 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
                 double dcur = e_lds_read_async<0>(aD);
                 e_lds_wait();
-                e_static_for<0, n>([&](auto I) {
+                e_static_for<0, S>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     double dn = 0.0;
-                    if constexpr (i + 1 < n) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
-                    xt = Step::fwd_plain(xt, dcur, m, cf);
+                    if constexpr (i + 1 < S) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
+                    if constexpr (i < S_LAST) xt = Step::fwd_plain(xt, dcur, m, cf);
+                    else if (!top) xt = Step::fwd_plain(xt, dcur, m, cf);
                     dcur = dn;
                 });
                 sE[wv * 64 + lane] = xt;
@@ -529,13 +530,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 auto fstep = [&](auto Q) {
                     constexpr int q = decltype(Q)::value;
                     double dn = 0.0, lon = lo_c, hin = hi_c, gln_next = 0.0, gcn_next = 0.0;
-                    if constexpr (q + 1 < n) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
-                    if constexpr (!CT && q + 1 < n) {
+                    if constexpr (q + 1 < S) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
+                    if constexpr (!CT && q + 1 < S) {
                         lon = e_lds_read_async<(q + 2) * W * 8>(aT);
                         hin = e_lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
                     }
-                    if constexpr (GCL && q + 1 < n) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
-                    if constexpr (GLL && q + 1 < n) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
+                    if constexpr (GCL && q + 1 < S) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
+                    if constexpr (GLL && q + 1 < S) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
                     xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);
                     if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                         double gcn, gln;
@@ -560,9 +561,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         hicur = hin;
                     }
                 };
-                constexpr int NG = (n + E_GROUP - 1) / E_GROUP;
+                constexpr int NG = (S + E_GROUP - 1) / E_GROUP;
                 e_static_for<0, NG>([&](auto Gi) {
-                    constexpr int g0 = Gi.value * E_GROUP, g1 = (g0 + E_GROUP < n) ? g0 + E_GROUP : n;
+                    constexpr int g0 = Gi.value * E_GROUP, g1 = (g0 + E_GROUP < S) ? g0 + E_GROUP : S;
                     if (may) {
                         // stale copy of the group's slots (still the previous iterate) before the blocks overwrite them -- only
                         // while some instance of this wavefront can still converge in this sweep (exact: the maxima only grow)
@@ -574,10 +575,15 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                             unsigned vo = voff + (unsigned)(s0 * 64);
                             double *base = gV1u;
                             asm volatile("" : "+v"(vo), "+s"(base));
-                            e_static_for<g0, g1>([&](auto Q) { (base + Q.value * 64)[vo] = V[Q.value]; });
+                            e_static_for<g0, g1>([&](auto Q) {
+                                if (real(Q.value)) (base + Q.value * 64)[vo] = V[Q.value];
+                            });
                         }
                     }
-                    e_static_for<g0, g1>([&](auto Q) { fstep(Q); });
+                    e_static_for<g0, g1>([&](auto Q) {
+                        if constexpr (Q.value < S_LAST) fstep(Q);
+                        else if (!top) fstep(Q);
+                    });
                 });
             }
             if (active) it_done = it1;  // admm.cpp:143
@@ -593,7 +599,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             }
 
             // ================= backward (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G =================
-            // chain of the chunk: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
+            // chain of a chunk of n slots: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
             // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
             // which the chunk below owns.
             load_ops(sMb, m);
@@ -601,19 +607,21 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 constexpr bool store = decltype(STORE)::value;
                 const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
                 double px, rcur, rnext, acc;
-                {
+                // head of the chain, from the chunk's last slot T: P and r_T, the accumulator start of step T, r_(T-1)
+                auto head = [&](auto T, bool terminal) {
+                    constexpr int tt = decltype(T)::value;
                     // state lanes: q~ of the last slot (the last wavefront: p_{N-1}, admm.cpp:81-82); input lanes: r of the last slot
-                    const double lr1 = lr_of(std::integral_constant<int, n - 1>{});
+                    const double lr1 = lr_of(T);
                     double lrT = lr1;
-                    if (top) {
+                    if (terminal) {
                         double pT = pnref;
                         if constexpr (FAM) {
-                            if constexpr (LX_LDS) pT += sLX[(n - 1) * RS + famIdx];
-                            else pT += LX[n - 1];
+                            if constexpr (LX_LDS) pT += sLX[tt * RS + famIdx];
+                            else pT += LX[tt];
                         }
                         lrT = is_x ? pT : lr1;
                     }
-                    const double lr2 = lr_of(std::integral_constant<int, n - 2>{});
+                    const double lr2 = lr_of(std::integral_constant<int, tt - 1>{});
                     const double lrmc2 = is_x ? lr2 + cb : cb;
                     double t;
                     asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
@@ -622,13 +630,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
                         "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
                         : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
-                        : [v1] "v"(V[n - 1]), [g1] "v"(G[n - 1]), [v2] "v"(V[n - 2]), [g2] "v"(G[n - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
+                        : [v1] "v"(V[tt]), [g1] "v"(G[tt]), [v2] "v"(V[tt - 1]), [g2] "v"(G[tt - 1]), [nrho] "s"(nrho), [lrT] "v"(lrT),
                           [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
-                    rcur = px;                   // (input lanes: r_(n-1))
+                    rcur = px;                   // (input lanes: r_T)
                     px = is_x ? px + cin : px;   // (state lanes: + the carry entering from above)
-                }
-                e_static_for<0, n - 1>([&](auto I) {
-                    constexpr int s = n - 1 - I.value;      // n-1 .. 1
+                };
+                auto block = [&](auto Sl) {
+                    constexpr int s = decltype(Sl)::value;
                     constexpr int s2 = s >= 2 ? s - 2 : 0;  // slot feeding the tail
                     const double lr2 = lr_of(std::integral_constant<int, s2>{});
                     // tail: accumulator start of step s-1 (state lanes: q_(s-2 slot) + cb; step 0 takes NO q: its knot belongs to the
@@ -642,7 +650,18 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     rcur = rnext;
                     rnext = rn;
                     acc = an;
-                });
+                };
+                if constexpr (S_LAST == S) {
+                    head(std::integral_constant<int, S - 1>{}, top);
+                } else {
+                    if (top) {
+                        head(std::integral_constant<int, S_LAST - 1>{}, true);
+                    } else {  // the S - S_LAST steps only a full chunk has, then the common part
+                        head(std::integral_constant<int, S - 1>{}, false);
+                        e_static_for<0, S - S_LAST>([&](auto I) { block(std::integral_constant<int, S - 1 - I.value>{}); });
+                    }
+                }
+                e_static_for<0, S_LAST - 1>([&](auto I) { block(std::integral_constant<int, S_LAST - 1 - I.value>{}); });  // S_LAST-1 .. 1
                 double a = acc;
                 Step::bwd_last(a, px, rcur, m);
                 if constexpr (store) e_lds_write_masked<0>(aD, a, wr_d);  // d of the chunk's first slot
@@ -683,12 +702,6 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             }
             // pass 2: the real sweep; only d is kept
             (void)bwd_chain(is_x ? cin : 0.0, std::true_type{});
-        };
-        if constexpr (S_LAST != S) {
-            if (top) iteration(std::integral_constant<int, S_LAST>{});
-            else iteration(std::integral_constant<int, S>{});
-        } else {
-            iteration(std::integral_constant<int, S>{});
         }
     }
     e_lds_wait();

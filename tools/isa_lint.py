@@ -1,6 +1,6 @@
 """ISA lint of the generated gfx950 code: the DPP data hazard of the fused mat-vec chain.
 
-`v_fmac_f64_dpp acc, w, m row_newbcast:k` reads `w` through the DPP crossbar; a VGPR written by a VALU instruction
+`v_fmac_f64_dpp acc, w, m row_newbcast:k` (and `v_mov_b64_dpp acc, w row_newbcast:k`) reads `w` through the DPP crossbar; a VGPR written by a VALU instruction
 must not be read through DPP within the next 2 wait states, and neither the hardware nor hipcc (the instructions live in
 inline asm) guards that. `lint(asm_text)` walks back from every DPP FMA: 2 wait states must pass before any VALU
 instruction that writes the registers of `w` (or a label, behind which the predecessors are unknown) is met.
@@ -37,7 +37,7 @@ def lint(asm_text: str):
         parts = line.split(None, 1)
         mnem, ops = parts[0], (parts[1] if len(parts) > 1 else "")
         toks = [t.strip() for t in ops.split(",")]
-        if mnem == "v_fmac_f64_dpp":
+        if mnem in ("v_fmac_f64_dpp", "v_mov_b64_dpp"):  # (the move: layout E's gathers under an EXEC mask)
             checked += 1
             src = _regs(toks[1].split()[0])
             waited = 0
