@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""One bench leg as a stand-alone workload, for rocprofv3 (tools/profile_legs.sh): the same handles bench.py builds for its
+extra legs, a few launches each, nothing else in the process (no torch import: numpy + the C ABI only).
+
+    python tools/leg_workload.py <leg> [launches]
+legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, adaptive_rho_batch, single_instance
+Prints one JSON line: leg, kernel layout, launches, iterations per launch, instances, median kernel ms (HIP events)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+P = pkg.problems
+
+
+def rocket_handle(N, batch, iters):
+    rk = P.rocket(N)
+    s = pkg.TinyMPC()
+    s.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=batch, rho=rk.rho, fdyn=rk.fdyn, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1)
+    s.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
+    s.set_x_ref(rk.x_ref)
+    s.set_u_ref(rk.u_ref)
+    s.set_cone_constraints(**rk.cones)
+    s.set_linear_constraints(**rk.linear)
+    if batch == 1:
+        s.set_x0(rk.x0)
+    else:
+        s.set_x0_batch(np.asfortranarray(rk.x0[:, None] * np.linspace(0.6, 1.2, batch)[None, :]))
+    return s
+
+
+def synthetic(nx, nu, N, batch, iters, seed, a_scale, b_scale, diag=1.0):
+    rng = np.random.default_rng(seed)
+    A = np.eye(nx) * diag + a_scale * rng.standard_normal((nx, nx))
+    B = b_scale * rng.standard_normal((nx, nu))
+    p = P.Problem("synthetic", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+    s = pkg.TinyMPC()
+    s.setup(p.A, p.B, p.Q, p.R, p.N, batch=batch, rho=p.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters)
+    s.set_bound_constraints(np.full(nx, -2.0), np.full(nx, 2.0), np.full(nu, -0.3), np.full(nu, 0.3))
+    s.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((nx, batch))))
+    return s
+
+
+def quadrotor(N, batch, iters, **extra):
+    prob = P.quadrotor(N)
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1, **extra)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if batch == 1:
+        s.set_x0(prob.x0)
+    else:
+        s.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(batch)))
+    return s
+
+
+def build(leg):
+    """-> (handle, instances, iterations per launch)"""
+    if leg == "headline":
+        return quadrotor(50, 8192, 200), 8192, 200
+    if leg == "rocket_batch":
+        return rocket_handle(100, 4096, 100), 4096, 100
+    if leg == "rocket_instance":
+        return rocket_handle(100, 1, 200), 1, 200
+    if leg == "wide_system":
+        return synthetic(24, 8, 30, 4096, 100, 0, 0.03, 0.1), 4096, 100
+    if leg == "long_horizon":
+        return quadrotor(100, 8192, 100), 8192, 100
+    if leg == "large_system":
+        return synthetic(96, 32, 20, 4096, 50, 96, 0.015, 0.08, 0.98), 4096, 50
+    if leg == "adaptive_rho_batch":
+        s = quadrotor(50, 8192, 100, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0)
+        s.set_sensitivity_matrices(*s.compute_sensitivity_autograd())
+        return s, 8192, 100
+    if leg == "single_instance":
+        return quadrotor(50, 1, 200), 1, 200
+    raise SystemExit("unknown leg " + leg)
+
+
+def main():
+    leg = sys.argv[1]
+    launches = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    s, inst, iters = build(leg)
+    ms = []
+    for _ in range(launches):
+        s.reset_workspace()
+        ms.append(s.solve_timed())
+    med = float(np.median(ms[1:])) if len(ms) > 1 else float(ms[0])
+    print(json.dumps({"leg": leg, "layout": s.launch_info()["layout"], "jit": s.jit_info(), "launches": launches, "iterations_per_launch": iters,
+                      "instances": inst, "kernel_ms_median": med, "iters_per_s": inst * iters / (med * 1e-3)}), flush=True)
+    s.reset()
+
+
+if __name__ == "__main__":
+    main()
