@@ -108,6 +108,7 @@ struct tinympc_solver {
     // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
     bool layout_d = false;
     bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
+    bool d_jit_asked = false;  // the specialiser was asked for the box kernel at setup (its answer may have been a refusal)
     // Large systems, 64 < nx+nu <= 128: tiles of 16 instances on the FP64 matrix cores, state streamed from HBM in the tile's
     // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
     // adaptive rho / session.
@@ -773,6 +774,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
         if (const char *env = getenv("TINYMPC_LAYOUT")) want_d = (env[0] == 'D' || env[0] == 'd');
         if (want_d && !d_compiled) {
             HIP_TRY_S(hipSetDevice(s->device));
+            s->d_jit_asked = true;
             s->d_jit = solve_jit_supported(W, nx, nu, N, true);
             want_d = s->d_jit;
         }
@@ -1607,7 +1609,7 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
     if (s->layout_m) snprintf(buf, (size_t)len, "compiled-in layout=M");
     else if (!s->e_sig.empty() && fam && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), true, s->fs, buf, (size_t)len);
     else if (s->use_layout_d() && !(s->d_jit || fam || adaptive || (!s->tables_const() && s->d_varying_jit))) snprintf(buf, (size_t)len, "compiled-in layout=D");
-    else if (s->layout_d || s->d_jit) {
+    else if (s->layout_d || s->d_jit || s->d_jit_asked) {
         if ((rc = bind_device(s))) return rc;
         solve_jit_describe(s->W, s->nx, s->nu, s->N, s->tables_const(), fam && !adaptive, adaptive && !fam, buf, (size_t)len);
     } else snprintf(buf, (size_t)len, "compiled-in layout=%c", (char)tinympc_get_layout(s));
