@@ -178,7 +178,7 @@ struct tinympc_solver {
     bool use_layout_d() const {
         return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
     }
-    bool use_layout_e() const { return e_ok && families_active() && !st.adaptive_rho && !use_layout_d(); }
+    bool use_layout_e() const { return e_ok && !st.adaptive_rho && !use_layout_d(); }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
@@ -438,22 +438,28 @@ void decide_layout_d_variants(tinympc_solver *s) {
 // kind of the tables changed (the kernel is specialised on both; compiling takes seconds the first time, the answer is cached
 // inside tinympc_jit.hip). TINYMPC_LAYOUT=E forces it at any batch size (tests), any other value excludes it.
 int decide_layout_e(tinympc_solver *s) {
-    bool want = s->W == 16 && !s->layout_m && s->families_active() && !s->st.adaptive_rho && !s->use_layout_d() && s->batch >= kLayoutEBatchMin;
-    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'E' || env[0] == 'e') && s->W == 16 && !s->layout_m && s->families_active() && !s->st.adaptive_rho;
+    const bool fam = s->families_active();
+    // (single-instance handles exchange x0 / the solution through pinned host memory, which only the latency kernel serves)
+    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && s->batch > 1;
+    // families: wherever layout D has no kernel; box path: horizons for which the specialiser has no layout-D kernel at all (no plan,
+    // or a plan whose code object spilled) -- long horizons, where layouts B / A are left with one or two wavefronts per CU
+    bool want = possible && !s->use_layout_d() &&
+                (fam ? s->batch >= kLayoutEBatchMin : (s->d_jit_asked && !s->layout_d && s->batch > kLayoutCBatchMax && s->N >= 26));
+    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'E' || env[0] == 'e') && possible;
     if (!want) {
         s->e_ok = false;
         s->e_sig.clear();
         return TINYMPC_OK;
     }
-    const FamilyStructure fs = family_structure(s);
+    const FamilyStructure fs = fam ? family_structure(s) : FamilyStructure();
     std::string sig = s->tables_const() ? "ct|" : "var|";
     for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
-    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu);
+    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
     if (sig == s->e_sig) return TINYMPC_OK;
     s->e_sig = sig;
     s->fs = fs;
-    s->e_ok = solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), true, fs) &&
-              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), true, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds);
+    s->e_ok = solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), fam, fs) &&
+              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds);
     if (s->e_ok && !s->dctab_e) {
         int rc = dalloc(s, &s->dctab_e, chunk_table_doubles(s->nx, 1));
         if (rc) return rc;
@@ -496,7 +502,7 @@ int launch(tinympc_solver *s, bool timed) {
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     p.const_tables = s->tables_const() ? 1 : 0;
-    if (s->zero_copy_tick && !s->use_layout_d() && !s->layout_m) {  // set by tinympc_mpc_step_batch for the duration of one launch
+    if (s->zero_copy_tick && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {  // set by tinympc_mpc_step_batch for the duration of one launch
         p.x0 = s->h_x0;
         p.x0_mirror = s->dx0;
         p.u0_host = s->h_u0;
@@ -547,6 +553,9 @@ int launch(tinympc_solver *s, bool timed) {
         // handle can switch between them from one solve to the next.
         p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
         HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
+    } else if (s->use_layout_e()) {  // (box path: horizons beyond layout D's plans)
+        p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
+        HIP_TRY(launch_solve_e(p, s->fs, s->stream));
     } else if (s->use_layout_d()) {
         HIP_TRY((s->d_jit || (!p.const_tables && s->d_varying_jit)) ? launch_solve_jit(p, s->W, s->stream)
                          : s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
@@ -1044,7 +1053,8 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
     decide_layout_d_variants(s);
-    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->layout_m) {
+    if ((rc = decide_layout_e(s))) return rc;
+    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
@@ -1607,7 +1617,7 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
     buf[0] = '\0';
     const bool fam = s->families_active(), adaptive = s->st.adaptive_rho != 0;
     if (s->layout_m) snprintf(buf, (size_t)len, "compiled-in layout=M");
-    else if (!s->e_sig.empty() && fam && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), true, s->fs, buf, (size_t)len);
+    else if (!s->e_sig.empty() && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), fam, s->fs, buf, (size_t)len);
     else if (s->use_layout_d() && !(s->d_jit || fam || adaptive || (!s->tables_const() && s->d_varying_jit))) snprintf(buf, (size_t)len, "compiled-in layout=D");
     else if (s->layout_d || s->d_jit || s->d_jit_asked) {
         if ((rc = bind_device(s))) return rc;

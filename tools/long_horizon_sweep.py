@@ -1,5 +1,6 @@
 """Long horizons on the batched box path (16 lanes per instance): layout D's two plans (two wavefronts per SIMD; one
-wavefront with 512 registers once the duals no longer fit) against layouts B and A. Kernel time, fraction of the FP64 vector
+wavefront with 512 registers once the duals no longer fit) and layout E (the horizon cut across the eight wavefronts of a
+workgroup, two per SIMD at any horizon) against layouts B and A. Kernel time, fraction of the FP64 vector
 roof, parity of the same run against the oracle.
 Usage (GPU box): python tools/long_horizon_sweep.py > gpurun_out/long_horizon_sweep.txt"""
 import os
@@ -32,12 +33,19 @@ def system(nx, nu, N, seed=0):
 
 
 print(f"# {ITERS} forced iterations per solve; (12,4): quadrotor, other sizes: random systems as in tools/wide_sweep.py")
-for nx, nu, N, BATCH in ((12, 4, 40, 8192), (12, 4, 50, 8192), (12, 4, 60, 8192), (12, 4, 75, 8192), (12, 4, 100, 8192), (12, 4, 110, 8192), (12, 4, 125, 8192),
-                         (6, 3, 100, 8192), (24, 8, 30, 4096), (24, 8, 60, 4096), (24, 8, 80, 4096), (48, 16, 20, 2048), (48, 16, 40, 2048), (48, 16, 60, 2048)):
-    prob = P.quadrotor(N) if (nx, nu) == (12, 4) else system(nx, nu, N)
+SHAPES = ((12, 4, 40, 8192), (12, 4, 50, 8192), (12, 4, 60, 8192), (12, 4, 75, 8192), (12, 4, 100, 8192), (12, 4, 110, 8192), (12, 4, 125, 8192), (12, 4, 200, 8192),
+          (6, 3, 100, 8192), (4, 1, 200, 8192), (24, 8, 30, 4096), (24, 8, 60, 4096), (24, 8, 80, 4096), (48, 16, 20, 2048), (48, 16, 40, 2048), (48, 16, 60, 2048))
+if "--narrow" in sys.argv:
+    SHAPES = tuple(sh for sh in SHAPES if sh[0] + sh[1] <= 16)
+for nx, nu, N, BATCH in SHAPES:
+    prob = P.quadrotor(N) if (nx, nu) == (12, 4) else P.cartpole(N, True) if (nx, nu) == (4, 1) else system(nx, nu, N)
     rng = np.random.default_rng(1)
     x0s = np.asfortranarray(prob.x0[:, None] + 0.1 * rng.standard_normal((prob.nx, BATCH)))
-    for layout in (None, "B", "A"):
+    for layout in (None, "D", "E", "B", "A"):
+        if layout == "E" and nx + nu > 16:
+            continue
+        if layout == "A" and "--narrow" in sys.argv:
+            continue
         if layout:
             os.environ["TINYMPC_LAYOUT"] = layout
         else:
@@ -46,6 +54,7 @@ for nx, nu, N, BATCH in ((12, 4, 40, 8192), (12, 4, 50, 8192), (12, 4, 60, 8192)
         s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=BATCH, rho=prob.rho, max_iter=ITERS, abs_pri_tol=0.0, abs_dua_tol=0.0)
         s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         s.set_x0_batch(x0s)
+        s.prepare()  # (layout E and the variants of layout D are decided -- and built -- here rather than at the first launch)
         info = s.launch_info()
         if layout and info["layout"] != layout:
             s.reset()
