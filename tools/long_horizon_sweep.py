@@ -41,7 +41,11 @@ for nx, nu, N, BATCH in SHAPES:
     prob = P.quadrotor(N) if (nx, nu) == (12, 4) else P.cartpole(N, True) if (nx, nu) == (4, 1) else system(nx, nu, N)
     rng = np.random.default_rng(1)
     x0s = np.asfortranarray(prob.x0[:, None] + 0.1 * rng.standard_normal((prob.nx, BATCH)))
-    for layout in (None, "D", "E", "B", "A"):
+    LAYOUTS = (None, "D", "E", "B", "A")
+    for a in sys.argv:
+        if a.startswith("--layouts="):
+            LAYOUTS = tuple(x for x in a.split("=", 1)[1].split(","))
+    for layout in LAYOUTS:
         if layout == "E" and nx + nu > 16:
             continue
         if layout == "A" and "--narrow" in sys.argv:
