@@ -145,14 +145,14 @@ def test_unsupported_family_shapes_fail_loudly(pkg):
     rk = P.rocket(10, with_linear=False)
     rk.cones = {}
     s = make(pkg, rk, {})
-    with pytest.raises(pkg.TinyMPCError) as ei:  # overlapping state cones
-        s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
+    with pytest.raises(pkg.TinyMPCError) as ei:  # a chain of five cones, each sharing a row with its predecessor: five rounds
+        s.set_cone_constraints([0, 1, 2, 3, 4], [2, 2, 2, 2, 2], [0.5] * 5, [], [], [])
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     with pytest.raises(pkg.TinyMPCError) as ei:  # cone outside the state vector
         s.set_cone_constraints([4], [3], [0.5], [], [], [])
     assert ei.value.code == pkg._lib.ERR_INVALID_INPUT
-    with pytest.raises(pkg.TinyMPCError) as ei:  # more rows than the kernel keeps in registers
-        s.set_linear_constraints(np.ones((9, 6)), np.ones(9), np.zeros((0, 3)), np.zeros(0))
+    with pytest.raises(pkg.TinyMPCError) as ei:  # more rows than the family buffer holds
+        s.set_linear_constraints(np.ones((33, 6)), np.ones(33), np.zeros((0, 3)), np.zeros(0))
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     s.solve()  # nothing was installed by the failed calls: plain box solve still works
     s.reset()
@@ -384,4 +384,125 @@ def test_layout_d_variants_share_the_persistent_state_with_the_other_kernels(pkg
         assert seen == ["D"] * 4, seen
     else:
         assert seen[0] == "D" and seen[2] == "D" and seen[1] != "D" and seen[3] != "D", seen
+    s.reset()
+
+
+def _many_rows(rng, n, dim, point, margin):
+    """n half-spaces a'k s <= b_k that a given point satisfies with `margin` to spare (so that the set is not empty)."""
+    A = rng.standard_normal((n, dim))
+    b = A @ point + margin * rng.uniform(0.5, 1.5, n)
+    return A, b
+
+
+@pytest.mark.parametrize("layout,N,batch", [("A", 12, 3), ("C", 20, 1), ("D", 16, 1301), ("E", 100, 203)])
+def test_twelve_linear_rows_per_side(pkg, kernel_layout, monkeypatch, layout, N, batch):
+    """More linear rows than any kernel keeps in registers (bindings.cpp:408-431 forwards any number): 12 state rows and 5 input
+    rows, walked one after another as upstream does, on every kernel that carries the families -- k_admm_solve_fam (rows beyond
+    the eighth from L2), the latency kernel and layout D (LDS, run-time loop), layout E (LDS; more than four rows: one copy of the
+    row's code behind a loop)."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.setenv("TINYMPC_LAYOUT", layout)
+    rk = pkg.problems.rocket(N)
+    rng = np.random.default_rng(12)
+    Ax, bx = _many_rows(rng, 12, 6, np.array([0.0, 0.0, 5.0, 0.0, 0.0, 0.0]), 30.0)
+    Au, bu = _many_rows(rng, 5, 3, np.array([0.0, 0.0, 10.0]), 40.0)
+    rk.linear = dict(Alin_x=Ax, blin_x=bx, Alin_u=Au, blin_u=bu)
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-4)
+    s = make(pkg, rk, settings, batch=batch)
+    x0s = rk.x0[:, None] * rng.uniform(0.7, 1.1, (1, batch)) + 0.05 * rng.standard_normal((6, batch))
+    if batch > 1:
+        s.set_x0_batch(x0s)
+    else:
+        s.set_x0(x0s[:, 0])
+    s.solve()
+    assert s.launch_info()["layout"] == layout, s.jit_info()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    for b in sorted({0, batch // 2, batch - 1}):
+        o = oracle(rk, settings)
+        o.set_x0(x0s[:, b])
+        o.solve()
+        assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], b
+        assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
+    s.reset()
+    with pytest.raises(pkg.TinyMPCError) as ei:  # the buffer's limit
+        s2 = make(pkg, rk, settings)
+        s2.set_linear_constraints(np.ones((33, 6)), np.ones(33), np.zeros((0, 3)), np.zeros(0))
+    assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
+    s2.reset()
+
+
+@pytest.mark.parametrize("layout,N,batch", [("C", 20, 1), ("E", 100, 203)])
+def test_equality_constraints_through_the_class_surface(pkg, kernel_layout, monkeypatch, layout, N, batch):
+    """set_equality_constraints (TinyMPC.m:296-317): Aeq s == beq becomes the two inequalities [A; -A] s <= [b; -b] -- five
+    equality rows are ten linear rows, more than the kernels' register budget of round 2 allowed. The solution must satisfy the
+    equalities within the primal tolerance and equal the restatement's."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.setenv("TINYMPC_LAYOUT", layout)
+    rk = pkg.problems.rocket(N, with_linear=False)
+    rk.cones = dict(Acx=[], qcx=[], cx=[], Acu=[0], qcu=[3], cu=[0.25])
+    rng = np.random.default_rng(5)
+    Aeq = np.vstack([np.eye(6)[[0, 1, 3]] * [[1.0], [1.0], [0.5]], rng.standard_normal((2, 6)) * 0.2])  # 5 rows
+    Aeq[3:, 2] = 0.0
+    beq = np.zeros(5)  # x = y = 0, vx = 0 and two more combinations: consistent (the origin satisfies them)
+    s = make(pkg, rk, dict(max_iter=80, abs_pri_tol=1e-3, abs_dua_tol=1e-4), batch=batch)
+    s.set_equality_constraints(Aeq, beq, np.zeros((0, 3)), np.zeros(0))
+    x0s = rk.x0[:, None] * rng.uniform(0.8, 1.1, (1, batch))
+    if batch > 1:
+        s.set_x0_batch(x0s)
+    else:
+        s.set_x0(x0s[:, 0])
+    s.solve()
+    assert s.launch_info()["layout"] == layout, s.jit_info()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    rk2 = pkg.problems.rocket(N, with_linear=False)
+    rk2.cones = rk.cones
+    rk2.linear = dict(Alin_x=np.vstack([Aeq, -Aeq]), blin_x=np.concatenate([beq, -beq]), Alin_u=np.zeros((0, 3)), blin_u=np.zeros(0))
+    for b in sorted({0, batch - 1}):
+        o = oracle(rk2, dict(max_iter=80, abs_pri_tol=1e-3, abs_dua_tol=1e-4))
+        o.set_x0(x0s[:, b])
+        o.solve()
+        assert st["iter"][b] == o.stats()["iter"], b
+        assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
+    s.reset()
+
+
+@pytest.mark.parametrize("layout,N,batch", [("A", 12, 1), ("A", 30, 37), ("E", 100, 203)])
+def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, monkeypatch, layout, N, batch):
+    """Two state cones that share rows (rows 0-2 and rows 1-4) plus the input cone: upstream projects the cones of a knot in list
+    order (each sees its predecessor's result), which differs from projecting them at once. The kernels group the list into
+    rounds of pairwise-disjoint cones: k_admm_solve_fam walks the rounds with mask rows from L2 (any batch, any horizon, also
+    where the latency kernel would otherwise run), layout E has them compiled in. Against the restatement (sequential loops)."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.setenv("TINYMPC_LAYOUT", layout)
+    rk = pkg.problems.rocket(N)
+    rk.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.5, 0.8], Acu=[0], qcu=[3], cu=[0.25])
+    settings = dict(max_iter=70, abs_pri_tol=1e-3, abs_dua_tol=1e-4)
+    rng = np.random.default_rng(3)
+    s = make(pkg, rk, settings, batch=batch)
+    x0s = rk.x0[:, None] * rng.uniform(0.7, 1.1, (1, batch)) + 0.05 * rng.standard_normal((6, batch))
+    if batch > 1:
+        s.set_x0_batch(x0s)
+    else:
+        s.set_x0(x0s[:, 0])
+    s.solve()
+    assert s.launch_info()["layout"] == layout, s.jit_info()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    differs = False
+    for b in sorted({0, batch // 2, batch - 1}):
+        o = oracle(rk, settings)
+        o.set_x0(x0s[:, b])
+        o.solve()
+        assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], b
+        assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
+        # (and the order matters: the reversed list gives another trajectory)
+        rv = pkg.problems.rocket(N)
+        rv.cones = dict(Acx=[1, 0], qcx=[4, 3], cx=[0.8, 0.5], Acu=[0], qcu=[3], cu=[0.25])
+        o2 = oracle(rv, settings)
+        o2.set_x0(x0s[:, b])
+        o2.solve()
+        differs = differs or rel_err(o2.solution()[0], o.solution()[0]) > 1e-6
+    assert differs, "the test problem does not exercise the order of the projections"
     s.reset()

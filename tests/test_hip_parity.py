@@ -87,7 +87,9 @@ def test_layout_selection(pkg, kernel_layout, monkeypatch):
     assert info["layout"] == "D" and info["workgroups"] == 128  # N = 120: the plan with one wavefront per SIMD (four per workgroup)
     s.reset()
     s = make_solver(pkg, P.cartpole(250, True), {}, batch=2048)
-    assert s.launch_info()["layout"] in ("A", "B")  # N = 250 fits neither register plan of layout D
+    assert s.launch_info()["layout"] in ("A", "B")  # N = 250 fits neither register plan of layout D ...
+    s.prepare()
+    assert s.launch_info()["layout"] == "E" and s.launch_info()["workgroups"] == 512  # ... layout E cuts the horizon across a workgroup's wavefronts
     s.reset()
     monkeypatch.setenv("TINYMPC_LAYOUT", "B")
     s = make_solver(pkg, P.cartpole(5, True), {})

@@ -309,13 +309,13 @@ int refresh_derived(tinympc_solver *s) {
 FamilyStructure family_structure(const tinympc_solver *s, double *mu = nullptr) {
     FamilyStructure fs;
     const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
-    unsigned used = 0;  // lanes taken by the cones of the current round
+    unsigned long long used = 0;  // lanes taken by the cones of the current round
     auto add = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
         if (!on) return;
         for (size_t k = 0; k < Ac.size() && fs.ncone < MAX_CONES; ++k) {
             const int first = base + Ac[k], last = first + qc[k] - 1;
-            unsigned lanes = 0;
-            for (int r = first; r <= last; ++r) lanes |= 1u << r;
+            unsigned long long lanes = 0;
+            for (int r = first; r <= last; ++r) lanes |= 1ull << (r & 63);
             if (fs.ncone == 0) fs.nround = 1;
             if (lanes & used) {  // overlaps an earlier cone of this round: upstream projects one after the other
                 fs.nround += 1;
@@ -364,20 +364,31 @@ int refresh_families(tinympc_solver *s) {
         for (int k = 0; k < nxu; ++k)
             if ((k < nx) == is_x) Ty[(size_t)r * KT + k] = 1.0;
     }
-    auto add_cones = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
-        if (!on) return;
-        for (size_t ci = 0; ci < Ac.size(); ++ci) {
-            const int first = base + Ac[ci], last = first + qc[ci] - 1;
+    // cones, round by round (family_structure: cones of one round are pairwise disjoint): round 0 into the arrays every kernel
+    // reads, later rounds -- they exist only where cones share rows -- behind them for the kernels that walk rounds
+    {
+        std::vector<double> cmu(MAX_CONES, 0.0);
+        const FamilyStructure fs = family_structure(s, cmu.data());
+        f[fam_nround_offset(W, KT)] = (double)(fs.nround > 0 ? fs.nround : 1);
+        for (int c = 0; c < fs.ncone; ++c) {
+            const int q = fs.cone[c][0], first = fs.cone[c][1], last = fs.cone[c][2];
+            double *rl = role, *m = mu, *cn = Cn, *ct = Ct;
+            if (q >= 1) {
+                rl = f.data() + fam_round_offset(W, KT, q);
+                m = rl + W;
+                cn = m + W;
+                ct = cn + (size_t)W * KT;
+            }
             for (int r = first; r <= last; ++r) {
-                role[r] = (r == last) ? 2.0 : 1.0;
-                mu[r] = c[ci];
-                for (int k = first; k < last; ++k) Cn[(size_t)r * KT + k] = 1.0;
-                Ct[(size_t)r * KT + last] = 1.0;
+                rl[r] = (r == last) ? 2.0 : 1.0;
+                m[r] = cmu[c];
+                for (int k = first; k < last; ++k) cn[(size_t)r * KT + k] = 1.0;
+                ct[(size_t)r * KT + last] = 1.0;
             }
         }
-    };
-    add_cones(cone_x, s->Acx, s->qcx, s->cx, 0);
-    add_cones(cone_u, s->Acu, s->qcu, s->cu, nx);
+    }
+    (void)cone_x;
+    (void)cone_u;
     const int nlx = lin_x ? s->n_lin_x : 0, nlu = lin_u ? s->n_lin_u : 0;
     const int nl = nlx > nlu ? nlx : nlu;
     lin[0] = (double)nl;
@@ -430,7 +441,9 @@ void decide_layout_d_variants(tinympc_solver *s) {
     if (s->families_active() && !s->st.adaptive_rho) {
         // families: a run-time specialisation (16-lane form, horizons whose five register pairs per knot fit)? Asked every
         // time -- the answer is cached inside -- because it also depends on the tables' kind.
-        s->d_fam = (s->W == 16 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+        // (cones that share rows need the round-by-round projection, which layout D's families variant and the latency kernel
+        // do not have: layout E or k_admm_solve_fam run those)
+        s->d_fam = (s->W == 16 && family_structure(s).nround <= 1 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
     }
 }
 
@@ -542,7 +555,7 @@ int launch(tinympc_solver *s, bool timed) {
         p.families = 1;
         p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
         HIP_TRY(launch_solve_e(p, s->fs, s->stream));
-    } else if (fam && s->fam_c) {
+    } else if (fam && s->fam_c && family_structure(s).nround <= 1) {
         // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
         p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
         p.families = 1;
@@ -1083,6 +1096,8 @@ int tinympc_session_begin(tinympc_solver *s) {
     if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
     if (s->families_active() && s->chunk_len > 4)
         return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
+    if (s->families_active() && family_structure(s).nround > 1)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows are not supported by the resident kernel");
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
     if (!s->h_mail) {
         HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
@@ -1346,24 +1361,43 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
     if ((ncx > 0 && (!Acx || !qcx || !cx)) || (ncu > 0 && (!Acu || !qcu || !cu)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_cone_constraints: NULL array for a non-empty side");
     if (s->session_active && (rc = bind_device(s))) return rc;  // the resident kernel was started with the old families
-    // Each cone must lie inside its vector and cones of one side must not share rows: the kernel projects
-    // all cones of a knot at once (upstream applies them one after another, which only differs if they overlap).
+    // Each cone must lie inside its vector. Cones of one side MAY share rows: upstream projects the cones of a knot one after
+    // another (bindings.cpp:433-478 hands the list over in order), which the kernels reproduce by grouping the list into rounds of
+    // pairwise-disjoint cones (family_structure); at most MAX_CONES cones in MAX_ROUNDS rounds.
     auto check_side = [&](const int *Ac, const int *qc, const double *c, int n, int dim, const char *side) -> int {
-        std::vector<int> owner(dim, -1);
         for (int k = 0; k < n; ++k) {
             if (qc[k] < 1 || Ac[k] < 0 || Ac[k] + qc[k] > dim)
                 return fail(TINYMPC_ERR_INVALID_INPUT, "%s cone %d (start %d, dimension %d) does not fit a vector of %d rows", side, k, Ac[k], qc[k], dim);
             if (!(c[k] > 0.0)) return fail(TINYMPC_ERR_INVALID_INPUT, "%s cone %d has non-positive slope %g", side, k, c[k]);
-            for (int r = Ac[k]; r < Ac[k] + qc[k]; ++r) {
-                if (owner[r] >= 0)
-                    return fail(TINYMPC_ERR_UNSUPPORTED, "%s cones %d and %d overlap at row %d: overlapping cones are not supported by the HIP kernel", side, owner[r], k, r);
-                owner[r] = k;
-            }
         }
         return TINYMPC_OK;
     };
     if ((rc = check_side(Acx, qcx, cx, ncx, s->nx, "state"))) return rc;
     if ((rc = check_side(Acu, qcu, cu, ncu, s->nu, "input"))) return rc;
+    if (ncx + ncu > MAX_CONES)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d cones are supported by the HIP kernels (got %d state + %d input)", MAX_CONES, ncx, ncu);
+    {   // rounds of the whole list, both sides enabled (the worst case of what a launch can see)
+        int rounds = 0;
+        unsigned long long used = 0;
+        auto walk = [&](const int *Ac, const int *qc, int n, int base) {
+            for (int k = 0; k < n; ++k) {
+                unsigned long long lanes = 0;
+                for (int r = base + Ac[k]; r < base + Ac[k] + qc[k]; ++r) lanes |= 1ull << (r & 63);
+                if (rounds == 0) rounds = 1;
+                if (lanes & used) {
+                    rounds += 1;
+                    used = 0;
+                }
+                used |= lanes;
+            }
+        };
+        if (s->nx + s->nu <= 64) {  // (larger systems have no families kernel at all: refused at launch)
+            walk(Acx, qcx, ncx, 0);
+            walk(Acu, qcu, ncu, s->nx);
+        }
+        if (rounds > MAX_ROUNDS)
+            return fail(TINYMPC_ERR_UNSUPPORTED, "the cone list needs %d rounds of pairwise-disjoint cones; the HIP kernels support %d", rounds, MAX_ROUNDS);
+    }
     s->n_cone_x = ncx;
     s->n_cone_u = ncu;
     s->Acx.assign(Acx, Acx + ncx); s->qcx.assign(qcx, qcx + ncx); s->cx.assign(cx, cx + ncx);
@@ -1597,7 +1631,7 @@ int tinympc_get_layout(tinympc_solver *s) {
     if (s->use_layout_d()) return 'D';
     if (s->use_layout_e()) return 'E';
     // the families and adaptive rho have kernels of their own on layout A's plan (the families also in the latency kernel)
-    if (s->families_active()) return s->fam_c ? 'C' : 'A';
+    if (s->families_active()) return (s->fam_c && family_structure(s).nround <= 1) ? 'C' : 'A';
     if (s->st.adaptive_rho) return 'A';
     return s->layout_c ? 'C' : s->layout_b ? 'B' : 'A';
 }

@@ -182,10 +182,20 @@ struct AdaptTableParams {
 //   ak[W], bk[W], nk[W]   coefficient of the row in constraint k, its bound (+inf if absent), ||a_k||^2
 //   ... and, for layout E (which walks the cones one by one, in list order): cone_mu[MAX_CONES], the slope of cone c of the
 //   active list (state cones first, then input cones)
-constexpr int MAX_LIN_ROWS = 8;
+//   ... then the ROUNDS of the cone list beyond the first: upstream projects the cones one after another, which differs from
+//   projecting them at once only where two cones share a row. The cones are grouped into rounds of pairwise-disjoint cones (a
+//   cone that overlaps an earlier cone of the current round opens the next round); role / mu / Cn / Ct above describe round
+//   0, and behind cone_mu follow nround (1 double) and, for rounds 1 .. MAX_ROUNDS-1, role[W] | mu[W] | Cn[W][KT] | Ct[W][KT]:
+//   fam_round_offset(). The generic kernels that walk rounds (k_admm_solve_fam) read them from there.
+constexpr int MAX_LIN_ROWS = 32;  // per side; the coefficient block of the buffer and the kernels' LDS copies are sized for it
+constexpr int FAM_REG_ROWS = 8;   // k_admm_solve_fam keeps this many rows' coefficients in registers, the rest is read per use
 constexpr int MAX_CONES = 16;
+constexpr int MAX_ROUNDS = 4;
 __host__ __device__ inline size_t fam_cone_mu_offset(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
-__host__ __device__ inline size_t fam_doubles(int W, int KT) { return fam_cone_mu_offset(W, KT) + MAX_CONES; }
+__host__ __device__ inline size_t fam_round_doubles(int W, int KT) { return (size_t)2 * W + (size_t)2 * W * KT; }
+__host__ __device__ inline size_t fam_nround_offset(int W, int KT) { return fam_cone_mu_offset(W, KT) + MAX_CONES; }
+__host__ __device__ inline size_t fam_round_offset(int W, int KT, int round) { return fam_nround_offset(W, KT) + 1 + (size_t)(round - 1) * fam_round_doubles(W, KT); }
+__host__ __device__ inline size_t fam_doubles(int W, int KT) { return fam_round_offset(W, KT, MAX_ROUNDS); }
 
 // ---- layout E (tinympc_solve_e.hip): the horizon cut across the `wpg` wavefronts of a workgroup, S slots each (the last
 // wavefront: what is left). LDS plan per workgroup, in doubles:

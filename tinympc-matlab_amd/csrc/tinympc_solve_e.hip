@@ -347,15 +347,20 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         if constexpr (E_NL > 0) {
             const double s_in = val + gl_old;
             double sv = s_in;
-            e_static_for<0, E_NL>([&](auto K) {
-                constexpr int k = K.value;
+            auto row = [&](int k) {
                 const double a_k = sLin[(3 * k + 0) * W + r], b_k = sLin[(3 * k + 1) * W + r], in_k = sLin[(3 * k + 2) * W + r];
                 const double w = a_k * sv;
                 double dot = 0.0, unused = 0.0;
-                if constexpr (k < E_NLX) e_masked_gather<0, NX, false, 0>(mask_x, w, w, one, dot, unused);
-                if constexpr (k < E_NLU) e_masked_gather<NX, NU, false, 0>(mask_u, w, w, one, dot, unused);
+                if (k < E_NLX) e_masked_gather<0, NX, false, 0>(mask_x, w, w, one, dot, unused);
+                if (k < E_NLU) e_masked_gather<NX, NU, false, 0>(mask_u, w, w, one, dot, unused);
                 sv = halfspace_project_element(sv, dot, a_k, b_k, in_k);
-            });
+            };
+            if constexpr (E_NL <= 4) {  // a few rows: straight-line code (the row index folds into the branches above)
+                e_static_for<0, E_NL>([&](auto K) { row(K.value); });
+            } else {                    // many rows (an equality constraint counts twice): one copy of the row's code
+#pragma unroll 1
+                for (int k = 0; k < E_NL; ++k) row(k);
+            }
             const double gln = s_in - sv;
             if (faml) {
                 gl_new = gln;

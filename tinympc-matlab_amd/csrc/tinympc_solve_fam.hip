@@ -88,13 +88,17 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     const bool famc = p.fam[2 * W + r] != 0.0, faml = p.fam[3 * W + r] != 0.0;
     const double *lin = p.fam + 4 * W + (size_t)3 * W * KT;
     const int nl = (int)lin[0];
-    double ak[MAX_LIN_ROWS], bk[MAX_LIN_ROWS], ink[MAX_LIN_ROWS];  // ink = 1 / ||a_k||^2
+    // the first FAM_REG_ROWS rows' coefficients in registers; problems with more rows (an equality constraint of five rows is
+    // ten) read the rest from the family buffer (L2) where they are used
+    double ak[FAM_REG_ROWS], bk[FAM_REG_ROWS], ink[FAM_REG_ROWS];  // ink = 1 / ||a_k||^2
 #pragma unroll
-    for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+    for (int k = 0; k < FAM_REG_ROWS; ++k) {
         ak[k] = lin[1 + (size_t)(3 * k + 0) * W + r];
         bk[k] = lin[1 + (size_t)(3 * k + 1) * W + r];
         ink[k] = 1.0 / lin[1 + (size_t)(3 * k + 2) * W + r];
     }
+    // rounds of the cone list beyond the first (cones that share rows are projected one after another, as upstream does)
+    const int nround = (int)p.fam[fam_nround_offset(W, KT)];
     // wave-uniform switches: is either family in use at all?
     const bool any_cone = __ballot(famc) != 0ull, any_lin = __ballot(faml) != 0ull;
 
@@ -119,7 +123,22 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             const double sv = val + gc_old;                              // vcnew = x + gc (all rows of an enabled side)
             const double a2 = group_matvec<W, KT>(cn, sv * sv, 0.0);     // ||w||^2 of the row's cone
             const double t = group_matvec<W, KT>(ct, sv, 0.0);           // last entry of the row's cone
-            const double vc = soc_project_element(sv, a2, t, mu, inv_mu, role);
+            double vc = soc_project_element(sv, a2, t, mu, inv_mu, role);
+#pragma unroll 1
+            for (int q = 1; q < nround; ++q) {                           // (uniform trip count; the masks of round q from L2)
+                const double *rd = p.fam + fam_round_offset(W, KT, q);
+                const int role_q = (int)rd[r];
+                const double mu_q = rd[W + r];
+                double cq[KT], tq[KT];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    cq[k] = rd[2 * W + (size_t)r * KT + k];
+                    tq[k] = rd[2 * W + (size_t)W * KT + (size_t)r * KT + k];
+                }
+                const double a2q = group_matvec<W, KT>(cq, vc * vc, 0.0);
+                const double tq_ = group_matvec<W, KT>(tq, vc, 0.0);
+                vc = soc_project_element(vc, a2q, tq_, mu_q, (mu_q != 0.0) ? 1.0 / mu_q : 0.0, role_q);
+            }
             const double gcn = sv - vc;                                  // gc + x - vcnew
             if (famc) {
                 gc_new = gcn;
@@ -130,11 +149,18 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             const double s0 = val + gl_old;
             double sv = s0;
 #pragma unroll
-            for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+            for (int k = 0; k < FAM_REG_ROWS; ++k) {
                 if (k < nl) {                                            // wave-uniform
                     const double dot = group_matvec<W, KT>(ty, ak[k] * sv, 0.0);
                     sv = halfspace_project_element(sv, dot, ak[k], bk[k], ink[k]);
                 }
+            }
+#pragma unroll 1
+            for (int k = FAM_REG_ROWS; k < nl; ++k) {                    // (uniform trip count)
+                const double a_k = lin[1 + (size_t)(3 * k + 0) * W + r], b_k = lin[1 + (size_t)(3 * k + 1) * W + r];
+                const double in_k = 1.0 / lin[1 + (size_t)(3 * k + 2) * W + r];
+                const double dot = group_matvec<W, KT>(ty, a_k * sv, 0.0);
+                sv = halfspace_project_element(sv, dot, a_k, b_k, in_k);
             }
             const double gln = s0 - sv;
             if (faml) {
