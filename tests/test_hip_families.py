@@ -478,7 +478,7 @@ def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, m
         pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", layout)
     rk = pkg.problems.rocket(N)
-    rk.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.5, 0.8], Acu=[0], qcu=[3], cu=[0.25])
+    rk.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.2, 0.3], Acu=[0], qcu=[3], cu=[0.25])
     settings = dict(max_iter=70, abs_pri_tol=1e-3, abs_dua_tol=1e-4)
     rng = np.random.default_rng(3)
     s = make(pkg, rk, settings, batch=batch)
@@ -499,7 +499,7 @@ def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, m
         assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
         # (and the order matters: the reversed list gives another trajectory)
         rv = pkg.problems.rocket(N)
-        rv.cones = dict(Acx=[1, 0], qcx=[4, 3], cx=[0.8, 0.5], Acu=[0], qcu=[3], cu=[0.25])
+        rv.cones = dict(Acx=[1, 0], qcx=[4, 3], cx=[0.3, 0.2], Acu=[0], qcu=[3], cu=[0.25])
         o2 = oracle(rv, settings)
         o2.set_x0(x0s[:, b])
         o2.solve()
