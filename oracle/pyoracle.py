@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PORT_LIB = os.path.join(_HERE, "liboracle_port.so")
+# (TINYMPC_ORACLE_PORT_LIB: the sanitizer build of the same source, tools/asan_check.py)
+PORT_LIB = os.environ.get("TINYMPC_ORACLE_PORT_LIB") or os.path.join(_HERE, "liboracle_port.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref.so")
 REF_ZEROINIT_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref_zeroinit.so")  # see oracle/Makefile: adaptive rho only
 

@@ -27,9 +27,22 @@ def _fp(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _emit_library(pkg):
+    """The library whose tinympc_codegen_emit() the emitter tests drive: the product, or -- under tools/asan_check.py -- the
+    sanitizer build of the same source file (host-only code, no device involved either way)."""
+    path = os.environ.get("TINYMPC_ASAN_EMIT_LIB")
+    if not path:
+        return pkg.load_library()
+    lib = C.CDLL(path)
+    lib.tinympc_codegen_emit.restype = C.c_int
+    lib.tinympc_codegen_emit.argtypes = [C.POINTER(pkg._lib.CodegenData), C.c_char_p, C.c_int]
+    lib.tinympc_last_error.restype = C.c_char_p
+    return lib
+
+
 def _emit(pkg, out, prob, cache, settings, sens=None, it=0, solved=0):
     """Drive tinympc_codegen_emit() with plain host arrays (no device involved)."""
-    lib = pkg.load_library()
+    lib = _emit_library(pkg)
     d = pkg._lib.CodegenData()
     keep = []
 
@@ -55,7 +68,7 @@ def _emit(pkg, out, prob, cache, settings, sens=None, it=0, solved=0):
     for n, a in zip(("x_min", "x_max", "u_min", "u_max"), prob.expanded_bounds()):
         put(n, a)
     rc = lib.tinympc_codegen_emit(C.byref(d), str(out).encode(), 0)
-    assert rc == 0, pkg._lib.last_error()
+    assert rc == 0, lib.tinympc_last_error()
 
 
 def _body(path):
@@ -123,7 +136,7 @@ def test_emitter_sensitivity_block_and_errors(pkg, tmp_path):
     np.testing.assert_allclose(m["u_max"][0], prob.expanded_bounds()[3], rtol=0, atol=0)
     # writing twice into the same tree is fine (codegen.cpp:45-49); an unwritable target is an error code, not exit()
     _emit(pkg, tmp_path / "on", prob, cache, SETTINGS)
-    lib = pkg.load_library()
+    lib = _emit_library(pkg)
     assert lib.tinympc_codegen_emit(None, b"/tmp/x", 0) == pkg._lib.ERR_INVALID_INPUT
     blocker = tmp_path / "file"
     blocker.write_text("x")

@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 from conftest import ROOT, golden, rel_err
 
-MOCK = os.path.join(ROOT, "tests", "mock_mex", "libtinympc_matlab_mock.so")
+# (TINYMPC_MOCK_MEX_LIB: the sanitizer build of shim + mock, tools/asan_check.py)
+MOCK = os.environ.get("TINYMPC_MOCK_MEX_LIB") or os.path.join(ROOT, "tests", "mock_mex", "libtinympc_matlab_mock.so")
 
 
 class Mex:
