@@ -125,6 +125,7 @@ struct tinympc_solver {
     bool e_ok = false;
     int e_chunk_len = 0, e_wpg = 0;
     size_t e_lds = 0;
+    double *dclock = nullptr;    // (diagnostic build TINY_CLOCK_STAMP only) per-wavefront clock stamps of the last launch
     double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
     int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)
     // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
@@ -513,6 +514,12 @@ int launch(tinympc_solver *s, bool timed) {
     p.tables_in_lds = s->tables_in_lds ? 1 : 0;
     p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
+#ifdef TINY_CLOCK_STAMP  // diagnostic build (tools/clock_check.py): layout D stamps its iteration loop into this buffer
+    if (!s->state_in_global) {
+        if (!s->dclock && (rc = dalloc(s, &s->dclock, (size_t)8 * s->groups))) return rc;
+        p.scratch = s->dclock;
+    }
+#endif
     p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
     p.const_tables = s->tables_const() ? 1 : 0;
     if (s->zero_copy_tick && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {  // set by tinympc_mpc_step_batch for the duration of one launch
@@ -1659,6 +1666,18 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
     } else snprintf(buf, (size_t)len, "compiled-in layout=%c", (char)tinympc_get_layout(s));
     return TINYMPC_OK;
 }
+
+#ifdef TINY_CLOCK_STAMP
+// Diagnostic build only (not part of the ABI): the stamp records of the last layout-D launch, 8 values per wavefront (see the
+// kernel); returns the number of wavefronts copied into records[8 * capacity].
+int tinympc_debug_clock_stamps(tinympc_solver *s, unsigned long long *records, int capacity) {
+    if (!s || !s->dclock) return 0;
+    if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return 0;
+    const int n = s->groups < capacity ? s->groups : capacity;
+    if (hipMemcpy(records, s->dclock, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+#endif
 
 void *tinympc_get_stream(tinympc_solver *s) { return s ? (void *)s->stream : nullptr; }
 

@@ -148,15 +148,20 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // variable, persistent in p.rho_inst), the lane's operator rows are (base row) + (rho - rho0) * (derivative row) rebuilt from
 // LDS at every sweep, and every fifth iteration the four norms of the reference's dense KKT system ride on the forward sweep
 // (one extra mat-vec per step). Run-time specialised only (-DTINY_JIT_ADAPT=1), not together with the families.
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false>
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true>
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     static_assert(!(FAM && ADAPT), "adaptive rho and the constraint families exclude each other (as in the C ABI)");
+    // this wavefront's slot on its SIMD (HW_REG_HW_ID bits 3:0): the two wavefronts of a SIMD sit in different slots
+    const int simd_slot = TWO_PER_SIMD ? simd_slot_id() : 0;
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
     constexpr int TOFF = (N + 2) * W;
     static_assert(NS >= 3 && VL >= 0 && VL <= NS, "layout D: N >= 4");
     using Step = DStep<NX, NU>;
 
+#ifdef TINY_CLOCK_STAMP
+    const unsigned long long ck_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane >> 4, r = lane & 15;
@@ -211,6 +216,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     }
     __syncthreads();  // the only workgroup-wide barrier: from here on the waves are independent
     if (!grp_ok) return;
+#ifdef TINY_CLOCK_STAMP
+    const unsigned long long ck_barrier = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- register-resident state
     double G[NS], G0, Vr[NVR > 0 ? NVR : 1], V0;
@@ -361,12 +369,16 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         else return sVl[decltype(S)::value * 64];
     };
 
+#ifdef TINY_CLOCK_STAMP  // diagnostic build only (tools/clock_check.py): the shader clock held under this kernel
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int max_iter = p.max_iter;
     for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129
         // (readfirstlane: keeps the loop counter and everything derived from it in SGPRs, so that the branches below
         // are scalar branches and not EXEC-masked regions)
         const int it0 = __builtin_amdgcn_readfirstlane(it);
         const bool final_round = it0 >= max_iter;
+        if constexpr (TWO_PER_SIMD) fair_share_priority(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
         // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
         // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
         const bool wb = pending || (final_round && active);
@@ -669,6 +681,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         }
     }
     lds_wait();
+#ifdef TINY_CLOCK_STAMP
+    // Delta s_memtime (shader cycles) and Delta s_memrealtime (a constant 100 MHz) around the iteration loop, one pair per
+    // wavefront, into a buffer of their own that nothing else reads (SolveParams::scratch, unused by this layout otherwise)
+    const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
     // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
@@ -684,6 +701,23 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     const double rho_res = ADAPT ? snap_rho : rho;
     const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho_res, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho_res;
 
+#ifdef TINY_CLOCK_STAMP
+    // One record per wavefront, into a buffer of its own that nothing else reads (SolveParams::scratch, unused by this layout
+    // otherwise): shader cycles and 100 MHz ticks of the iteration loop (the final round's write-back included), and the ticks of
+    // the phases around it -- entry -> the prologue's barrier (operators, d and the LDS part of the slack in), barrier -> loop
+    // (the register part of the state in), loop end -> here (residual reductions), absolute entry / exit times.
+    if (p.scratch && lane == 0) {
+        unsigned long long *ck = reinterpret_cast<unsigned long long *>(p.scratch) + 8 * (size_t)grp;
+        ck[0] = ck_t1 - ck_t0;
+        ck[1] = ck_r1 - ck_r0;
+        ck[2] = ck_barrier - ck_entry;
+        ck[3] = ck_r0 - ck_barrier;
+        ck[4] = __builtin_amdgcn_s_memrealtime() - ck_r1;
+        ck[5] = ck_entry;
+        ck[6] = __builtin_amdgcn_s_memrealtime();
+        ck[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    }
+#endif
     if (inst_ok && r == 0) {
         if constexpr (ADAPT) p.rho_inst[inst] = rho;
         p.istats[inst * 2 + 0] = it_done;
@@ -732,7 +766,7 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ, ADJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
     __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ>(p, smem_jit);
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ, TINY_JIT_WPS == 2>(p, smem_jit);
 }
 namespace tinympc {
 #else

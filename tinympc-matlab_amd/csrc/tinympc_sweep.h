@@ -266,6 +266,29 @@ __device__ __forceinline__ double halfspace_project_element(double sv, double do
     return dot > bk ? fma(-dist, ak, sv) : sv;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fair share of a SIMD between the two wavefronts of the register-resident kernels (layout D and its wide forms). The issue
+// arbiter prefers the older wavefront: left alone, the wavefront in slot 0 of every SIMD finished its solve at 1.18 ms and its
+// partner at 1.92 ms of the same launch, the partner running ALONE -- every step's LDS wait exposed -- for the last third of the
+// kernel (in-kernel stamps per wavefront with HW_REG_HW_ID, tools/clock_check.py --hwid). The user priority therefore
+// alternates in WALL-CLOCK slices (s_memrealtime: 100 MHz, the same for every wavefront): in even slices of 2^14 ticks
+// (164 us) the wavefront in the even slot leads, in odd slices the other one. At any moment the two hold opposite priorities,
+// each leads half of the time, both advance at the same average rate: 1.68 / 1.71 ms, kernel 1.945 -> 1.80 ms. (Slices shorter
+// than a few iterations do not work -- the wavefronts sample the clock at different moments and compute the same priority half
+// of the time --, and a scheme keyed to the iteration count has no restoring force: one iteration apart both compute the same
+// priority.) Called once every eight iterations; harmless where a wavefront has its SIMD to itself.
+// ------------------------------------------------------------------------------------------------
+#ifndef TINY_PRIO_SHIFT
+#define TINY_PRIO_SHIFT 14
+#endif
+__device__ __forceinline__ int simd_slot_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 4); }  // HW_REG_HW_ID bits 3:0: the wave's slot on its SIMD
+__device__ __forceinline__ void fair_share_priority(int it0, int simd_slot) {
+    if ((it0 & 7) != 0) return;  // (it0: wave-uniform iteration counter)
+    const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> TINY_PRIO_SHIFT);
+    if ((slice ^ (unsigned)simd_slot) & 1u) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 template <int W>
 __device__ __forceinline__ double group_max(double v) {
 #pragma unroll
