@@ -378,7 +378,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         // are scalar branches and not EXEC-masked regions)
         const int it0 = __builtin_amdgcn_readfirstlane(it);
         const bool final_round = it0 >= max_iter;
-        if constexpr (TWO_PER_SIMD) fair_share_priority(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
+        if constexpr (TWO_PER_SIMD) fair_share_priority<NS>(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
         // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
         // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
         const bool wb = pending || (final_round && active);

@@ -276,14 +276,26 @@ __device__ __forceinline__ double halfspace_project_element(double sv, double do
 // each leads half of the time, both advance at the same average rate: 1.68 / 1.71 ms, kernel 1.945 -> 1.80 ms. (Slices shorter
 // than a few iterations do not work -- the wavefronts sample the clock at different moments and compute the same priority half
 // of the time --, and a scheme keyed to the iteration count has no restoring force: one iteration apart both compute the same
-// priority.) Called once every eight iterations; harmless where a wavefront has its SIMD to itself.
+// priority. A/B on the bench workload, stamped builds: off 2.03 ms, slices of 41 / 164 / 655 us 1.855 / 1.845 / 1.874 ms, 164 us
+// re-evaluated only every eighth iteration 1.90 ms.) Re-evaluated every iteration where an iteration is long (WORK = sweep steps
+// x DPP rows per instance >= 32: ~100 cycles of ~18,000), every 2nd / 4th / 8th for shorter ones; harmless where a wavefront has its
+// SIMD to itself.
 // ------------------------------------------------------------------------------------------------
 #ifndef TINY_PRIO_SHIFT
 #define TINY_PRIO_SHIFT 14
 #endif
 __device__ __forceinline__ int simd_slot_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 4); }  // HW_REG_HW_ID bits 3:0: the wave's slot on its SIMD
+template <int WORK>
 __device__ __forceinline__ void fair_share_priority(int it0, int simd_slot) {
-    if ((it0 & 7) != 0) return;  // (it0: wave-uniform iteration counter)
+#ifdef TINY_PRIO_OFF  // (A/B builds, tools/clock_check.py)
+    return;
+#endif
+#ifdef TINY_PRIO_EVERY
+    constexpr int EVERY = TINY_PRIO_EVERY;
+#else
+    constexpr int EVERY = WORK >= 32 ? 1 : WORK >= 16 ? 2 : WORK >= 8 ? 4 : 8;
+#endif
+    if ((it0 & (EVERY - 1)) != 0) return;  // (it0: wave-uniform iteration counter)
     const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> TINY_PRIO_SHIFT);
     if ((slice ^ (unsigned)simd_slot) & 1u) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);

@@ -32,7 +32,8 @@ def build():
     for src in ge.HIP_SOURCES:
         if src in ("tinympc_solve_d.hip", "tinympc_capi.hip"):
             obj = os.path.join(OUT, src.replace(".hip", ".o"))
-            cmd = [hipcc] + ge.HIP_CFLAGS + ["-DTINY_CLOCK_STAMP=1", "-c", os.path.join(ge.CSRC, src), "-o", obj]
+            extra = [a for a in sys.argv[2:] if a.startswith("-D")]  # (experiments: -DTINY_PRIO_SHIFT=.. -DTINY_PRIO_EVERY=.. -DTINY_PRIO_OFF)
+            cmd = [hipcc] + ge.HIP_CFLAGS + ["-DTINY_CLOCK_STAMP=1"] + extra + ["-c", os.path.join(ge.CSRC, src), "-o", obj]
             print("+", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
         else:
@@ -62,6 +63,12 @@ def run():
     groups = (batch + 3) // 4
     rec = (C.c_ulonglong * (8 * groups))()
     samples = []
+    if "--bench-like" in sys.argv:  # the driver's pattern: 5 warm-up + 20 timed cold-started launches, nothing before
+        ms = []
+        for _ in range(25):
+            s.reset_workspace()
+            ms.append(s.solve_timed())
+        print("bench-like: warm-up", ["%.3f" % x for x in ms[:5]], "timed avg %.4f" % (sum(ms[5:]) / 20), "min %.3f max %.3f" % (min(ms[5:]), max(ms[5:])))
     t0 = time.perf_counter()
     launches, ms = 0, []
     while True:
