@@ -184,6 +184,27 @@ def usable_cpus():
     return cpus, quota, src
 
 
+def leg_counters(leg: str, iters_per_s: float) -> dict:
+    """What rocprofv3 measured for this leg's kernel (profiles/r03_<leg>_pmc.json, tools/profile_legs.sh + collect_leg_profiles.py):
+    VALU issue fraction of the chip, HBM bytes per instance-iteration -> measured GB/s at the LIVE rate of this run. Empty when
+    the profile is absent. The counters belong to the kernels of the round's last collection; the rates are this run's."""
+    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % leg)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    out = {"source": "profiles/r03_%s_pmc.json" % leg}
+    dd, hb = d.get("derived") or {}, d.get("hbm") or {}
+    for k in ("valu_per_wave_iteration", "valu_issue_fraction_of_chip", "shader_clock_ghz_grbm"):
+        if k in dd:
+            out[k] = dd[k]
+    if "bytes_per_instance_iteration" in hb:
+        gbs = hb["bytes_per_instance_iteration"] * iters_per_s / 1e9
+        out.update(hbm_bytes_per_instance_iteration=hb["bytes_per_instance_iteration"], hbm_measured_gbs=gbs, hbm_measured_frac=gbs / PEAK_HBM_GBS)
+    return {"measured": out}
+
+
 def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host cores this
     process may use: one PROCESS per usable CPU (Eigen's per-operation malloc makes threads of one process contend), each
@@ -457,7 +478,7 @@ def main() -> int:
             med = ms[len(ms) // 2]
             out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
                                       "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                      "layout": one.launch_info()["layout"]}
+                                      "layout": one.launch_info()["layout"], **leg_counters("single_instance", args.iters / (med * 1e-3))}
             one.reset()
             # BASELINE config 4: one rocket-landing instance, N=100, second-order cones + a linear row + fdyn
             rk = P.rocket(100)
@@ -480,7 +501,8 @@ def main() -> int:
             med = sorted(ms[2:])[len(ms[2:]) // 2]
             out["rocket_instance"] = {"workload": "rocket landing nx=6 nu=3 N=100, state + input cones, 1 linear row, fdyn, %d forced iterations" % args.iters,
                                       "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
-                                      "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None}
+                                      "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None,
+                                      **leg_counters("rocket_instance", args.iters / (med * 1e-3))}
             one.reset()
             # ... and batches of it: N=100 (BASELINE config 4's horizon: the latency kernel, one workgroup per instance) and
             # N=10 (the horizon of examples/rocket_landing_constraints.m:14: layout D with the families in registers)
@@ -502,7 +524,9 @@ def main() -> int:
                     many.reset_workspace()
                     ms.append(many.solve_timed())
                 med = sorted(ms[1:])[len(ms[1:]) // 2]
-                rb["N=%d" % rN] = {"iters_per_s": rB * rit / (med * 1e-3), "kernel_ms": med, "layout": many.launch_info()["layout"]}
+                rb["N=%d" % rN] = {"iters_per_s": rB * rit / (med * 1e-3), "kernel_ms": med, "layout": many.launch_info()["layout"], "jit": many.jit_info(),
+                                   "box_part_fp64_frac": rB * rit * rkb.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                   **(leg_counters("rocket_batch", rB * rit / (med * 1e-3)) if rN == 100 else {})}
                 many.reset()
             out["rocket_batch"] = dict(workload="4096 rocket-landing instances (cones + linear row + fdyn) x 100 forced iterations", **rb)
             # Adaptive rho (admm.cpp:117-174) on a batch: rho, its operator rows and pNref per instance, layout D's ADAPT variant
@@ -520,7 +544,9 @@ def main() -> int:
             med = sorted(ms[1:])[len(ms[1:]) // 2]
             out["adaptive_rho_batch"] = {"workload": "quadrotor N=%d, %d instances x %d forced iterations, rho adapted every 5th" % (prob.N, aB, ait),
                                          "iters_per_s": aB * ait / (med * 1e-3), "kernel_ms": med, "layout": ad.launch_info()["layout"],
-                                         "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))]}
+                                         "fp64_frac_box_part": aB * ait * flops_iter / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                         "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))],
+                                         **leg_counters("adaptive_rho_batch", aB * ait / (med * 1e-3))}
             ad.reset()
         if not args.no_single:
             # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
@@ -542,7 +568,8 @@ def main() -> int:
             wtf = wB * wit * wp.flops_per_iteration() / (med * 1e-3) / 1e12
             out["wide_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (wnx, wnu, wN, wB, wit),
                                   "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
-                                  "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"]}
+                                  "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"],
+                                  **leg_counters("wide_system", wB * wit / (med * 1e-3))}
             wide.reset()
             # Long horizon: the quadrotor at N = 100. The duals of 99 knots do not fit 256 registers, so layout D runs its second
             # plan (one wavefront per SIMD with all 512 registers; the kernel is specialised at run time by tinympc_jit.hip).
@@ -560,7 +587,8 @@ def main() -> int:
             htf = hB * hit * hp.flops_per_iteration() / (med * 1e-3) / 1e12
             out["long_horizon"] = {"workload": "quadrotor N=100, box constraints, %d instances x %d forced iterations" % (hB, hit),
                                    "iters_per_s": hB * hit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": htf, "fp64_frac": htf / PEAK_FP64_TFLOPS,
-                                   "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"]}
+                                   "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"],
+                                   **leg_counters("long_horizon", hB * hit / (med * 1e-3))}
             longh.reset()
             # Large systems (64 < nx+nu <= 128): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
             # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
@@ -580,12 +608,16 @@ def main() -> int:
             med = sorted(ms[1:])[1]
             ltf = lB * lit * lp.flops_per_iteration() / (med * 1e-3) / 1e12
             lgb = lB * lit * lp.bytes_per_iteration() / (med * 1e-3) / 1e9
+            lmeas = leg_counters("large_system", lB * lit / (med * 1e-3))
             out["large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (lnx, lnu, lN, lB, lit),
                                    "iters_per_s": lB * lit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": ltf, "fp64_frac": ltf / PEAK_FP64_TFLOPS,
-                                   "hbm_algorithmic_gbs": lgb, "hbm_algorithmic_frac": lgb / PEAK_HBM_GBS, "layout": big.launch_info()["layout"],
-                                   "hbm_note": "algorithmic = SURVEY.md section 8d streaming model; the kernel's measured traffic is 130.5 KB per instance and "
-                                               "iteration (profiles/r02_large_pmc.json), about 2/3 of the model",
-                                   "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)"}
+                                   "hbm_measured_gbs": (lmeas.get("measured") or {}).get("hbm_measured_gbs"),
+                                   "hbm_measured_frac": (lmeas.get("measured") or {}).get("hbm_measured_frac"),
+                                   "hbm_model_gbs": lgb, "layout": big.launch_info()["layout"],
+                                   "hbm_note": "hbm_measured_*: the kernel's PMC-measured traffic per instance and iteration (FETCH_SIZE x 2 + WRITE_SIZE) at "
+                                               "this run's rate; hbm_model_gbs: SURVEY.md section 8d's streaming model (9-11 accesses per element), of which "
+                                               "the kernel moves about 2/3",
+                                   "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)", **lmeas}
             big.reset()
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.

@@ -1,8 +1,9 @@
 #!/bin/bash
 # tools/gpu_profile.sh <tag> -- run ON THE GPU BOX (through gpurun) from the repo root:
 #   bench.py (the driver's command), then the same workload under rocprofv3: kernel trace + stats, and the HBM byte
-#   counters FETCH_SIZE / WRITE_SIZE in two separate --pmc passes (MI355X_MICROARCH.md: they do not fit one pass and
-#   --pmc must not be combined with other trace domains). Everything lands in gpurun_out/; afterwards
+#   counters FETCH_SIZE / WRITE_SIZE in two separate --pmc passes (MI355X_MICROARCH.md: they do not fit one pass; a --pmc pass
+#   carries --kernel-trace only -- never --sys-trace / --runtime-trace / the hip, hsa, memory-copy or marker domains, which
+#   gpurun refuses next to counters). Everything lands in gpurun_out/; afterwards
 #   `python tools/collect_profiles_db.py <tag> ...` copies the judged summaries into profiles/.
 set -eo pipefail
 TAG=${1:?tag}
