@@ -492,14 +492,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // the true state entering the chunk: X_w = Phi^S X_(w-1) + e_(w-1), X_1 = e_0
             double xin = 0.0;
             if (!bottom) {
-                // (all carries are requested at once: fetched one per step, every step of the recurrence would wait for its LDS read)
-                double ph[16], ee[WPG - 1];
+                // (requesting all carries at once, ahead of the recurrence, measured no faster and costs 14 VGPRs -- with them the
+                // rocket's all-in-registers plan spilled)
+                double ph[16];
                 load_pow(sPow + r, ph);
-                e_static_for<0, WPG - 1>([&](auto Q) { ee[Q.value] = sE[Q.value * 64 + lane]; });
-                xin = ee[0];
-                e_static_for<1, WPG - 1>([&](auto Q) {
-                    if (Q.value < wv) xin = Step::fwd_plain(xin, 0.0, ph, ee[Q.value]);
-                });
+                xin = sE[lane];
+#pragma unroll 1
+                for (int q = 1; q < wv; ++q) xin = Step::fwd_plain(xin, 0.0, ph, sE[q * 64 + lane]);
             }
             // ================= forward, pass 2: the real sweep (F1) with S1 + D1 + R1 fused in =================
             double pri = 0.0, dua = 0.0;
@@ -701,14 +700,11 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // the carry entering from above: c_w = e''_(w+1) + Psi^S c_(w+1), c of the last wavefront = 0
             double cin = 0.0;
             if (!top) {
-                double ps[16], ee[WPG - 1];
+                double ps[16];
                 load_pow(sPow + 256 + r, ps);
-                e_static_for<0, WPG - 1>([&](auto Q) { ee[Q.value] = sB[(Q.value + 1) * 64 + lane]; });  // e'' of wavefronts 1 .. WPG-1
-                cin = ee[WPG - 2];
-                e_static_for<0, WPG - 2>([&](auto I) {
-                    constexpr int q = WPG - 2 - I.value;  // WPG-2 .. 1
-                    if (q > wv) cin = Step::fwd_plain(cin, 0.0, ps, ee[q - 1]);
-                });
+                cin = sB[(WPG - 1) * 64 + lane];
+#pragma unroll 1
+                for (int q = WPG - 2; q > wv; --q) cin = Step::fwd_plain(cin, 0.0, ps, sB[q * 64 + lane]);
                 load_ops(sMb, m);
             }
             // pass 2: the real sweep; only d is kept

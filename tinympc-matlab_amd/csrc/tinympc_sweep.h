@@ -296,8 +296,11 @@ __device__ __forceinline__ void fair_share_priority(int it0, int simd_slot) {
     constexpr int EVERY = WORK >= 32 ? 1 : WORK >= 16 ? 2 : WORK >= 8 ? 4 : 8;
 #endif
     if ((it0 & (EVERY - 1)) != 0) return;  // (it0: wave-uniform iteration counter)
+#ifndef TINY_PRIO_HI
+#define TINY_PRIO_HI 3
+#endif
     const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> TINY_PRIO_SHIFT);
-    if ((slice ^ (unsigned)simd_slot) & 1u) __builtin_amdgcn_s_setprio(3);
+    if ((slice ^ (unsigned)simd_slot) & 1u) __builtin_amdgcn_s_setprio(TINY_PRIO_HI);
     else __builtin_amdgcn_s_setprio(0);
 }
 

@@ -52,6 +52,9 @@ def run():
     P = pkg.problems
     prob = P.quadrotor(50)
     batch, iters = 8192, 200
+    for a in sys.argv:
+        if a.startswith("--batch="):
+            batch = int(a.split("=")[1])
     s = pkg.TinyMPC()
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1)
     s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -131,7 +134,8 @@ def run():
                 "kernel duration - loop time = the launch edge",
         "launch_edge_ms": kernel_ms - last["loop_us_median"] * 1e-3,
     }
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_clock.json"), "w"), indent=1)
+    if batch == 8192 and "--no-save" not in sys.argv:
+        json.dump(out, open(os.path.join(ROOT, "profiles", "r03_clock.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
