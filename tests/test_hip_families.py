@@ -506,3 +506,70 @@ def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, m
         differs = differs or rel_err(o2.solution()[0], o.solution()[0]) > 1e-6
     assert differs, "the test problem does not exercise the order of the projections"
     s.reset()
+
+
+@pytest.mark.parametrize("case", ["rocket100_both", "rocket100_cones", "rocket100_linear", "rocket100_const_refs", "rocket100_overlap", "rocket44_both",
+                                  "rocket10_both", "quadrotor50_box", "quadrotor23_box", "cartpole20_box"])
+@pytest.mark.parametrize("batch", [1, 5])
+def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch, case, batch):
+    """Layout F (tinympc_solve_f.hip): one instance per workgroup, up to 32 chunks on the DPP rows of up to eight wavefronts, shape /
+    chunk plan / structure of the families compiled in. Three consecutive solves (cold, warm after convergence, warm with new
+    references' worth of x0) against the restatement: iteration counts, statuses and residuals exact, trajectories 1e-9 --
+    through the single-instance verbs (pinned-host x0 / solution / completion stamp) for batch 1, the batched verbs for 5; then the
+    handle continues on the latency kernel of round 1 (layout C) from the state layout F left behind.
+    Chunk plans: N=100 -> 25 chunks of 4 (last: 3) on 7 wavefronts; N=44 -> 22 chunks of 2 (last: 1); N=10 -> 5 chunks of 2 (last: 1) on
+    2 wavefronts; quadrotor N=50 -> 25 chunks of 2 (last: 1); N=23 -> 11 chunks of 2."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.setenv("TINYMPC_LAYOUT", "F")
+    P = pkg.problems
+    name, variant = case.split("_", 1)
+    if name.startswith("rocket"):
+        N = int(name[6:])
+        prob = P.rocket(N, with_linear=variant in ("both", "linear", "const_refs", "overlap"))
+        if variant == "linear":
+            prob.cones = {}
+        if variant == "const_refs":
+            prob.x_ref = np.repeat(prob.x_ref[:, :1], N, axis=1)
+        if variant == "overlap":
+            prob.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.2, 0.3], Acu=[0], qcu=[3], cu=[0.25])
+        settings = dict(max_iter=150, abs_pri_tol=2e-3, abs_dua_tol=1e-4)
+    elif name.startswith("quadrotor"):
+        prob = P.quadrotor(int(name[9:]))
+        settings = dict(max_iter=80, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    else:
+        prob = P.cartpole(int(name[8:]), True)
+        settings = dict(max_iter=100, abs_pri_tol=1e-4, abs_dua_tol=1e-4)
+    rng = np.random.default_rng(len(case) + batch)
+    nx = prob.nx
+    x0a = prob.x0[:, None] * rng.uniform(0.7, 1.1, (1, batch)) + 0.02 * rng.standard_normal((nx, batch))
+    s = make(pkg, prob, settings, batch=batch)
+    orc = [oracle(prob, settings) for _ in range(batch)]
+    for rnd, x0s in enumerate((x0a, x0a * 0.97, x0a * 1.04)):
+        if rnd == 2:
+            monkeypatch.setenv("TINYMPC_LAYOUT", "C")  # the same handle, the other latency kernel, the same persistent state
+        if batch == 1:
+            s.set_x0(x0s[:, 0])
+        else:
+            s.set_x0_batch(x0s)
+        s.solve()
+        assert s.launch_info()["layout"] == ("F" if rnd < 2 else "C"), s.jit_info()
+        if rnd == 0:
+            info = s.jit_info()
+            assert (info.startswith("compiled ") or info.startswith("disk-cache ")) and "layout=F" in info and "scratch=0" in info, info
+        if batch == 1:
+            one, st1 = s.get_solution(), s.get_stats()
+            sol = dict(states=one["states"][:, :, None], controls=one["controls"][:, :, None])
+            st = dict(iter=np.array([st1["iter"]]), status=np.array([st1["status"]]))
+        else:
+            sol, st = s.get_solution_batch(), s.get_stats_batch()
+        for b in range(batch):
+            orc[b].set_x0(x0s[:, b])
+            orc[b].solve()
+            assert st["iter"][b] == orc[b].stats()["iter"] and st["status"][b] == orc[b].stats()["status"], (rnd, b, st["iter"][b], orc[b].stats()["iter"])
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL, (rnd, b)
+            assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+        if batch > 1:
+            res = np.array([[o.stats()[k] for k in ("pri_x", "dua_x", "pri_u", "dua_u")] for o in orc]).T
+            assert rel_err(s.get_stats_batch()["residuals"], res) < 1e-6
+    s.reset()

@@ -68,6 +68,7 @@ constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
 constexpr int kLayoutEBatchMin = 260;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
                                         // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
+constexpr int kLayoutFBatchMax = 256;   // layout F (the specialised latency kernel: one instance per CU, two wavefronts per SIMD) up to here
 constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
                                        // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
 
@@ -125,6 +126,15 @@ struct tinympc_solver {
     bool e_ok = false;
     int e_chunk_len = 0, e_wpg = 0;
     size_t e_lds = 0;
+    // Layout F (tinympc_solve_f.hip): the latency kernel as a run-time specialisation (shape, chunk plan and the families'
+    // structure compiled in); decided per launch like layout E
+    std::string f_sig;
+    bool f_ok = false;
+    FamilyStructure f_fs;
+    int f_chunk_len = 0, f_chunks = 0, f_wpg = 0;
+    size_t f_lds = 0;
+    double *dctab_f = nullptr;   // Phi^(S..4S) | Psi^(S..4S) for layout F's chunk length
+    int dctab_f_len = 0;
     double *dclock = nullptr;    // (diagnostic build TINY_CLOCK_STAMP only) per-wavefront clock stamps of the last launch
     double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
     int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)
@@ -180,6 +190,7 @@ struct tinympc_solver {
         return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
     }
     bool use_layout_e() const { return e_ok && !st.adaptive_rho && !use_layout_d(); }
+    bool use_layout_f() const { return f_ok && !st.adaptive_rho && !use_layout_d() && !use_layout_e(); }
     bool families_active() const {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
@@ -282,7 +293,8 @@ int refresh_derived(tinympc_solver *s) {
             c.ops = s->dops; c.out = s->dctab;
             HIP_TRY(launch_build_chunk_tables(c, s->stream));
         }
-        s->dctab_e_len = 0;  // (layout E's carry matrices are rebuilt on demand, below)
+        s->dctab_e_len = 0;  // (layout E's and F's carry matrices are rebuilt on demand, below)
+        s->dctab_f_len = 0;
         s->ops_dirty = false;
         s->tables_dirty = true;
     }
@@ -292,6 +304,13 @@ int refresh_derived(tinympc_solver *s) {
         c.ops = s->dops; c.out = s->dctab_e;
         HIP_TRY(launch_build_chunk_tables(c, s->stream));
         s->dctab_e_len = s->e_chunk_len;
+    }
+    if (s->f_ok && s->dctab_f && s->dctab_f_len != s->f_chunk_len) {  // powers S .. 4S for layout F's chunk length
+        ChunkTableParams c{};
+        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->f_chunk_len; c.Lc = 4;
+        c.ops = s->dops; c.out = s->dctab_f;
+        HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        s->dctab_f_len = s->f_chunk_len;
     }
     if (s->tables_dirty) {
         TableParams p{};
@@ -481,14 +500,46 @@ int decide_layout_e(tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+// Layout F for what the latency kernel (layout C) serves: single solves and small batches. The kernel is specialised on the
+// shape, the kind of the tables and the structure of the families, so it is asked whenever one of them changed (seconds the
+// first time; cached inside tinympc_jit.hip). TINYMPC_LAYOUT=F forces it at any batch size (tests), any other value excludes it.
+int decide_layout_f(tinympc_solver *s) {
+    const bool fam = s->families_active();
+    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && !s->session_active && s->N >= 6;
+    bool want = possible && !s->use_layout_d() && !s->use_layout_e() && s->batch <= kLayoutFBatchMax && (fam ? s->fam_c : s->layout_c);
+    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
+    if (!want) {
+        s->f_ok = false;
+        s->f_sig.clear();
+        return TINYMPC_OK;
+    }
+    const FamilyStructure fs = fam ? family_structure(s) : FamilyStructure();
+    std::string sig = s->tables_const() ? "ct|" : "var|";
+    for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
+    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
+    if (sig == s->f_sig) return TINYMPC_OK;
+    s->f_sig = sig;
+    s->f_fs = fs;
+    s->f_ok = solve_f_supported(s->nx, s->nu, s->N, s->tables_const(), fam, fs) &&
+              solve_f_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->f_chunk_len, &s->f_chunks, &s->f_wpg, &s->f_lds);
+    if (s->f_ok && !s->dctab_f) {
+        int rc = dalloc(s, &s->dctab_f, chunk_table_doubles(s->nx, 4));
+        if (rc) return rc;
+    }
+    return TINYMPC_OK;
+}
+
 int launch(tinympc_solver *s, bool timed) {
     int rc;
     s->flag_pending = false;
     decide_layout_d_variants(s);
     if ((rc = decide_layout_e(s))) return rc;
+    if ((rc = decide_layout_f(s))) return rc;
     const bool fam = s->families_active();
     const bool adaptive = s->st.adaptive_rho != 0;
-    if (s->refs_on_host && adaptive) {  // k_build_adapt reads the device copy before the solve kernel starts
+    // k_build_adapt reads the device copy of the references before the solve kernel starts; layout F has no in-kernel staging of
+    // references left in pinned host memory (layout C does): bring the device copies and the tables up to date the ordinary way
+    if (s->refs_on_host && (adaptive || s->use_layout_f())) {
         if ((rc = flush_host_refs(s))) return rc;
     }
     if ((rc = refresh_derived(s))) return rc;
@@ -558,6 +609,11 @@ int launch(tinympc_solver *s, bool timed) {
     } else if (fam && s->use_layout_d()) {
         p.families = 1;
         HIP_TRY(launch_solve_jit(p, s->W, s->stream));
+    } else if (s->use_layout_f()) {  // the specialised latency kernel (families or box path alike)
+        p.families = fam ? 1 : 0;
+        p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
+        arm_completion_flag(s, p);
+        HIP_TRY(launch_solve_f(p, s->f_fs, s->stream));
     } else if (fam && s->use_layout_e()) {
         p.families = 1;
         p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
@@ -1074,6 +1130,7 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
     decide_layout_d_variants(s);
     if ((rc = decide_layout_e(s))) return rc;
+    if ((rc = decide_layout_f(s))) return rc;
     if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
@@ -1616,11 +1673,13 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
     if (rc) return rc;
     if (lanes_per_instance) *lanes_per_instance = s->W;
     if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups && s->use_layout_e()) *workgroups = s->groups;
+    if (workgroups && s->use_layout_f()) *workgroups = s->batch;
+    else if (workgroups && s->use_layout_e()) *workgroups = s->groups;
     else if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active(), s->st.adaptive_rho != 0) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
     if (lds_bytes) {
         size_t l = s->layout_c ? s->lds_bytes_c : s->lds_bytes;
         if (s->layout_m) l = 0;  // (static LDS: see the kernel)
+        else if (s->use_layout_f()) l = s->f_lds;
         else if (s->use_layout_e()) l = s->e_lds;
         else if (s->use_layout_d())
             l = (s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit))
@@ -1637,6 +1696,7 @@ int tinympc_get_layout(tinympc_solver *s) {
     if (s->layout_m) return 'M';
     if (s->use_layout_d()) return 'D';
     if (s->use_layout_e()) return 'E';
+    if (s->use_layout_f()) return 'F';
     // the families and adaptive rho have kernels of their own on layout A's plan (the families also in the latency kernel)
     if (s->families_active()) return (s->fam_c && family_structure(s).nround <= 1) ? 'C' : 'A';
     if (s->st.adaptive_rho) return 'A';
@@ -1648,7 +1708,8 @@ int tinympc_prepare(tinympc_solver *s) {
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
     decide_layout_d_variants(s);
-    return decide_layout_e(s);
+    if ((rc = decide_layout_e(s))) return rc;
+    return decide_layout_f(s);
 }
 
 int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
@@ -1658,6 +1719,7 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
     buf[0] = '\0';
     const bool fam = s->families_active(), adaptive = s->st.adaptive_rho != 0;
     if (s->layout_m) snprintf(buf, (size_t)len, "compiled-in layout=M");
+    else if (!s->f_sig.empty() && !adaptive && !s->use_layout_d() && !s->use_layout_e()) solve_f_describe(s->nx, s->nu, s->N, s->tables_const(), fam, s->f_fs, buf, (size_t)len);
     else if (!s->e_sig.empty() && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), fam, s->fs, buf, (size_t)len);
     else if (s->use_layout_d() && !(s->d_jit || fam || adaptive || (!s->tables_const() && s->d_varying_jit))) snprintf(buf, (size_t)len, "compiled-in layout=D");
     else if (s->layout_d || s->d_jit || s->d_jit_asked) {

@@ -170,6 +170,14 @@ struct AdaptTableParams {
     double *out;
 };
 
+// ---- layout F (tinympc_solve_f.hip): one instance per workgroup, up to 4 * wpg chunks of S slots on the DPP rows of `wpg`
+// wavefronts. LDS per workgroup, in doubles: operators | tables (!ct) | linear rows (fam) | carry matrices [2][4][16][16] |
+// wavefront totals [2][wpg][16] | flags [16] | residual partials [4 wpg][4] | per wavefront d[S * 4 nu]
+__host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg, int S, bool fam, int nl) {
+    return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg +
+                             (size_t)wpg * ((S * 4 * nu + 1) & ~1));
+}
+
 // Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
 //   role[W]   0 = row in no cone, 1 = norm member, 2 = the cone's last ("t") row
 //   mu[W]     slope of the row's cone
@@ -231,6 +239,11 @@ bool solve_e_supported(int nx, int nu, int N, bool const_tables, bool families, 
 hipError_t launch_solve_e(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
 void solve_e_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
 void solve_jit_describe(int W, int nx, int nu, int N, bool const_tables, bool families, bool adaptive, char *buf, size_t len);
+// Layout F (tinympc_solve_f.hip, run-time specialised only): the latency kernel with compile-time shape and structure
+bool solve_f_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *chunks, int *wpg, size_t *lds_bytes);
+bool solve_f_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
+hipError_t launch_solve_f(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
+void solve_f_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);

@@ -1,0 +1,458 @@
+// tinympc_solve_f.hip -- layout F: the LATENCY kernel as a run-time specialisation. One MPC instance per workgroup, the horizon
+// cut into up to 32 chunks that the DPP rows of up to eight wavefronts sweep concurrently -- layout C's idea (tinympc_solve_c.hip:
+// both sweeps are linear time-invariant recurrences, so a chunk can be swept from a zero incoming state, the true incoming states
+// come from a carry scan, and a second pass IS the sequential sweep) with layout E's means:
+//   * the shape (nx, nu, N), the chunk plan and the STRUCTURE of the cone / linear families are compile-time constants
+//     (tinympc_jit.hip), so a sweep step is layout D's single asm block with exactly nx+nu columns, and the families' cross-lane
+//     sums are a handful of DPP instructions under an EXEC mask instead of three masked 12-column mat-vecs and their 72 mask
+//     registers (tinympc_solve_e_common.h);
+//   * 150-odd VGPRs instead of 418, so the workgroup's wavefronts sit TWO per SIMD and fill each other's barrier and LDS waits,
+//     where layout C's lone wavefront per SIMD issues VALU 55 % of the time (profiles/r03_rocket_instance_pmc.json);
+//   * chunks of 3-4 slots instead of 7-8 (32 rows instead of 16): half the serial work per sweep;
+//   * no linear-cost exchange between neighbours (layout E's cut: a chunk's backward chain starts from the q~ of its OWN last state
+//     slot and leaves out the q of its first knot, which the chunk below adds from its own registers), the termination ballots ride
+//     on the backward scan's barrier: two barriers per ADMM iteration instead of three.
+// Chunk c = 4 w + j is DPP row j of wavefront w and owns slots [c S, (c+1) S); the last chunk in use owns what is left, rows
+// beyond it idle (their steps sit behind lane predicates -- whole DPP rows, so no DPP read crosses the mask).
+// Carry scan per sweep (as in layout C): inside a wavefront the four rows' prefix by cross-row swaps (P^S, P^2S), the
+// wavefronts' totals through LDS behind ONE barrier and a Horner recurrence with P^4S, a last mat-vec (P^jS) per row.
+// Given exact carries pass 2 IS the sequential sweep; results differ from the other layouts through the rounding of the carries
+// (~1e-14 relative), iteration counts match the restatement in every test. Same persistent HBM state as every other kernel;
+// single-instance handles' pinned-host paths (x0 in, solution / statistics / completion stamp out) as in layout C. No session,
+// no adaptive rho.
+#include <type_traits>
+
+#include "tinympc_device.h"
+#include "tinympc_sweep.h"
+
+#ifndef TINY_JIT  // build-time instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
+#define TINY_CHAIN_NOP 1
+#define TINY_JIT_NX 6
+#define TINY_JIT_NU 3
+#define TINY_JIT_N 100
+#define TINY_JIT_CT 0
+#define TINY_JIT_FAM 1
+#define TINY_JIT_F_WPG 7
+#define TINY_JIT_F_S 4
+#define TINY_JIT_E_NROUND 1
+#define TINY_JIT_E_NCONE 2
+#define TINY_JIT_E_CONES {0, 0, 2}, {0, 6, 8}
+#define TINY_JIT_E_NLX 1
+#define TINY_JIT_E_NLU 0
+#endif
+
+namespace tinympc {
+template <int NX, int NU>
+struct DStep;  // tinympc_solve_d_chain.h
+}  // namespace tinympc
+#define D_NX TINY_JIT_NX
+#define D_NU TINY_JIT_NU
+#include "tinympc_solve_d_chain.h"
+#include "tinympc_solve_e_common.h"
+
+namespace tinympc {
+
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM>
+__device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double *smem) {
+    constexpr int W = 16, NXU = NX + NU, NS = N - 1, DS = 4 * NU;
+    constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
+    constexpr int KS = NX <= 8 ? 8 : NX <= 12 ? 12 : 16;    // row stride of the carry matrices (chunk_ks)
+    constexpr int TOFF = (N + 2) * W;
+    constexpr int NCH = (NS + S - 1) / S;                    // chunks in use
+    constexpr int S_LAST = NS - (NCH - 1) * S;               // slots of the last chunk in use, 1 .. S
+    static_assert(S >= 2 && NCH >= 2 && NCH <= 4 * WPG && NCH > 4 * (WPG - 1), "layout F: chunk plan");
+    using Step = DStep<NX, NU>;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane >> 4, r = lane & 15;  // j: DPP row = chunk within the wavefront
+    const int c = 4 * wv + j;                // chunk
+    const long inst = blockIdx.x;
+    const bool is_x = r < NX;
+    const bool is_u = (r >= NX) && (r < NXU);
+    const bool row_ok = r < NXU;
+    const int koff = is_x ? 1 : 0;           // slot s = knot s+1 on state lanes, knot s on input lanes
+    const bool topc = c == NCH - 1, bottomc = c == 0;
+    const int nsl = c < NCH - 1 ? S : (topc ? S_LAST : 0);  // real slots of this row
+    const int s0 = c * S;
+
+    // ---- LDS
+    double *sOps = smem;                                    // [2][16 k][16 r]
+    double *sT = sOps + 512;                                // tables (!CT)
+    double *sLin = sT + (CT ? 0 : 3 * (N + 2) * 16 + 16);   // [E_NL][3][16] (FAM)
+    double *sPow = sLin + (FAM ? 3 * E_NL * 16 : 0);        // [2 Phi|Psi][4 levels: powers S, 2S, 3S, 4S][16 k][16 r]
+    double *sY = sPow + 2 * 4 * 256;                        // [2][WPG][16] the wavefronts' totals of a scan, double-buffered
+    int *sFlag = reinterpret_cast<int *>(sY + 2 * WPG * 16);  // [2][WPG] "every lane below tolerance" per wavefront (16 doubles)
+    double *sRes = sY + 2 * WPG * 16 + 16;                  // [4 WPG][4] residual maxima per chunk
+    double *sD = sRes + 4 * WPG * 4 + (size_t)wv * ((S * DS + 1) & ~1);  // per wavefront: d[S][4 rows x nu]
+
+    for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
+        const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
+        sOps[i] = (k < KT) ? p.ops[(size_t)which * W * KT + (size_t)rr * KT + k] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 2 * 4 * 256; i += 64 * WPG) {
+        const int mat = i >> 8, k = (i >> 4) & 15, rr = i & 15;  // mat = which * 4 + level, as k_build_chunk_tables lays them out
+        sPow[i] = (k < NX && rr < NX) ? p.ctab[(size_t)mat * W * KS + (size_t)rr * KS + k] : 0.0;
+    }
+    if constexpr (!CT)
+        for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
+    if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, 64 * WPG);
+
+    // canonical HBM layout shared with the other kernels (instance = lane group inst % 4 of wave group inst / 4)
+    const long wg = inst >> 2;
+    const int jj = (int)(inst & 3);
+    const size_t vbase = ((size_t)wg * v_rows(N) + V_PAD) * 64 + jj * 16 + r;
+    double *const gG = p.G + (size_t)wg * (N + 1) * 64 + jj * 16 + r;  // row kn = knot kn
+    double *const gV = p.V + vbase;
+    double *const gD = p.D + (size_t)wg * (size_t)(NS * DS) + jj * NU + (is_u ? r - NX : 0);
+    const int dIdx = j * NU + (is_u ? r - NX : 0);
+
+    // ---- this lane's elements, in registers for the whole solve: slot i <-> step s0 + i
+    double G[S], V[S], Vp[S], GC[FAM ? S : 1], GL[FAM ? S : 1], LX[FAM ? S : 1];
+    e_static_for<0, S>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const bool on = (i < nsl) && row_ok;
+        const size_t kn = on ? (size_t)(s0 + i + koff) : 0;
+        G[i] = on ? gG[kn * 64] : 0.0;
+        V[i] = on ? gV[kn * 64] : 0.0;
+        Vp[i] = V[i];
+        if constexpr (FAM) {
+            GC[i] = on ? (p.GC + vbase)[kn * 64] : 0.0;
+            GL[i] = on ? (p.GL + vbase)[kn * 64] : 0.0;
+            LX[i] = 0.0;
+        }
+        if ((i < nsl) && is_u) sD[i * DS + dIdx] = gD[(size_t)(s0 + i) * DS];
+    });
+    // knot 0 of the state rows: chunk 0, state lanes
+    const bool k0 = bottomc && is_x;
+    double G0 = k0 ? gG[0] : 0.0, V0 = k0 ? gV[0] : 0.0, V0p = V0;
+    double GC0 = (FAM && k0) ? (p.GC + vbase)[0] : 0.0, GL0 = (FAM && k0) ? (p.GL + vbase)[0] : 0.0;
+    const double x0v = k0 ? p.x0[inst * NX + r] : 0.0;
+    if (p.x0_mirror && k0) p.x0_mirror[inst * NX + r] = x0v;  // x0 came from pinned host memory: keep the device copy current
+    __syncthreads();  // (the only barrier that also waits for global loads)
+
+    EFamilies<NX, NU> fam_eval;
+    if constexpr (FAM) fam_eval.init(p.fam, KT, sLin, r, p.rho);
+
+    const double cf = p.ops[(size_t)2 * W * KT + r];
+    const double cb = p.ops[(size_t)2 * W * KT + W + r];
+    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    const double nrho = -p.rho;
+    const double rhom = is_x ? nrho : 0.0;
+    const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
+    const double *const sTl = sT + (size_t)(s0 + koff) * W + r;  // (!CT) row of local slot i: sTl[(i + 1) * W]  (idle rows: never read)
+    const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
+    const unsigned aD = e_lds_addr(sD + dIdx);
+    const int ct = p.check_termination;
+
+    auto load_ops = [&](const double *src, double (&m)[16]) {
+        e_static_for<0, 16>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * 16]; });
+    };
+    auto load_pow = [&](const double *mat, double (&m)[KS]) {  // a carry matrix row (state lanes; zero elsewhere)
+        e_static_for<0, KS>([&](auto K) { m[K.value] = (K.value < NX && is_x) ? mat[K.value * 16 + r] : 0.0; });
+    };
+    auto lr_of = [&](auto I) -> double {  // linref of local slot I (+ the families' term)
+        double base;
+        if constexpr (CT) base = lr_c;
+        else base = (decltype(I)::value < nsl) ? sTl[2 * TOFF + (I.value + 1) * W] : 0.0;
+        if constexpr (FAM) base += LX[I.value];
+        return base;
+    };
+
+    // ---- carry scan over the chunks (layout C's, for up to eight wavefronts). In: the chunk's pass-1 end value (state lanes; 0
+    // elsewhere and in idle rows). Out: the true value ENTERING the chunk from its neighbour c + dir,
+    //   I_c = sum_{q>=1} Pm^((q-1) S) end_(c + q dir).
+    //   A  inside the wavefront, rows only (cross-row swaps):  t_j = e_j + P1 e_(j-1);  L_j = t_j + P2 t_(j-2)
+    //   B  the wavefront's total goes to LDS; ONE barrier; Horner over the wavefronts before it with P4
+    //   C  I_j = L_(j-1) + P_j Cin for the rows behind the first; the first row's incoming value is Cin itself.
+    int cur = 0;
+    auto rows_shift1 = [&](int dir, double x) -> double {  // row j <- row j + dir (the wavefront's edge row <- 0)
+        double e, o, lo2, hi2;
+        cross_row_pair<1>(x, e, o);  // e = [r0 r0 r2 r2], o = [r1 r1 r3 r3]
+        if (dir < 0) {
+            cross_row_pair<0>(o, lo2, hi2);  // lo2 = [r1 r1 r1 r1]
+            return j == 0 ? 0.0 : (j == 2 ? lo2 : e);
+        } else {
+            cross_row_pair<0>(e, lo2, hi2);  // hi2 = [r2 r2 r2 r2]
+            return j == 3 ? 0.0 : (j == 1 ? hi2 : o);
+        }
+    };
+    auto rows_shift2 = [&](int dir, double x) -> double {  // row j <- row j + 2 dir
+        double lo2, hi2;
+        cross_row_pair<0>(x, lo2, hi2);  // lo2 = [r0 r1 r0 r1], hi2 = [r2 r3 r2 r3]
+        return dir < 0 ? (j >= 2 ? lo2 : 0.0) : (j < 2 ? hi2 : 0.0);
+    };
+    auto carry_scan = [&](int dir, const double *Pm, double end_val) -> double {
+        const int jr = dir < 0 ? j : 3 - j;  // rows counted from the side the carry comes from
+        double L;
+        {
+            double m1[KS], m2[KS];
+            load_pow(Pm, m1);
+            load_pow(Pm + 256, m2);
+            const double t = end_val + group_matvec<W, KS>(m1, rows_shift1(dir, end_val), 0.0);
+            L = t + group_matvec<W, KS>(m2, rows_shift2(dir, t), 0.0);
+        }
+        double m4[KS], mj[KS];
+        load_pow(Pm + 3 * 256, m4);
+        load_pow(Pm + (size_t)(jr >= 1 ? jr - 1 : 0) * 256, mj);
+        if (jr == 3 && is_x) sY[(cur * WPG + wv) * 16 + r] = L;
+        const double Lprev = rows_shift1(dir, L);
+        e_barrier();
+        // totals of the wavefronts the carry comes from, nearest last: cin = T_far; cin = T_next + P4 cin; ...
+        double tv[WPG - 1];
+        e_static_for<0, WPG - 1>([&](auto Q) {
+            const int v = dir < 0 ? Q.value : WPG - 1 - Q.value;  // forward: 0, 1, ..; backward: WPG-1, WPG-2, ..
+            tv[Q.value] = is_x ? sY[(cur * WPG + v) * 16 + r] : 0.0;
+        });
+        const int nbefore = dir < 0 ? wv : WPG - 1 - wv;  // wavefronts on the side the carry comes from (uniform)
+        double cin = nbefore > 0 ? tv[0] : 0.0;
+        e_static_for<1, WPG - 1>([&](auto Q) {
+            if (Q.value < nbefore) cin = tv[Q.value] + group_matvec<W, KS>(m4, cin, 0.0);
+        });
+        const double far = Lprev + group_matvec<W, KS>(mj, cin, 0.0);
+        cur ^= 1;
+        return is_x ? (jr == 0 ? cin : far) : 0.0;
+    };
+
+    int it_done = 0, status = 11;  // TINY_UNSOLVED (admm.cpp:114)
+    bool res_valid = false, converged = false;
+    double snap_pri = 0.0, snap_dua = 0.0;
+
+    const int max_iter = p.max_iter;
+    for (int it = 0; it < max_iter; ++it) {  // admm.cpp:129
+        const int it0 = __builtin_amdgcn_readfirstlane(it);
+        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && (((it0 + 1) % ct) == 0))) != 0;  // admm.cpp:91
+        double m[16];
+        load_ops(sMf, m);
+        // ================= forward, pass 1: the chunk's end state from a zero incoming state (chunk 0: from x_0) =================
+        double xt = bottomc ? x0v : 0.0;
+        e_static_for<0, S>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (i < nsl) {
+                const double di = sD[i * DS + dIdx];
+                xt = Step::fwd_plain(xt, di, m, cf);
+            }
+        });
+        const double xin = carry_scan(-1, sPow, (is_x && c < NCH) ? xt : 0.0);
+        // ================= forward, pass 2: the real sweep (F1) with S1 + D1 + R1 fused in =================
+        double pri = 0.0, dua = 0.0;
+        if (wv == 0) {  // knot 0, state lanes of chunk 0: x_0 is given (tiny_set_x0), no mat-vec
+            const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
+            const double s = x0v + G0;
+            const double snew = fmin(hi0, fmax(lo0, s));
+            if (k0) {
+                V0p = V0;
+                G0 = s - snew;
+                pri = fabs(x0v - snew);
+                dua = fabs(V0 - snew);
+                V0 = snew;
+            }
+            if constexpr (FAM) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
+                double gcn, gln;
+                (void)fam_eval.eval(x0v, GC0, GL0, gcn, gln);
+                if (k0) {
+                    GC0 = gcn;
+                    GL0 = gln;
+                }
+            }
+        }
+        double xcur = bottomc ? x0v : xin;
+        e_static_for<0, S>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            if (q < nsl) {
+                const double dq = sD[q * DS + dIdx];
+                double loq = lo_c, hiq = hi_c;
+                if constexpr (!CT) {
+                    loq = sTl[(q + 1) * W];
+                    hiq = sTl[TOFF + (q + 1) * W];
+                }
+                Vp[q] = V[q];
+                xcur = Step::fwd_reg(xcur, dq, m, cf, loq, hiq, G[q], V[q], pri, dua);
+                if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                    double gcn, gln;
+                    LX[q] = fam_eval.eval(xcur, GC[q], GL[q], gcn, gln);
+                    GC[q] = gcn;
+                    GL[q] = gln;
+                }
+            }
+        });
+        it_done = it0 + 1;  // admm.cpp:143
+
+        // ---- R1 (admm.cpp:93-101): one ballot per wavefront; the flags cross with the backward scan's barrier
+        if (check) {
+            snap_pri = pri;
+            snap_dua = dua;
+            res_valid = true;
+            const bool below = (pri < p.abs_pri_tol) && (dua * p.rho < p.abs_dua_tol);
+            const bool wave_ok = __ballot(!below) == 0ull;
+            if (lane == 0) sFlag[(it0 & 1) * WPG + wv] = wave_ok ? 1 : 0;
+        }
+
+        // ================= backward (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G =================
+        // chain of a chunk of n slots: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
+        // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
+        // which the chunk below owns.
+        load_ops(sMb, m);
+        auto bwd_chain = [&](double cin, auto STORE) -> double {
+            constexpr bool store = decltype(STORE)::value;
+            double px = 0.0, rcur = 0.0, rnext = 0.0, acc = cb;
+            // head of the chain, from the chunk's last slot T: P and r_T, the accumulator start of step T, r_(T-1)
+            auto head = [&](auto T, bool terminal) {
+                constexpr int tt = decltype(T)::value;
+                const double lr1 = lr_of(T);
+                double lrT = lr1;
+                if (terminal) {  // the last chunk: p_{N-1} (admm.cpp:81-82)
+                    double pT = pnref;
+                    if constexpr (FAM) pT += LX[tt];
+                    lrT = is_x ? pT : lr1;
+                }
+                px = nrho * (V[tt] - G[tt]) + lrT;
+                if constexpr (tt >= 1) {
+                    const double lr2 = lr_of(std::integral_constant<int, tt - 1>{});
+                    const double t2 = V[tt - 1] - G[tt - 1];
+                    acc = rhom * t2 + (is_x ? lr2 + cb : cb);
+                    rnext = nrho * t2 + lr2;
+                } else {
+                    acc = cb;  // (a one-slot chunk: its only step is the chunk's first, which takes no q)
+                }
+                rcur = px;                  // (input lanes: r_T)
+                px = is_x ? px + cin : px;  // (state lanes: + the carry entering from above)
+            };
+            auto block = [&](auto Sl) {
+                constexpr int s = decltype(Sl)::value;
+                constexpr int s2 = s >= 2 ? s - 2 : 0;  // slot feeding the tail
+                const double lr2 = lr_of(std::integral_constant<int, s2>{});
+                const double lrmc2 = (s >= 2) ? (is_x ? lr2 + cb : cb) : cb;
+                const double rh = (s >= 2) ? rhom : 0.0;
+                double a = acc, an, rn;
+                Step::bwd(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
+                if constexpr (store)
+                    if (is_u) sD[s * DS + dIdx] = a;  // d_s
+                px = a;
+                rcur = rnext;
+                rnext = rn;
+                acc = an;
+            };
+            if constexpr (S_LAST == S) {
+                if (nsl > 0) head(std::integral_constant<int, S - 1>{}, topc);
+            } else {
+                if (topc) {
+                    head(std::integral_constant<int, S_LAST - 1>{}, true);
+                } else if (nsl > 0) {  // the S - S_LAST steps only a full chunk has, then the common part
+                    head(std::integral_constant<int, S - 1>{}, false);
+                    e_static_for<0, S - S_LAST>([&](auto I) { block(std::integral_constant<int, S - 1 - I.value>{}); });
+                }
+            }
+            double a = 0.0;
+            if (nsl > 0) {
+                e_static_for<0, S_LAST - 1>([&](auto I) { block(std::integral_constant<int, S_LAST - 1 - I.value>{}); });  // S_LAST-1 .. 1
+                a = acc;
+                Step::bwd_last(a, px, rcur, m);
+                if constexpr (store)
+                    if (is_u) sD[dIdx] = a;  // d of the chunk's first slot
+            }
+            return a;
+        };
+        // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
+        const double e2 = bwd_chain(0.0, std::false_type{});
+        const double pin = carry_scan(+1, sPow + 4 * 256, (is_x && c < NCH) ? e2 : 0.0);
+        if (check) {  // (behind the scan's barrier)
+            int all = 1;
+#pragma unroll
+            for (int q = 0; q < WPG; ++q) all &= sFlag[(it0 & 1) * WPG + q];
+            if (all != 0) {  // uniform over the workgroup: one instance. TINY_SOLVED: the solve returns BEFORE the backward pass and
+                status = 1;  // before v <- vnew (admm.cpp:181-197)
+                converged = true;
+                break;
+            }
+        }
+        // pass 2: the real sweep, from the true p entering the chunk; only d is kept
+        (void)bwd_chain(is_x ? pin : 0.0, std::true_type{});
+    }
+
+    // ---- the four residual norms of the last check: rows, then chunks through LDS
+    const double gpx = group_max<W>(is_x ? snap_pri : 0.0), gpu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double gdx = group_max<W>(is_x ? snap_dua : 0.0), gdu = group_max<W>(is_u ? snap_dua : 0.0);
+    e_barrier();
+    if (r < 4) sRes[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gdx : (r == 2) ? gpu : gdu;
+    e_barrier();
+
+    // ---- write-back: solution (device + pinned host), the ADMM state for the next launch. A converged solve returned before
+    // v <- vnew: its canonical slack is the previous iterate.
+    if (max_iter > 0) {
+        e_static_for<0, S>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if ((i < nsl) && row_ok) {
+                const size_t k = (size_t)(s0 + i), kn = k + koff;
+                gG[kn * 64] = G[i];
+                gV[kn * 64] = converged ? Vp[i] : V[i];
+                if constexpr (FAM) {
+                    (p.GC + vbase)[kn * 64] = GC[i];
+                    (p.GL + vbase)[kn * 64] = GL[i];
+                }
+                if (is_x) {
+                    p.sol_x[((size_t)inst * N + kn) * NX + r] = V[i];
+                    if (p.host_sol) p.host_sol[kn * NX + r] = V[i];
+                } else {
+                    p.sol_u[((size_t)inst * NS + kn) * NU + (r - NX)] = V[i];
+                    if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * NU + (r - NX)] = V[i];  // first controls straight to the host
+                    if (p.host_sol) p.host_sol[(size_t)N * NX + kn * NU + (r - NX)] = V[i];
+                    gD[k * DS] = sD[i * DS + dIdx];
+                }
+            }
+        });
+        if (k0) {
+            gG[0] = G0;
+            gV[0] = converged ? V0p : V0;
+            if constexpr (FAM) {
+                (p.GC + vbase)[0] = GC0;
+                (p.GL + vbase)[0] = GL0;
+            }
+            p.sol_x[(size_t)inst * N * NX + r] = V0;
+            if (p.host_sol) p.host_sol[r] = V0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        double res[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) res[k] = fmax(res[k], sRes[q * 4 + k]);
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            p.dstats[inst * 4 + 0] = res[0];
+            p.dstats[inst * 4 + 1] = res[1] * p.rho;
+            p.dstats[inst * 4 + 2] = res[2];
+            p.dstats[inst * 4 + 3] = res[3] * p.rho;
+        }
+        if (p.host_sol) {
+            double *hs = p.host_sol + (size_t)N * NX + (size_t)NS * NU;
+            hs[4] = (double)it_done;
+            hs[5] = (double)status;
+            if (res_valid) {
+                hs[0] = res[0];
+                hs[1] = res[1] * p.rho;
+                hs[2] = res[2];
+                hs[3] = res[3] * p.rho;
+            }
+        }
+    }
+    if (p.host_sol && p.host_seq != 0.0) {  // (uniform) everything above is in pinned memory: raise the completion stamp
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(p.host_sol + (size_t)N * NX + (size_t)NS * NU + 6, p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace tinympc
+
+// (two wavefronts per SIMD wherever the workgroup has more than four)
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, 2)))
+tinympc_jit_solve(const tinympc::SolveParams p) {
+    constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
+    constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL);
+    static_assert(bytes <= 160 * 1024, "layout F: the workgroup's LDS plan exceeds a CU");
+    __shared__ __attribute__((aligned(16))) double smem_f[bytes / sizeof(double)];
+    tinympc::k_admm_solve_f_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ>(p, smem_f);
+}

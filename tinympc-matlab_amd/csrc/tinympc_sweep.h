@@ -105,11 +105,11 @@ template <int B0>
 __device__ __forceinline__ void dpp_block4(double &a, double w, const double *m4, bool first) {
     if (first)
         asm("s_nop 1\n\t" TINY_FMQ(0) TINY_FMQ(1) TINY_FMQ(2) TINY_FMQ(3)
-            : [a] "+v"(a)
+            : [a] "+&v"(a)
             : [w] "v"(w), [m0] "v"(m4[0]), [m1] "v"(m4[1]), [m2] "v"(m4[2]), [m3] "v"(m4[3]), [b0] "n"(B0), [b1] "n"(B0 + 1), [b2] "n"(B0 + 2), [b3] "n"(B0 + 3));
     else
         asm(TINY_FMQ(0) TINY_FMQ(1) TINY_FMQ(2) TINY_FMQ(3)
-            : [a] "+v"(a)
+            : [a] "+&v"(a)
             : [w] "v"(w), [m0] "v"(m4[0]), [m1] "v"(m4[1]), [m2] "v"(m4[2]), [m3] "v"(m4[3]), [b0] "n"(B0), [b1] "n"(B0 + 1), [b2] "n"(B0 + 2), [b3] "n"(B0 + 3));
 }
 template <int NCOLS>
@@ -151,6 +151,9 @@ __device__ __forceinline__ void matvec_accumulate(const double (&m)[KT], double 
 // issue-bound, not latency-bound, so extra partial sums only add moves and adds.
 // Hazard: a VALU-written VGPR read through DPP needs 2 wait states, which hipcc does not insert
 // inside inline asm -> `s_nop 1` opens the chain (w was just produced by a v_cndmask).
+// The accumulator is an early-clobber operand ("+&v"): with plain "+v" the register allocator may give `a` and `w` ONE
+// register when both hold the same value at the call (e.g. a mat-vec of a constant zero vector onto a zero start), and the
+// chain would then overwrite its own operand (found by the ISA lint in layout F's carry recurrence).
 // The chain is emitted as blocks of FOUR instructions, not volatile: the scheduler then drops the step's other
 // work (LDS / global accesses, address arithmetic, selects) into the gaps between the blocks, where it issues in the
 // shadow of the dependent FP64 chain instead of after it -- 4.79 -> 4.29 ms per launch on layout B (8,192 quadrotor
@@ -173,10 +176,10 @@ __device__ __forceinline__ double group_matvec(const double (&m)[KT], double w, 
     if constexpr (W == 16) {
         static_assert(KT == 8 || KT == 12 || KT == 16, "W=16 supports KT 8, 12, 16");
         double a = c;
-        asm("s_nop 1\n\t" TINY_FM(0) TINY_FM(1) TINY_FM(2) TINY_FM(3) : [a] "+v"(a) : [w] "v"(w), TINY_M8);
-        asm(TINY_FM(4) TINY_FM(5) TINY_FM(6) TINY_FM(7) : [a] "+v"(a) : [w] "v"(w), TINY_M8);
-        if constexpr (KT >= 12) asm(TINY_FM(8) TINY_FM(9) TINY_FM(10) TINY_FM(11) : [a] "+v"(a) : [w] "v"(w), TINY_M12);
-        if constexpr (KT == 16) asm(TINY_FM(12) TINY_FM(13) TINY_FM(14) TINY_FM(15) : [a] "+v"(a) : [w] "v"(w), TINY_M16);
+        asm("s_nop 1\n\t" TINY_FM(0) TINY_FM(1) TINY_FM(2) TINY_FM(3) : [a] "+&v"(a) : [w] "v"(w), TINY_M8);
+        asm(TINY_FM(4) TINY_FM(5) TINY_FM(6) TINY_FM(7) : [a] "+&v"(a) : [w] "v"(w), TINY_M8);
+        if constexpr (KT >= 12) asm(TINY_FM(8) TINY_FM(9) TINY_FM(10) TINY_FM(11) : [a] "+&v"(a) : [w] "v"(w), TINY_M12);
+        if constexpr (KT == 16) asm(TINY_FM(12) TINY_FM(13) TINY_FM(14) TINY_FM(15) : [a] "+&v"(a) : [w] "v"(w), TINY_M16);
         return a;
     } else {
 #ifdef TINYMPC_WIDE_SHFL
