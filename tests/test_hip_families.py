@@ -553,7 +553,8 @@ def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch
         else:
             s.set_x0_batch(x0s)
         s.solve()
-        assert s.launch_info()["layout"] == ("F" if rnd < 2 else "C"), s.jit_info()
+        # (cones that share rows: the round-1 latency kernel has no round-by-round projection, k_admm_solve_fam takes over)
+        assert s.launch_info()["layout"] == ("F" if rnd < 2 else "A" if variant == "overlap" else "C"), s.jit_info()
         if rnd == 0:
             info = s.jit_info()
             assert (info.startswith("compiled ") or info.startswith("disk-cache ")) and "layout=F" in info and "scratch=0" in info, info

@@ -68,7 +68,6 @@ constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
 constexpr int kLayoutEBatchMin = 260;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
                                         // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
-constexpr int kLayoutFBatchMax = 256;   // layout F (the specialised latency kernel: one instance per CU, two wavefronts per SIMD) up to here
 constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
                                        // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
 
@@ -506,7 +505,10 @@ int decide_layout_e(tinympc_solver *s) {
 int decide_layout_f(tinympc_solver *s) {
     const bool fam = s->families_active();
     const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && !s->session_active && s->N >= 6;
-    bool want = possible && !s->use_layout_d() && !s->use_layout_e() && s->batch <= kLayoutFBatchMax && (fam ? s->fam_c : s->layout_c);
+    // Default: the families at small batches -- rocket landing N=100, one instance: 4.5 us per iteration against 6.55 on the
+    // round-1 latency kernel. The box path stays on layout C (quadrotor N=50: 2.9 us against 3.4 here: chunks of two slots leave the
+    // carry scans most of the iteration).
+    bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin && s->fam_c;
     if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
     if (!want) {
         s->f_ok = false;
