@@ -244,8 +244,9 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
  * after 2 s without a command (a crashed host does not leave it spinning); the next step restarts it transparently.
  * While the resident kernel spins, calls that synchronise the whole DEVICE (hipFree / hipMalloc of another handle's
  * setup or reset, hipDeviceSynchronize, torch.cuda.synchronize) wait for it -- up to the 2 s idle time-out: end the
- * session before such calls. Results are identical, bit for bit, to the same ticks issued as tinympc_mpc_step_batch
- * calls. */
+ * session before such calls. The resident kernel is layout C's: its results are identical, bit for bit, to the same
+ * ticks issued as tinympc_mpc_step_batch calls on that kernel (with the cone / linear families a launched tick runs on
+ * layout F by default, whose results differ in the last bits: the carries of its chunks round differently). */
 int tinympc_session_begin(tinympc_solver *s);
 int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out);
 int tinympc_session_end(tinympc_solver *s);
@@ -281,7 +282,8 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
  * L2-resident in HBM, four wavefronts per workgroup), 'C' (one instance per workgroup, horizon swept in 16 concurrent
  * chunks; batches up to 768 and every single solve), 'D' (horizon unrolled at compile time, state in registers; large
  * batches), 'E' (as D with the horizon cut across the wavefronts of a workgroup: cone / linear families at long horizons),
- * 'M' (64 < nx+nu <= 128 on the FP64 matrix cores). The environment variable TINYMPC_LAYOUT=A|B|C|D|E overrides the choice.
+ * 'F' (the latency kernel specialised at run time: up to 32 chunks on two wavefronts per SIMD; the families at small batches),
+ * 'M' (64 < nx+nu <= 128 on the FP64 matrix cores). The environment variable TINYMPC_LAYOUT=A|B|C|D|E|F overrides the choice.
  * 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
 

@@ -159,3 +159,30 @@ def test_embedded_kernel_sources_are_the_sources_on_disk():
         assert body == src, name
         for inc_name in re.findall(r'#include "([^"]+)"', src):
             assert inc_name in ge.JIT_EMBEDDED, f"{name} includes {inc_name}, which is not embedded"
+
+
+@pytest.mark.parametrize("nx,nu,N,ct,wpg,S,fam", [
+    (6, 3, 100, 0, 7, 4, E_ROCKET),     # BASELINE config 4, one instance (the build lints the same instance)
+    (6, 3, 100, 1, 7, 4, dict(nround=2, ncone=3, cones="{0,0,2},{0,6,8},{1,1,4}", nlx=12, nlu=5)),  # overlapping cones, many rows (run-time loop)
+    (6, 3, 10, 0, 2, 2, E_ROCKET),      # short horizon: five chunks of two slots, a one-slot last chunk
+    (12, 4, 50, 1, 7, 2, None),         # box path
+    (4, 1, 120, 1, 8, 4, None),         # eight wavefronts
+])
+def test_layout_f_specialisations_have_no_dpp_hazard_and_no_scratch(nx, nu, N, ct, wpg, S, fam, tmp_path):
+    """tinympc_solve_f.hip (the specialised latency kernel) as hiprtc will build it on the GPU box, compiled here with hipcc: DPP
+    hazards in the sweep chains, the carry scans' mat-vecs (the early-clobber accumulator: a shared register there was this lint's
+    find) and the EXEC-masked gathers; no scratch."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    f = fam or dict(nround=0, ncone=0, cones="{-1,0,0}", nlx=0, nlu=0)
+    out = tmp_path / "jit_f.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                    "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_CT={ct}", f"-DTINY_JIT_FAM={1 if fam else 0}",
+                    f"-DTINY_JIT_F_WPG={wpg}", f"-DTINY_JIT_F_S={S}", f"-DTINY_JIT_E_NROUND={f['nround']}", f"-DTINY_JIT_E_NCONE={f['ncone']}",
+                    f"-DTINY_JIT_E_CONES={f['cones']}", f"-DTINY_JIT_E_NLX={f['nlx']}", f"-DTINY_JIT_E_NLU={f['nlu']}",
+                    "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "tinympc_solve_f.hip")], check=True, timeout=900)
+    text = out.read_text()
+    checked, bad = _lint(text)
+    assert checked > 100 and not bad, bad[:3]
+    assert ".private_segment_fixed_size: 0" in text and "vgpr_spill_count: 0" in text, "the specialisation spills"

@@ -58,8 +58,11 @@ def test_session_ticks_equal_launched_ticks(pkg, name):
     b.reset()
 
 
-def test_session_with_per_tick_references_and_families(pkg):
-    """rocket_landing_constraints.m:86-121 inside a session: references re-sent every tick, cones + linear row + fdyn."""
+def test_session_with_per_tick_references_and_families(pkg, monkeypatch):
+    """rocket_landing_constraints.m:86-121 inside a session: references re-sent every tick, cones + linear row + fdyn. The session
+    is the resident variant of the latency kernel of layout C, so its ticks are bit-identical to LAUNCHED ticks of that kernel
+    (TINYMPC_LAYOUT=C here: by default small family batches launch layout F, whose carries round differently -- 1e-15)."""
+    monkeypatch.setenv("TINYMPC_LAYOUT", "C")
     P = pkg.problems
     prob = P.rocket(20)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
