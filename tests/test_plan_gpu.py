@@ -1,0 +1,101 @@
+"""The kernel of a launch is chosen in ONE function (tinympc_plan.hip: current_plan) from the shape, the batch size and the variant
+of the configuration. This table enumerates (problem, batch, variant, environment) -> expected layout, origin of the kernel
+(compiled in / run-time specialised) and grid, and checks that a solve on the chosen kernel matches the restatement."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from conftest import rel_err
+
+import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _wide(P, nx, nu, N, seed=0):
+    rng = np.random.default_rng(seed)
+    A = np.eye(nx) * (0.98 if nx > 64 else 1.0) + (0.015 if nx > 64 else 0.03) * rng.standard_normal((nx, nx))
+    B = (0.08 if nx > 64 else 0.1) * rng.standard_normal((nx, nu))
+    p = P.Problem("synthetic", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
+    p.x_min, p.x_max, p.u_min, p.u_max = np.full(nx, -2.0), np.full(nx, 2.0), np.full(nu, -0.3), np.full(nu, 0.3)
+    return p
+
+
+# (name, problem factory, batch, variant, env, expected layout, expected origin prefix(es), expected workgroups or None)
+CASES = [
+    ("quadrotor50 single", lambda P: P.quadrotor(50), 1, "box", {}, "C", ("compiled-in",), 1),
+    ("quadrotor50 x512", lambda P: P.quadrotor(50), 512, "box", {}, "C", ("compiled-in",), 512),
+    ("quadrotor50 x2048", lambda P: P.quadrotor(50), 2048, "box", {}, "D", ("compiled-in",), 128),
+    ("quadrotor40 x2048", lambda P: P.quadrotor(40), 2048, "box", {}, "D", ("compiled", "disk-cache"), 128),
+    ("quadrotor40 x2048 per-knot references", lambda P: P.quadrotor(40), 2048, "varying", {}, "D", ("compiled", "disk-cache"), None),
+    ("quadrotor40 x2048 no specialiser", lambda P: P.quadrotor(40), 2048, "box", {"TINYMPC_JIT": "0"}, "B", ("refused(TINYMPC_JIT=0)",), 128),
+    ("quadrotor200 x2048", lambda P: P.quadrotor(200), 2048, "box", {}, "E", ("compiled", "disk-cache"), 512),
+    ("cartpole250 x2048", lambda P: P.cartpole(250, True), 2048, "box", {}, "E", ("compiled", "disk-cache"), 512),
+    ("quadrotor50 x8192 adaptive rho", lambda P: P.quadrotor(50), 8192, "adaptive", {}, "D", ("compiled", "disk-cache"), None),
+    ("quadrotor50 single adaptive rho", lambda P: P.quadrotor(50), 1, "adaptive", {}, "A", ("compiled-in",), 1),
+    ("rocket100 single", lambda P: P.rocket(100), 1, "families", {}, "F", ("compiled", "disk-cache"), 1),
+    ("rocket100 x200", lambda P: P.rocket(100), 200, "families", {}, "F", ("compiled", "disk-cache"), 200),
+    ("rocket100 x4096", lambda P: P.rocket(100), 4096, "families", {}, "E", ("compiled", "disk-cache"), 1024),
+    ("rocket10 x4096", lambda P: P.rocket(10), 4096, "families", {}, "D", ("compiled", "disk-cache"), None),
+    ("rocket100 single no specialiser", lambda P: P.rocket(100), 1, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 1),
+    ("rocket100 x4096 no specialiser", lambda P: P.rocket(100), 4096, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 4096),
+    ("rocket100 overlapping cones single", lambda P: P.rocket(100), 1, "overlap", {}, "F", ("compiled", "disk-cache"), 1),
+    ("rocket100 overlapping cones single no specialiser", lambda P: P.rocket(100), 1, "overlap", {"TINYMPC_JIT": "0"}, "A", ("refused(TINYMPC_JIT=0)",), 1),
+    ("wide 24+8 x4096", lambda P: _wide(P, 24, 8, 30), 4096, "box", {}, "D", ("compiled-in",), None),
+    ("large 96+32 x64", lambda P: _wide(P, 96, 32, 12, 96), 64, "box", {}, "M", ("compiled-in",), 4),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_plan_table(pkg, monkeypatch, case):
+    name, factory, batch, variant, env, layout, origins, workgroups = case
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = pkg.problems
+    prob = factory(P)
+    settings = dict(max_iter=25, abs_pri_tol=1e-4, abs_dua_tol=1e-4)
+    s = pkg.TinyMPC()
+    extra = dict(adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0) if variant == "adaptive" else {}
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=getattr(prob, "fdyn", None), **settings, **extra)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    orc = O.OraclePort(prob)
+    if variant in ("families", "overlap"):
+        if variant == "overlap":
+            prob.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.2, 0.3], Acu=[0], qcu=[3], cu=[0.25])
+        s.set_cone_constraints(**prob.cones)
+        s.set_linear_constraints(**prob.linear)
+        s.set_x_ref(prob.x_ref)
+        s.set_u_ref(prob.u_ref)
+    if variant == "varying":
+        prob.x_ref = 0.05 * np.sin(np.arange(prob.N))[None, :] * np.ones((prob.nx, 1))
+        s.set_x_ref(prob.x_ref)
+    if variant == "adaptive":
+        dK, dP, dC1, dC2 = s.compute_sensitivity_autograd()
+        s.set_sensitivity_matrices(dK, dP, dC1, dC2)
+    rng = np.random.default_rng(7)
+    x0s = prob.x0[:, None] * rng.uniform(0.8, 1.1, (1, batch))
+    if batch == 1:
+        s.set_x0(x0s[:, 0])
+    else:
+        s.set_x0_batch(x0s)
+    s.prepare()
+    info, origin = s.launch_info(), s.jit_info()
+    assert info["layout"] == layout, (name, info, origin)
+    assert origin.startswith(origins), (name, origin)
+    if workgroups is not None:
+        assert info["workgroups"] == workgroups, (name, info)
+    s.solve()
+    assert s.launch_info()["layout"] == layout
+    orc = orc.load_problem(prob, settings)
+    if variant == "adaptive":
+        orc.set_adaptive_rho(True, 0.2, 40.0, True)
+        orc.set_sensitivity(dK, dP)
+    b = batch - 1
+    orc.set_x0(x0s[:, b])
+    orc.solve()
+    sol = s.get_solution_batch(b, 1)
+    st = s.get_stats_batch(b, 1)
+    assert st["iter"][0] == orc.stats()["iter"], name
+    assert rel_err(sol["controls"][:, :, 0], orc.solution()[1]) < 1e-9, name
+    s.reset()

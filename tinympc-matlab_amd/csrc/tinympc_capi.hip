@@ -1,737 +1,16 @@
-// tinympc_capi.hip -- the extern "C" boundary declared in include/tinympc_hip.h.
-//
-// Host-side bookkeeping only: argument validation with the reference's error behaviour, device
-// buffer ownership, lazy rebuild of the fused operators / per-knot tables when their inputs change,
-// and kernel launches. Every number the solver produces is computed by the kernels in
-// tinympc_kernels.hip; there is no CPU fallback anywhere in this file.
-#include "tinympc_hip.h"
+// tinympc_capi.hip -- the verbs of the extern "C" boundary declared in include/tinympc_hip.h: argument validation with the
+// reference's error behaviour, data in and out. The handle and its helpers: tinympc_handle.h / .hip; which kernel a launch runs:
+// tinympc_plan.hip; the resident session: tinympc_session.hip. Host-side bookkeeping only -- every number the solver produces is
+// computed by the kernels; there is no CPU fallback anywhere.
+#include "tinympc_handle.h"
 
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
 #include <atomic>
-#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
-#include <string>
-#include <vector>
-
-#include "tinympc_device.h"
-#include "tinympc_host.h"
-
-namespace tinympc {
-
-std::string &last_error_slot() {
-    thread_local std::string slot;
-    return slot;
-}
-
-int fail(int code, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    last_error_slot() = buf;
-    return code;
-}
-
-}  // namespace tinympc
 
 using namespace tinympc;
-
-namespace {
-
-#define HIP_TRY(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e__ = (expr);                                                                 \
-        if (e__ != hipSuccess)                                                                   \
-            return fail(TINYMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                        __FILE__, __LINE__);                                                     \
-    } while (0)
-
-struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings.cpp:583-586)
-    double abs_pri_tol, abs_dua_tol;
-    int max_iter, check_termination;
-    int en_state_bound, en_input_bound;
-    int en_state_soc, en_input_soc, en_state_linear, en_input_linear;
-    int adaptive_rho;
-    double adaptive_rho_min, adaptive_rho_max;
-    int adaptive_rho_enable_clipping;
-};
-
-constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
-// Every pinned buffer the kernels and the host exchange data through WHILE a kernel runs (completion flags, the session
-// mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
-// GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
-constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
-constexpr int kLayoutEBatchMin = 260;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
-                                        // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
-constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
-                                       // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
-
-}  // namespace
-
-struct tinympc_solver {
-    int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
-    int W = 0, KT = 0, IPW = 0, groups = 0;
-    double rho = 0.0;
-    Settings st{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // problem + cache
-    double *dA = nullptr, *dB = nullptr, *dfdyn = nullptr, *dQd = nullptr, *dRd = nullptr;
-    double *dKinf = nullptr, *dPinf = nullptr, *dQuu = nullptr, *dAmBKt = nullptr, *dAPf = nullptr, *dBPf = nullptr;
-    double *dscratch = nullptr;
-    int *dinfo = nullptr;
-    // the .m class's own Riccati helpers (compute_cache_terms / solve_lqr / compute_sensitivity_autograd)
-    double *dQfull = nullptr, *dRfull = nullptr, *dlqr_scratch = nullptr, *dlqr_out = nullptr;  // dlqr_out: 3 x cache_doubles()
-    // adaptive rho: sensitivities dKinf/drho, dPinf/drho (zeros until set), kernel tables, per-instance rho
-    double *ddK = nullptr, *ddP = nullptr, *dadapt = nullptr, *drho_inst = nullptr;
-    size_t cache_doubles() const { return (size_t)nu * nx + (size_t)2 * nx * nx + (size_t)nu * nu; }  // K | P | C1 | C2
-    // user-layout bounds / refs
-    double *dxmin = nullptr, *dxmax = nullptr, *dumin = nullptr, *dumax = nullptr, *dXref = nullptr, *dUref = nullptr;
-    // derived
-    double *dops = nullptr, *dtables = nullptr;
-    bool ops_dirty = true, tables_dirty = true;
-    // per-instance state
-    double *dx0 = nullptr, *dG = nullptr, *dV = nullptr, *dD = nullptr, *dsolx = nullptr, *dsolu = nullptr;
-    int *distats = nullptr;
-    double *ddstats = nullptr;
-    size_t lds_bytes = 0;
-    bool tables_in_lds = false;
-    bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
-    bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
-    // Horizon unrolled at compile time, state in registers, two waves per SIMD (tinympc_solve_d.hip). Wanted for large
-    // batches of a shape that is compiled in; each launch still checks that bounds / references are time-invariant and
-    // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
-    bool layout_d = false;
-    bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
-    bool d_jit_asked = false;  // the specialiser was asked for the box kernel at setup (its answer may have been a refusal)
-    // Large systems, 64 < nx+nu <= 128: tiles of 16 instances on the FP64 matrix cores, state streamed from HBM in the tile's
-    // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
-    // adaptive rho / session.
-    bool layout_m = false;
-    bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
-    int d_adapt = -1;       // ... and with adaptive rho
-    int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
-    int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
-    // Layout E (tinympc_solve_e.hip, run-time specialised on the families' STRUCTURE): the horizon cut across the wavefronts of a
-    // workgroup -- the throughput kernel for the families at horizons layout D cannot hold. Decided per launch
-    // (decide_layout_variants): `e_sig` is the structure / table kind the answer `e_ok` belongs to.
-    FamilyStructure fs;
-    std::string e_sig;
-    bool e_ok = false;
-    int e_chunk_len = 0, e_wpg = 0;
-    size_t e_lds = 0;
-    // Layout F (tinympc_solve_f.hip): the latency kernel as a run-time specialisation (shape, chunk plan and the families'
-    // structure compiled in); decided per launch like layout E
-    std::string f_sig;
-    bool f_ok = false;
-    FamilyStructure f_fs;
-    int f_chunk_len = 0, f_chunks = 0, f_wpg = 0;
-    size_t f_lds = 0;
-    double *dctab_f = nullptr;   // Phi^(S..4S) | Psi^(S..4S) for layout F's chunk length
-    int dctab_f_len = 0;
-    double *dclock = nullptr;    // (diagnostic build TINY_CLOCK_STAMP only) per-wavefront clock stamps of the last launch
-    double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
-    int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)
-    // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
-    bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
-    bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
-    bool zero_copy_tick = false;  // this launch reads x0 from / writes u0 to pinned host memory (mpc_step, small batches)
-    bool c_tables = false;  // the chunk tables exist (layout C is possible for this shape and not excluded)
-    bool fam_c = false;     // the cone / linear families run in the latency kernel's FAM variant
-    int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
-    size_t lds_bytes_c = 0;
-    double *dctab = nullptr;
-    double *dV2 = nullptr;
-    int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
-    // cone / linear families (host copies of what the verbs received; k_admm_solve_fam consumes `dfam`)
-    std::vector<int> Acx, qcx, Acu, qcu;
-    std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
-    double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
-    double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch (and x0 of single-instance handles)
-    // Single-instance handles (batch == 1, what the MEX shim creates): set_x0 only fills the pinned h_x0, the next
-    // launch reads it from there (and mirrors it into dx0), and the kernels also write solution + statistics into the
-    // pinned h_sol -- the reference's per-tick sequence set_x0 / solve / get_solution then costs ONE launch and ONE
-    // synchronisation instead of three synchronous copies around the launch.
-    double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
-    // Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks
-    // from this mailbox in pinned memory (layout: SolveParams::mail).
-    double *h_mail = nullptr;          // [64]
-    bool session_active = false;
-    // references re-sent inside a session that turned out to be the previous ones moved up by one knot (receding horizon):
-    // only the new last column travels, with the command (flags 4 / 8); two shifts without a step in between, or any other
-    // change, fall back to the full re-read (refs_on_host)
-    bool xref_shift = false, uref_shift = false;
-    bool session_refs_shifted = false;  // the device copies / tables lag behind the pinned references
-    // ONE counter stamps session commands and flag-raising launches alike (both complete by writing their stamp into the
-    // same slot of h_sol: a launch after a session must not find its number already there)
-    unsigned long long session_seq = 0;  // stamp of the last session command / flag-raising launch
-    bool flag_pending = false;
-    // ... and set_x_ref / set_u_ref only fill these pinned copies; the next launch's workgroup rebuilds the
-    // reference-dependent table rows from them (refresh_reference_tables): a tick with per-tick references
-    // (rocket_landing_constraints.m:86-121) is still one launch and one synchronisation.
-    double *h_xref = nullptr, *h_uref = nullptr;
-    bool refs_on_host = false;         // the pinned references are newer than dXref / dUref and the tables
-    bool x0_on_host = false;           // h_x0 is newer than dx0
-    int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
-    bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d && !layout_m; }  // (layout D writes to device memory only)
-    bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
-    double *dscratch_state = nullptr;
-    bool fam_dirty = true;
-    size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
-    bool tables_in_lds_a = false;
-
-    bool use_layout_d() const {
-        return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
-    }
-    bool use_layout_e() const { return e_ok && !st.adaptive_rho && !use_layout_d(); }
-    bool use_layout_f() const { return f_ok && !st.adaptive_rho && !use_layout_d() && !use_layout_e(); }
-    bool families_active() const {
-        return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
-               (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
-    }
-    std::vector<void *> allocs;
-
-    size_t X() const { return (size_t)nx * N; }
-    size_t U() const { return (size_t)nu * (N - 1); }
-    size_t state_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N + 1) * 64; }  // G; row N: per-lane dummy slot
-    size_t v_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * v_rows(N) * 64; }     // V (and V2)
-    size_t d_doubles() const { return layout_m ? solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N - 1) * IPW * nu; }
-};
-
-namespace {
-
-template <typename T>
-int dalloc(tinympc_solver *s, T **p, size_t count) {
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
-    if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", sizeof(T) * count, hipGetErrorString(e));
-    s->allocs.push_back(q);
-    *p = static_cast<T *>(q);
-    return TINYMPC_OK;
-}
-
-int end_session(tinympc_solver *s);
-
-// Every verb that touches the device passes through here first: a resident session kernel would make it wait forever
-// on the handle's stream, so the session is ended (its state is in HBM after every tick) before anything else happens.
-int bind_device(tinympc_solver *s) {
-    HIP_TRY(hipSetDevice(s->device));
-    if (s->session_active) return end_session(s);
-    return TINYMPC_OK;
-}
-
-// true if every row of the column-major rows x cols matrix holds one value (bit-wise; inf == inf)
-bool rows_constant(const double *m, int rows, int cols) {
-    for (int c = 1; c < cols; ++c)
-        for (int r = 0; r < rows; ++r)
-            if (!(m[r + (size_t)c * rows] == m[r])) return false;
-    return true;
-}
-
-int upload(tinympc_solver *s, double *dst, const double *src, size_t count) {
-    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));  // the caller keeps ownership of src: copy completes inside the call
-    return TINYMPC_OK;
-}
-
-int download(tinympc_solver *s, void *dst, const void *src, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    return TINYMPC_OK;
-}
-
-int fill_host_upload(tinympc_solver *s, double *dst, size_t count, double value) {
-    std::vector<double> h(count, value);
-    return upload(s, dst, h.data(), count);
-}
-
-int check_handle(const tinympc_solver *s) {
-    if (!s) return fail(TINYMPC_ERR_NOT_INITIALIZED, "Solver not initialized");
-    return TINYMPC_OK;
-}
-
-int run_precompute(tinympc_solver *s) {
-    PrecomputeParams p{};
-    p.nx = s->nx; p.nu = s->nu; p.rho = s->rho;
-    p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
-    p.Kinf = s->dKinf; p.Pinf = s->dPinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
-    p.info = s->dinfo; p.scratch = s->dscratch;
-    p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
-    HIP_TRY(launch_precompute(p, s->stream));
-    s->ops_dirty = true;
-    s->tables_dirty = true;
-    return TINYMPC_OK;
-}
-
-// References left in pinned host memory by set_x_ref / set_u_ref -> device copies, the ordinary way.
-int flush_host_refs(tinympc_solver *s) {
-    int rc;
-    if ((rc = upload(s, s->dXref, s->h_xref, s->X()))) return rc;
-    if (s->U() && (rc = upload(s, s->dUref, s->h_uref, s->U()))) return rc;
-    s->refs_on_host = false;
-    s->tables_dirty = true;
-    return TINYMPC_OK;
-}
-
-int refresh_derived(tinympc_solver *s) {
-    if (s->ops_dirty) {
-        OperatorParams p{};
-        p.nx = s->nx; p.nu = s->nu; p.W = s->W; p.KT = s->KT;
-        p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
-        p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
-        p.ops = s->dops;
-        HIP_TRY(launch_build_operators(p, s->stream));
-        if (s->c_tables) {  // powers of the sweep operators for the chunked kernel
-            ChunkTableParams c{};
-            c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->chunk_len; c.Lc = s->chunk_levels;
-            c.ops = s->dops; c.out = s->dctab;
-            HIP_TRY(launch_build_chunk_tables(c, s->stream));
-        }
-        s->dctab_e_len = 0;  // (layout E's and F's carry matrices are rebuilt on demand, below)
-        s->dctab_f_len = 0;
-        s->ops_dirty = false;
-        s->tables_dirty = true;
-    }
-    if (s->e_ok && s->dctab_e && s->dctab_e_len != s->e_chunk_len) {  // Phi^S, Psi^S for layout E's chunk length
-        ChunkTableParams c{};
-        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->e_chunk_len; c.Lc = 1;
-        c.ops = s->dops; c.out = s->dctab_e;
-        HIP_TRY(launch_build_chunk_tables(c, s->stream));
-        s->dctab_e_len = s->e_chunk_len;
-    }
-    if (s->f_ok && s->dctab_f && s->dctab_f_len != s->f_chunk_len) {  // powers S .. 4S for layout F's chunk length
-        ChunkTableParams c{};
-        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->f_chunk_len; c.Lc = 4;
-        c.ops = s->dops; c.out = s->dctab_f;
-        HIP_TRY(launch_build_chunk_tables(c, s->stream));
-        s->dctab_f_len = s->f_chunk_len;
-    }
-    if (s->tables_dirty) {
-        TableParams p{};
-        p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.W = s->W; p.KT = s->KT;
-        p.en_state_bound = s->st.en_state_bound; p.en_input_bound = s->st.en_input_bound;
-        p.x_min = s->dxmin; p.x_max = s->dxmax; p.u_min = s->dumin; p.u_max = s->dumax;
-        p.Xref = s->dXref; p.Uref = s->dUref; p.Pinf = s->dPinf; p.ops = s->dops; p.tables = s->dtables;
-        HIP_TRY(launch_build_tables(p, s->stream));
-        s->tables_dirty = false;
-    }
-    return TINYMPC_OK;
-}
-
-// The ACTIVE cones in list order (state cones, then input cones) with their rounds, and the linear rows per side: what layout E
-// is specialised on (FamilyStructure, tinympc_device.h). `mu` receives the slopes in the same order.
-FamilyStructure family_structure(const tinympc_solver *s, double *mu = nullptr) {
-    FamilyStructure fs;
-    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
-    unsigned long long used = 0;  // lanes taken by the cones of the current round
-    auto add = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
-        if (!on) return;
-        for (size_t k = 0; k < Ac.size() && fs.ncone < MAX_CONES; ++k) {
-            const int first = base + Ac[k], last = first + qc[k] - 1;
-            unsigned long long lanes = 0;
-            for (int r = first; r <= last; ++r) lanes |= 1ull << (r & 63);
-            if (fs.ncone == 0) fs.nround = 1;
-            if (lanes & used) {  // overlaps an earlier cone of this round: upstream projects one after the other
-                fs.nround += 1;
-                used = 0;
-            }
-            used |= lanes;
-            fs.cone[fs.ncone][0] = fs.nround - 1;
-            fs.cone[fs.ncone][1] = first;
-            fs.cone[fs.ncone][2] = last;
-            if (mu) mu[fs.ncone] = c[k];
-            fs.ncone += 1;
-        }
-    };
-    add(cone_x, s->Acx, s->qcx, s->cx, 0);
-    add(cone_u, s->Acu, s->qcu, s->cu, s->nx);
-    fs.nlx = (s->st.en_state_linear && s->n_lin_x > 0) ? s->n_lin_x : 0;
-    fs.nlu = (s->st.en_input_linear && s->n_lin_u > 0) ? s->n_lin_u : 0;
-    return fs;
-}
-
-// Per-lane description of the cone / linear families for k_admm_solve_fam (layout: fam_doubles()).
-// Masks and user coefficients only -- no solver arithmetic happens here.
-int refresh_families(tinympc_solver *s) {
-    const int W = s->W, KT = s->KT, nx = s->nx, nu = s->nu, nxu = nx + nu;
-    if (!s->dfam) {
-        int rc;
-        if ((rc = dalloc(s, &s->dfam, fam_doubles(W, KT)))) return rc;
-        if ((rc = dalloc(s, &s->dGC, s->v_doubles()))) return rc;
-        if ((rc = dalloc(s, &s->dGL, s->v_doubles()))) return rc;
-        if ((rc = dalloc(s, &s->dLX, s->v_doubles()))) return rc;
-        HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
-        HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
-        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
-        s->fam_dirty = true;
-    }
-    if (!s->fam_dirty) return TINYMPC_OK;
-    std::vector<double> f(fam_doubles(W, KT), 0.0);
-    double *role = f.data(), *mu = role + W, *famc = mu + W, *faml = famc + W;
-    double *Cn = faml + W, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT, *lin = Ty + (size_t)W * KT;
-    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
-    const bool lin_x = s->st.en_state_linear && s->n_lin_x > 0, lin_u = s->st.en_input_linear && s->n_lin_u > 0;
-    for (int r = 0; r < nxu; ++r) {
-        const bool is_x = r < nx;
-        famc[r] = (is_x ? cone_x : cone_u) ? 1.0 : 0.0;
-        faml[r] = (is_x ? lin_x : lin_u) ? 1.0 : 0.0;
-        for (int k = 0; k < nxu; ++k)
-            if ((k < nx) == is_x) Ty[(size_t)r * KT + k] = 1.0;
-    }
-    // cones, round by round (family_structure: cones of one round are pairwise disjoint): round 0 into the arrays every kernel
-    // reads, later rounds -- they exist only where cones share rows -- behind them for the kernels that walk rounds
-    {
-        std::vector<double> cmu(MAX_CONES, 0.0);
-        const FamilyStructure fs = family_structure(s, cmu.data());
-        f[fam_nround_offset(W, KT)] = (double)(fs.nround > 0 ? fs.nround : 1);
-        for (int c = 0; c < fs.ncone; ++c) {
-            const int q = fs.cone[c][0], first = fs.cone[c][1], last = fs.cone[c][2];
-            double *rl = role, *m = mu, *cn = Cn, *ct = Ct;
-            if (q >= 1) {
-                rl = f.data() + fam_round_offset(W, KT, q);
-                m = rl + W;
-                cn = m + W;
-                ct = cn + (size_t)W * KT;
-            }
-            for (int r = first; r <= last; ++r) {
-                rl[r] = (r == last) ? 2.0 : 1.0;
-                m[r] = cmu[c];
-                for (int k = first; k < last; ++k) cn[(size_t)r * KT + k] = 1.0;
-                ct[(size_t)r * KT + last] = 1.0;
-            }
-        }
-    }
-    (void)cone_x;
-    (void)cone_u;
-    const int nlx = lin_x ? s->n_lin_x : 0, nlu = lin_u ? s->n_lin_u : 0;
-    const int nl = nlx > nlu ? nlx : nlu;
-    lin[0] = (double)nl;
-    const double inf = std::numeric_limits<double>::infinity();
-    for (int k = 0; k < MAX_LIN_ROWS; ++k) {
-        double *ak = lin + 1 + (size_t)(3 * k + 0) * W, *bk = ak + W, *nk = bk + W;
-        double nrm_x = 0.0, nrm_u = 0.0;
-        if (k < nlx) for (int c = 0; c < nx; ++c) { const double a = s->Alin_x[k + (size_t)c * s->n_lin_x]; nrm_x += a * a; }
-        if (k < nlu) for (int c = 0; c < nu; ++c) { const double a = s->Alin_u[k + (size_t)c * s->n_lin_u]; nrm_u += a * a; }
-        for (int r = 0; r < W; ++r) {
-            ak[r] = 0.0; bk[r] = inf; nk[r] = 1.0;
-            if (r < nx && k < nlx) { ak[r] = s->Alin_x[k + (size_t)r * s->n_lin_x]; bk[r] = s->blin_x[k]; nk[r] = nrm_x; }
-            if (r >= nx && r < nxu && k < nlu) { ak[r] = s->Alin_u[k + (size_t)(r - nx) * s->n_lin_u]; bk[r] = s->blin_u[k]; nk[r] = nrm_u; }
-        }
-    }
-    (void)family_structure(s, f.data() + fam_cone_mu_offset(W, KT));  // slopes of the active cones, in list order (layout E)
-    int rc = upload(s, s->dfam, f.data(), f.size());
-    if (rc) return rc;
-    s->fam_dirty = false;
-    return TINYMPC_OK;
-}
-
-// Single-instance launches of the latency kernel end by writing a sequence number behind the solution in pinned host
-// memory; tinympc_synchronize polls it (a few hundred nanoseconds after the kernel's last store) instead of sleeping in
-// hipStreamSynchronize (whose wake-up costs several microseconds of a ~25 us tick).
-void arm_completion_flag(tinympc_solver *s, SolveParams &p) {
-    if (!p.host_sol) return;
-    s->session_seq += 1;
-    p.host_seq = (double)s->session_seq;
-    s->flag_pending = true;
-}
-
-// Layout D's variants beyond the constant-table box path are decided when first needed (they may have to be specialised,
-// which takes seconds): time-varying tables and the cone / linear families. Called by everything that asks use_layout_d()
-// before a launch, so that the answer does not change between that question and the launch itself.
-void decide_layout_d_variants(tinympc_solver *s) {
-    if (!s->layout_d) return;
-    if (s->d_varying < 0 && !s->tables_const()) {
-        // is there a kernel for per-knot tables (compiled in -- 16-lane form only -- or specialised now)? Otherwise these launches
-        // run on layout B / A, as before.
-        if (s->W == 16 && !s->d_jit && solve_d_supported(s->nx, s->nu, s->N, false)) {
-            s->d_varying = 1;
-        } else {
-            s->d_varying_jit = solve_jit_supported(s->W, s->nx, s->nu, s->N, false);
-            s->d_varying = s->d_varying_jit ? 1 : 0;
-        }
-    }
-    if (s->st.adaptive_rho && !s->families_active())
-        s->d_adapt = (s->W == 16 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), false, true)) ? 1 : 0;
-    if (s->families_active() && !s->st.adaptive_rho) {
-        // families: a run-time specialisation (16-lane form, horizons whose five register pairs per knot fit)? Asked every
-        // time -- the answer is cached inside -- because it also depends on the tables' kind.
-        // (cones that share rows need the round-by-round projection, which layout D's families variant and the latency kernel
-        // do not have: layout E or k_admm_solve_fam run those)
-        s->d_fam = (s->W == 16 && family_structure(s).nround <= 1 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
-    }
-}
-
-// Layout E for the families where layout D has no kernel (long horizons): asked whenever the structure of the families or the
-// kind of the tables changed (the kernel is specialised on both; compiling takes seconds the first time, the answer is cached
-// inside tinympc_jit.hip). TINYMPC_LAYOUT=E forces it at any batch size (tests), any other value excludes it.
-int decide_layout_e(tinympc_solver *s) {
-    const bool fam = s->families_active();
-    // (single-instance handles exchange x0 / the solution through pinned host memory, which only the latency kernel serves)
-    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && s->batch > 1;
-    // families: wherever layout D has no kernel; box path: horizons for which the specialiser has no layout-D kernel at all (no plan,
-    // or a plan whose code object spilled) -- long horizons, where layouts B / A are left with one or two wavefronts per CU
-    bool want = possible && !s->use_layout_d() &&
-                (fam ? s->batch >= kLayoutEBatchMin : (s->d_jit_asked && !s->layout_d && s->batch > kLayoutCBatchMax && s->N >= 26));
-    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'E' || env[0] == 'e') && possible;
-    if (!want) {
-        s->e_ok = false;
-        s->e_sig.clear();
-        return TINYMPC_OK;
-    }
-    const FamilyStructure fs = fam ? family_structure(s) : FamilyStructure();
-    std::string sig = s->tables_const() ? "ct|" : "var|";
-    for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
-    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
-    if (sig == s->e_sig) return TINYMPC_OK;
-    s->e_sig = sig;
-    s->fs = fs;
-    s->e_ok = solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), fam, fs) &&
-              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds);
-    if (s->e_ok && !s->dctab_e) {
-        int rc = dalloc(s, &s->dctab_e, chunk_table_doubles(s->nx, 1));
-        if (rc) return rc;
-    }
-    return TINYMPC_OK;
-}
-
-// Layout F for what the latency kernel (layout C) serves: single solves and small batches. The kernel is specialised on the
-// shape, the kind of the tables and the structure of the families, so it is asked whenever one of them changed (seconds the
-// first time; cached inside tinympc_jit.hip). TINYMPC_LAYOUT=F forces it at any batch size (tests), any other value excludes it.
-int decide_layout_f(tinympc_solver *s) {
-    const bool fam = s->families_active();
-    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && !s->session_active && s->N >= 6;
-    // Default: the families at small batches -- rocket landing N=100, one instance: 4.5 us per iteration against 6.55 on the
-    // round-1 latency kernel. The box path stays on layout C (quadrotor N=50: 2.9 us against 3.4 here: chunks of two slots leave the
-    // carry scans most of the iteration).
-    bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin && s->fam_c;
-    if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
-    if (!want) {
-        s->f_ok = false;
-        s->f_sig.clear();
-        return TINYMPC_OK;
-    }
-    const FamilyStructure fs = fam ? family_structure(s) : FamilyStructure();
-    std::string sig = s->tables_const() ? "ct|" : "var|";
-    for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
-    sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
-    if (sig == s->f_sig) return TINYMPC_OK;
-    s->f_sig = sig;
-    s->f_fs = fs;
-    s->f_ok = solve_f_supported(s->nx, s->nu, s->N, s->tables_const(), fam, fs) &&
-              solve_f_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->f_chunk_len, &s->f_chunks, &s->f_wpg, &s->f_lds);
-    if (s->f_ok && !s->dctab_f) {
-        int rc = dalloc(s, &s->dctab_f, chunk_table_doubles(s->nx, 4));
-        if (rc) return rc;
-    }
-    return TINYMPC_OK;
-}
-
-int launch(tinympc_solver *s, bool timed) {
-    int rc;
-    s->flag_pending = false;
-    decide_layout_d_variants(s);
-    if ((rc = decide_layout_e(s))) return rc;
-    if ((rc = decide_layout_f(s))) return rc;
-    const bool fam = s->families_active();
-    const bool adaptive = s->st.adaptive_rho != 0;
-    // k_build_adapt reads the device copy of the references before the solve kernel starts; layout F has no in-kernel staging of
-    // references left in pinned host memory (layout C does): bring the device copies and the tables up to date the ordinary way
-    if (s->refs_on_host && (adaptive || s->use_layout_f())) {
-        if ((rc = flush_host_refs(s))) return rc;
-    }
-    if ((rc = refresh_derived(s))) return rc;
-    if (adaptive && fam)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
-    if (s->layout_m && (adaptive || fam))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "systems with nx+nu > 64 support box constraints only (no cone / linear families, no adaptive_rho)");
-    if (adaptive) {  // tiny tables from the current cache, sensitivities and Xref; rebuilt per launch (a few microseconds)
-        AdaptTableParams a{};
-        a.nx = s->nx; a.nu = s->nu; a.N = s->N; a.W = s->W; a.KT = s->KT;
-        a.A = s->dA; a.B = s->dB; a.Pinf = s->dPinf; a.dK = s->ddK; a.dP = s->ddP; a.Xref = s->dXref; a.out = s->dadapt;
-        HIP_TRY(launch_build_adapt(a, s->stream));
-    }
-    if (fam && (rc = refresh_families(s))) return rc;
-    SolveParams p{};
-    p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = s->batch;
-    p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
-    p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
-    p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0;
-    p.groups = s->groups;
-    p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
-    p.istats = s->distats; p.dstats = s->ddstats;
-    p.tables_in_lds = s->tables_in_lds ? 1 : 0;
-    p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
-    p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
-#ifdef TINY_CLOCK_STAMP  // diagnostic build (tools/clock_check.py): layout D stamps its iteration loop into this buffer
-    if (!s->state_in_global) {
-        if (!s->dclock && (rc = dalloc(s, &s->dclock, (size_t)8 * s->groups))) return rc;
-        p.scratch = s->dclock;
-    }
-#endif
-    p.scratch_stride = state_scratch_doubles(s->nu, s->N, s->W);
-    p.const_tables = s->tables_const() ? 1 : 0;
-    if (s->zero_copy_tick && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {  // set by tinympc_mpc_step_batch for the duration of one launch
-        p.x0 = s->h_x0;
-        p.x0_mirror = s->dx0;
-        p.u0_host = s->h_u0;
-    }
-    if (s->host_path()) {
-        if (s->x0_on_host) {
-            p.x0 = s->h_x0;
-            p.x0_mirror = s->dx0;
-            s->x0_on_host = false;  // the kernel mirrors it into dx0
-        }
-        if (s->st.max_iter > 0) {   // (a 0-iteration solve writes nothing anywhere)
-            p.host_sol = s->h_sol;
-            s->host_sol_state = 1;
-        }
-    }
-    if (s->refs_on_host) {  // (host_path() handles only: batch == 1, one workgroup)
-        p.href_x = s->h_xref; p.href_u = s->h_uref;
-        p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;
-        s->refs_on_host = false;  // the kernel brings the tables and the device copies up to date
-    }
-    p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
-    p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
-    if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-    if (s->layout_m) {
-        HIP_TRY(launch_solve_m(p, s->stream));
-    } else if (adaptive && s->use_layout_d()) {
-        p.adaptive = 1;
-        HIP_TRY(launch_solve_jit(p, s->W, s->stream));
-    } else if (adaptive) {
-        // layout A's LDS plan; shares the persistent state (G, canonical V, D) with the other kernels
-        p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
-        HIP_TRY(launch_solve_adapt(p, s->W, s->KT, s->lds_bytes_a, s->stream));
-    } else if (fam && s->use_layout_d()) {
-        p.families = 1;
-        HIP_TRY(launch_solve_jit(p, s->W, s->stream));
-    } else if (s->use_layout_f()) {  // the specialised latency kernel (families or box path alike)
-        p.families = fam ? 1 : 0;
-        p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
-        arm_completion_flag(s, p);
-        HIP_TRY(launch_solve_f(p, s->f_fs, s->stream));
-    } else if (fam && s->use_layout_e()) {
-        p.families = 1;
-        p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
-        HIP_TRY(launch_solve_e(p, s->fs, s->stream));
-    } else if (fam && s->fam_c && family_structure(s).nround <= 1) {
-        // the latency kernel carries the families itself (same HBM state as k_admm_solve_fam)
-        p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
-        p.families = 1;
-        arm_completion_flag(s, p);
-        HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
-    } else if (fam) {
-        // The families kernel shares the persistent state (G, canonical V, D) with layouts A and B, so a
-        // handle can switch between them from one solve to the next.
-        p.tables_in_lds = s->tables_in_lds_a ? 1 : 0;
-        HIP_TRY(launch_solve_fam(p, s->W, s->KT, s->lds_bytes_a, s->stream));
-    } else if (s->use_layout_e()) {  // (box path: horizons beyond layout D's plans)
-        p.ctab = s->dctab_e; p.chunk_len = s->e_chunk_len; p.chunk_count = s->e_wpg; p.chunk_levels = 1;
-        HIP_TRY(launch_solve_e(p, s->fs, s->stream));
-    } else if (s->use_layout_d()) {
-        HIP_TRY((s->d_jit || (!p.const_tables && s->d_varying_jit)) ? launch_solve_jit(p, s->W, s->stream)
-                         : s->W == 64 ? launch_solve_dx(p, s->stream) : s->W == 32 ? launch_solve_dw(p, s->stream) : launch_solve_d(p, s->stream));
-    } else if (s->layout_c) {
-        p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
-        arm_completion_flag(s, p);
-        HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
-    } else if (s->layout_b) {
-        HIP_TRY(launch_solve_b(p, s->W, s->KT, s->lds_bytes, s->stream));
-    } else {
-        HIP_TRY(launch_solve(p, s->W, s->KT, s->lds_bytes, s->stream));
-    }
-    if (timed) HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    return TINYMPC_OK;
-}
-
-// ---- closed-loop session ------------------------------------------------------------------------------------
-constexpr double kSessionIdleSeconds = 2.0;  // the resident kernel leaves on its own after this long without a command
-
-void write_command(tinympc_solver *s, int flags, const double *x0) {
-    // payload: 0 flags | x0 (nx) | new last column of x_ref (flag 4) | new last column of u_ref (flag 8); line l = [7 payload |
-    // stamp]. Payload before stamp, line by line (x86 keeps the order of stores; the fences keep the compiler from
-    // reordering them).
-    double pay[56];
-    int npay = 0;
-    pay[npay++] = (double)flags;
-    for (int i = 0; i < s->nx; ++i) pay[npay++] = x0 ? x0[i] : 0.0;
-    if (flags & 4) for (int i = 0; i < s->nx; ++i) pay[npay++] = s->h_xref[(size_t)(s->N - 1) * s->nx + i];
-    if (flags & 8) for (int i = 0; i < s->nu; ++i) pay[npay++] = s->h_uref[(size_t)(s->N - 2) * s->nu + i];
-    volatile double *m = s->h_mail;
-    const double stamp = (double)(++s->session_seq);
-    const int nlines = (npay + 6) / 7;
-    for (int l = 0; l < nlines; ++l) {
-        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = pay[q];
-        std::atomic_thread_fence(std::memory_order_release);
-        m[8 * l + 7] = stamp;
-    }
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-}
-
-int launch_session_kernel(tinympc_solver *s) {
-    int rc = refresh_derived(s);
-    if (rc) return rc;
-    const bool fam = s->families_active();
-    if (fam && (rc = refresh_families(s))) return rc;
-    SolveParams p{};
-    p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = 1;
-    p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
-    p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
-    p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0; p.x0_mirror = s->dx0;
-    p.groups = s->groups;
-    p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
-    p.istats = s->distats; p.dstats = s->ddstats;
-    p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
-    p.const_tables = s->tables_const() ? 1 : 0;
-    p.host_sol = s->h_sol;
-    p.href_x = s->h_xref; p.href_u = s->h_uref; p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;  // (re-read on request)
-    s->refs_on_host = false;  // the prologue stages them
-    s->xref_shift = s->uref_shift = false;
-    p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
-    p.families = fam ? 1 : 0;
-    p.mail = s->h_mail;
-    p.session_expect = (double)(s->session_seq + 1);
-    p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
-    HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
-    return TINYMPC_OK;
-}
-
-int end_session(tinympc_solver *s) {
-    if (!s->session_active) return TINYMPC_OK;
-    write_command(s, 1, nullptr);  // stop
-    s->session_active = false;     // (before anything that could come back here)
-    if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
-    s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    return TINYMPC_OK;
-}
-
-void destroy(tinympc_solver *s) {
-    if (!s) return;
-    // teardown is best effort: errors here have nowhere useful to go
-    (void)hipSetDevice(s->device);
-    if (s->session_active) (void)end_session(s);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (void *q : s->allocs) (void)hipFree(q);
-    if (s->h_sol) (void)hipHostFree(s->h_sol);
-    if (s->h_mail) (void)hipHostFree(s->h_mail);
-    if (s->h_xref) (void)hipHostFree(s->h_xref);
-    if (s->h_uref) (void)hipHostFree(s->h_uref);
-    if (s->h_x0) (void)hipHostFree(s->h_x0);
-    if (s->h_u0) (void)hipHostFree(s->h_u0);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    delete s;
-}
-
-}  // namespace
+using namespace tinympc::host;
 
 extern "C" {
 
@@ -1130,10 +409,8 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         s->host_sol_state = 2;
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
-    decide_layout_d_variants(s);
-    if ((rc = decide_layout_e(s))) return rc;
-    if ((rc = decide_layout_f(s))) return rc;
-    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && !s->use_layout_d() && !s->use_layout_e() && !s->layout_m) {
+    if ((rc = resolve_plan(s))) return rc;
+    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && current_plan(s).host_exchange) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
@@ -1153,80 +430,8 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     return TINYMPC_OK;
 }
 
-int tinympc_session_begin(tinympc_solver *s) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if ((rc = bind_device(s))) return rc;  // (ends a session that is still open)
-    if (!s->host_path() || !(s->layout_c || (s->families_active() && s->fam_c)))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles on the latency kernel only (batch 1, nx+nu <= 16, N <= 129)");
-    if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
-    if (s->families_active() && s->chunk_len > 4)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
-    if (s->families_active() && family_structure(s).nround > 1)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows are not supported by the resident kernel");
-    if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
-    if (!s->h_mail) {
-        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
-        std::memset(s->h_mail, 0, sizeof(double) * 64);
-    }
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if ((rc = launch_session_kernel(s))) return rc;
-    s->session_active = true;
-    s->flag_pending = false;
-    return TINYMPC_OK;
-}
 
-int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
-    if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
-    HIP_TRY(hipSetDevice(s->device));  // (the restart path below launches; a multi-GPU caller may have another device current)
-    int flags = 0;
-    if (s->refs_on_host) flags = 2;  // full re-read (covers any pending shift: the pinned copies are current)
-    else flags = (s->xref_shift ? 4 : 0) | (s->uref_shift ? 8 : 0);
-    if (flags & 12) s->session_refs_shifted = true;
-    s->refs_on_host = s->xref_shift = s->uref_shift = false;
-    write_command(s, flags, x0);
-    const volatile double *done = s->h_sol + s->X() + s->U() + 6;
-    double want = (double)s->session_seq;
-    const auto t_start = std::chrono::steady_clock::now();
-    for (long spin = 0;; ++spin) {
-        if (*done == want) break;
-        __builtin_ia32_pause();
-        if ((spin & 0xffff) == 0xffff) {
-            // Nothing for a while: has the kernel left (idle time-out)? Then start it again; it waits for exactly the
-            // command that is pending. A stream error or 30 s without an answer end the session with an error.
-            const hipError_t q = hipStreamQuery(s->stream);
-            if (q == hipSuccess) {
-                // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
-                // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
-                rc = launch_session_kernel(s);  // waits for session_seq + 1
-                if (rc) { s->session_active = false; return rc; }
-                write_command(s, 0, x0);
-                want = (double)s->session_seq;
-            } else if (q != hipErrorNotReady) {
-                s->session_active = false;
-                return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
-            }
-            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
-                (void)end_session(s);
-                return fail(TINYMPC_ERR_HIP, "session_step: no answer from the resident kernel within 30 s");
-            }
-        }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    s->host_sol_state = 2;
-    std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
-    return TINYMPC_OK;
-}
 
-int tinympc_session_end(tinympc_solver *s) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(s->device));
-    return end_session(s);
-}
 
 int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count) {
     int rc = check_handle(s);
@@ -1669,67 +874,9 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
     return TINYMPC_OK;
 }
 
-int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *instances_per_wave, int *workgroups,
-                            int *lds_bytes, int *tables_in_lds) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if (lanes_per_instance) *lanes_per_instance = s->W;
-    if (instances_per_wave) *instances_per_wave = s->IPW;
-    if (workgroups && s->use_layout_f()) *workgroups = s->batch;
-    else if (workgroups && s->use_layout_e()) *workgroups = s->groups;
-    else if (workgroups) *workgroups = s->use_layout_d() ? ((s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit)) ? solve_jit_workgroups(s->W, s->nx, s->nu, s->N, s->tables_const(), s->groups, s->families_active(), s->st.adaptive_rho != 0) : s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups) : solve_d_workgroups(s->nu, s->N, s->tables_const(), s->groups)) : s->layout_c ? s->batch : s->layout_b ? (s->groups + WAVES_PER_GROUP_B - 1) / WAVES_PER_GROUP_B : s->groups;
-    if (lds_bytes) {
-        size_t l = s->layout_c ? s->lds_bytes_c : s->lds_bytes;
-        if (s->layout_m) l = 0;  // (static LDS: see the kernel)
-        else if (s->use_layout_f()) l = s->f_lds;
-        else if (s->use_layout_e()) l = s->e_lds;
-        else if (s->use_layout_d())
-            l = (s->d_jit || s->families_active() || s->st.adaptive_rho || (!s->tables_const() && s->d_varying_jit))
-                    ? solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, s->tables_const(), s->families_active(), s->st.adaptive_rho != 0)
-                    : s->W == 64 ? solve_dx_lds_bytes(s->nu, s->N) : s->W == 32 ? solve_dw_lds_bytes(s->nu, s->N) : solve_d_lds_bytes(s->nu, s->N, s->tables_const());
-        *lds_bytes = (int)l;
-    }
-    if (tables_in_lds) *tables_in_lds = (s->tables_in_lds && !s->layout_c) ? 1 : 0;  // layout C keeps its table entries in registers
-    return TINYMPC_OK;
-}
 
-int tinympc_get_layout(tinympc_solver *s) {
-    if (!s) return 0;
-    if (s->layout_m) return 'M';
-    if (s->use_layout_d()) return 'D';
-    if (s->use_layout_e()) return 'E';
-    if (s->use_layout_f()) return 'F';
-    // the families and adaptive rho have kernels of their own on layout A's plan (the families also in the latency kernel)
-    if (s->families_active()) return (s->fam_c && family_structure(s).nround <= 1) ? 'C' : 'A';
-    if (s->st.adaptive_rho) return 'A';
-    return s->layout_c ? 'C' : s->layout_b ? 'B' : 'A';
-}
 
-int tinympc_prepare(tinympc_solver *s) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if ((rc = bind_device(s))) return rc;
-    decide_layout_d_variants(s);
-    if ((rc = decide_layout_e(s))) return rc;
-    return decide_layout_f(s);
-}
 
-int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if (!buf || len < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "get_jit_info: buffer required");
-    buf[0] = '\0';
-    const bool fam = s->families_active(), adaptive = s->st.adaptive_rho != 0;
-    if (s->layout_m) snprintf(buf, (size_t)len, "compiled-in layout=M");
-    else if (!s->f_sig.empty() && !adaptive && !s->use_layout_d() && !s->use_layout_e()) solve_f_describe(s->nx, s->nu, s->N, s->tables_const(), fam, s->f_fs, buf, (size_t)len);
-    else if (!s->e_sig.empty() && !adaptive && !s->use_layout_d()) solve_e_describe(s->nx, s->nu, s->N, s->tables_const(), fam, s->fs, buf, (size_t)len);
-    else if (s->use_layout_d() && !(s->d_jit || fam || adaptive || (!s->tables_const() && s->d_varying_jit))) snprintf(buf, (size_t)len, "compiled-in layout=D");
-    else if (s->layout_d || s->d_jit || s->d_jit_asked) {
-        if ((rc = bind_device(s))) return rc;
-        solve_jit_describe(s->W, s->nx, s->nu, s->N, s->tables_const(), fam && !adaptive, adaptive && !fam, buf, (size_t)len);
-    } else snprintf(buf, (size_t)len, "compiled-in layout=%c", (char)tinympc_get_layout(s));
-    return TINYMPC_OK;
-}
 
 #ifdef TINY_CLOCK_STAMP
 // Diagnostic build only (not part of the ABI): the stamp records of the last layout-D launch, 8 values per wavefront (see the

@@ -1,0 +1,227 @@
+// tinympc_handle.h -- the solver handle behind the C ABI (include/tinympc_hip.h) and the host-side helpers its translation units
+// share:  tinympc_capi.hip (the verbs), tinympc_handle.hip (buffers, derived tables, the families' description),
+//         tinympc_plan.hip (WHICH kernel a launch runs -- one LaunchPlan, chosen in one function -- and the launch itself),
+//         tinympc_session.hip (the resident closed-loop session).
+// Host-side bookkeeping only: every number the solver produces is computed by the kernels; there is no CPU fallback anywhere.
+#pragma once
+#include "tinympc_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "tinympc_device.h"
+#include "tinympc_host.h"
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return tinympc::fail(TINYMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                 __FILE__, __LINE__);                                                     \
+    } while (0)
+
+namespace tinympc {
+
+struct Settings {  // TinySettings (types.hpp:61-74) + the newer flags (bindings.cpp:583-586)
+    double abs_pri_tol, abs_dua_tol;
+    int max_iter, check_termination;
+    int en_state_bound, en_input_bound;
+    int en_state_soc, en_input_soc, en_state_linear, en_input_linear;
+    int adaptive_rho;
+    double adaptive_rho_min, adaptive_rho_max;
+    int adaptive_rho_enable_clipping;
+};
+
+constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
+// Every pinned buffer the kernels and the host exchange data through WHILE a kernel runs (completion flags, the session
+// mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
+// GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
+constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
+constexpr int kLayoutEBatchMin = 260;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
+                                        // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
+constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four
+                                       // wavefronts per workgroup passes the latency kernel between 512 and 1,024 instances)
+
+
+}  // namespace tinympc
+
+struct tinympc_solver {
+    int nx = 0, nu = 0, N = 0, batch = 0, device = 0;
+    int W = 0, KT = 0, IPW = 0, groups = 0;
+    double rho = 0.0;
+    tinympc::Settings st{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // problem + cache
+    double *dA = nullptr, *dB = nullptr, *dfdyn = nullptr, *dQd = nullptr, *dRd = nullptr;
+    double *dKinf = nullptr, *dPinf = nullptr, *dQuu = nullptr, *dAmBKt = nullptr, *dAPf = nullptr, *dBPf = nullptr;
+    double *dscratch = nullptr;
+    int *dinfo = nullptr;
+    // the .m class's own Riccati helpers (compute_cache_terms / solve_lqr / compute_sensitivity_autograd)
+    double *dQfull = nullptr, *dRfull = nullptr, *dlqr_scratch = nullptr, *dlqr_out = nullptr;  // dlqr_out: 3 x cache_doubles()
+    // adaptive rho: sensitivities dKinf/drho, dPinf/drho (zeros until set), kernel tables, per-instance rho
+    double *ddK = nullptr, *ddP = nullptr, *dadapt = nullptr, *drho_inst = nullptr;
+    size_t cache_doubles() const { return (size_t)nu * nx + (size_t)2 * nx * nx + (size_t)nu * nu; }  // K | P | C1 | C2
+    // user-layout bounds / refs
+    double *dxmin = nullptr, *dxmax = nullptr, *dumin = nullptr, *dumax = nullptr, *dXref = nullptr, *dUref = nullptr;
+    // derived
+    double *dops = nullptr, *dtables = nullptr;
+    bool ops_dirty = true, tables_dirty = true;
+    // per-instance state
+    double *dx0 = nullptr, *dG = nullptr, *dV = nullptr, *dD = nullptr, *dsolx = nullptr, *dsolu = nullptr;
+    int *distats = nullptr;
+    double *ddstats = nullptr;
+    size_t lds_bytes = 0;
+    bool tables_in_lds = false;
+    bool layout_b = false;  // 4-wave workgroups, V as an HBM ping-pong pair (tinympc_solve_b.hip)
+    bool layout_c = false;  // one instance per workgroup, horizon swept in concurrent chunks (tinympc_solve_c.hip)
+    // Horizon unrolled at compile time, state in registers, two waves per SIMD (tinympc_solve_d.hip). Wanted for large
+    // batches of a shape that is compiled in; each launch still checks that bounds / references are time-invariant and
+    // that no family / adaptive rho is active, and otherwise runs the layout-B (or A) kernel on the same HBM state.
+    bool layout_d = false;
+    bool d_jit = false;     // ... as a run-time specialisation (tinympc_jit.hip) rather than a compiled-in instantiation
+    bool d_jit_asked = false;  // the specialiser was asked for the box kernel at setup (its answer may have been a refusal)
+    // Large systems, 64 < nx+nu <= 128: tiles of 16 instances on the FP64 matrix cores, state streamed from HBM in the tile's
+    // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
+    // adaptive rho / session.
+    bool layout_m = false;
+    bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
+    int d_adapt = -1;       // ... and with adaptive rho
+    int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
+    int d_varying = -1;     // layout D with bounds / references that vary over the horizon: -1 not asked yet, 0 no, 1 yes
+    // Layout E (tinympc_solve_e.hip, run-time specialised on the families' STRUCTURE): the horizon cut across the wavefronts of a
+    // workgroup -- the throughput kernel for the families at horizons layout D cannot hold. Decided per launch
+    // (decide_layout_variants): `e_sig` is the structure / table kind the answer `e_ok` belongs to.
+    tinympc::FamilyStructure fs;
+    std::string e_sig;
+    bool e_ok = false;
+    int e_chunk_len = 0, e_wpg = 0;
+    size_t e_lds = 0;
+    // Layout F (tinympc_solve_f.hip): the latency kernel as a run-time specialisation (shape, chunk plan and the families'
+    // structure compiled in); decided per launch like layout E
+    std::string f_sig;
+    bool f_ok = false;
+    tinympc::FamilyStructure f_fs;
+    int f_chunk_len = 0, f_chunks = 0, f_wpg = 0;
+    size_t f_lds = 0;
+    double *dctab_f = nullptr;   // Phi^(S..4S) | Psi^(S..4S) for layout F's chunk length
+    int dctab_f_len = 0;
+    double *dclock = nullptr;    // (diagnostic build TINY_CLOCK_STAMP only) per-wavefront clock stamps of the last launch
+    double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
+    int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)
+    // every row of the bounds / references is the same at all knots (what the verbs last received; defaults are)
+    bool xmin_const = true, xmax_const = true, umin_const = true, umax_const = true, xref_const = true, uref_const = true;
+    bool tables_const() const { return xmin_const && xmax_const && umin_const && umax_const && xref_const && uref_const; }
+    bool zero_copy_tick = false;  // this launch reads x0 from / writes u0 to pinned host memory (mpc_step, small batches)
+    bool c_tables = false;  // the chunk tables exist (layout C is possible for this shape and not excluded)
+    bool fam_c = false;     // the cone / linear families run in the latency kernel's FAM variant
+    int chunk_len = 0, chunk_count = 0, chunk_levels = 0;
+    size_t lds_bytes_c = 0;
+    double *dctab = nullptr;
+    double *dV2 = nullptr;
+    int n_cone_x = 0, n_cone_u = 0, n_lin_x = 0, n_lin_u = 0;
+    // cone / linear families (host copies of what the verbs received; k_admm_solve_fam consumes `dfam`)
+    std::vector<int> Acx, qcx, Acu, qcu;
+    std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
+    double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
+    double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch (and x0 of single-instance handles)
+    // Single-instance handles (batch == 1, what the MEX shim creates): set_x0 only fills the pinned h_x0, the next
+    // launch reads it from there (and mirrors it into dx0), and the kernels also write solution + statistics into the
+    // pinned h_sol -- the reference's per-tick sequence set_x0 / solve / get_solution then costs ONE launch and ONE
+    // synchronisation instead of three synchronous copies around the launch.
+    double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
+    // Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks
+    // from this mailbox in pinned memory (layout: SolveParams::mail).
+    double *h_mail = nullptr;          // [64]
+    bool session_active = false;
+    // references re-sent inside a session that turned out to be the previous ones moved up by one knot (receding horizon):
+    // only the new last column travels, with the command (flags 4 / 8); two shifts without a step in between, or any other
+    // change, fall back to the full re-read (refs_on_host)
+    bool xref_shift = false, uref_shift = false;
+    bool session_refs_shifted = false;  // the device copies / tables lag behind the pinned references
+    // ONE counter stamps session commands and flag-raising launches alike (both complete by writing their stamp into the
+    // same slot of h_sol: a launch after a session must not find its number already there)
+    unsigned long long session_seq = 0;  // stamp of the last session command / flag-raising launch
+    bool flag_pending = false;
+    // ... and set_x_ref / set_u_ref only fill these pinned copies; the next launch's workgroup rebuilds the
+    // reference-dependent table rows from them (refresh_reference_tables): a tick with per-tick references
+    // (rocket_landing_constraints.m:86-121) is still one launch and one synchronisation.
+    double *h_xref = nullptr, *h_uref = nullptr;
+    bool refs_on_host = false;         // the pinned references are newer than dXref / dUref and the tables
+    bool x0_on_host = false;           // h_x0 is newer than dx0
+    int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
+    bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d && !layout_m; }  // (layout D writes to device memory only)
+    bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
+    double *dscratch_state = nullptr;
+    bool fam_dirty = true;
+    size_t lds_bytes_a = 0;       // layout-A LDS plan (the families kernel always uses layout A)
+    bool tables_in_lds_a = false;
+
+    bool use_layout_d() const {
+        return layout_d && (tables_const() || d_varying == 1) && (!families_active() || d_fam == 1) && (!st.adaptive_rho || d_adapt == 1);
+    }
+    bool use_layout_e() const { return e_ok && !st.adaptive_rho && !use_layout_d(); }
+    bool use_layout_f() const { return f_ok && !st.adaptive_rho && !use_layout_d() && !use_layout_e(); }
+    bool families_active() const {
+        return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
+               (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
+    }
+    std::vector<void *> allocs;
+
+    size_t X() const { return (size_t)nx * N; }
+    size_t U() const { return (size_t)nu * (N - 1); }
+    size_t state_doubles() const { return layout_m ? tinympc::solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N + 1) * 64; }  // G; row N: per-lane dummy slot
+    size_t v_doubles() const { return layout_m ? tinympc::solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * tinympc::v_rows(N) * 64; }     // V (and V2)
+    size_t d_doubles() const { return layout_m ? tinympc::solve_m_state_doubles(nx, nu, N, groups) : (size_t)groups * (N - 1) * IPW * nu; }
+};
+
+namespace tinympc {
+namespace host {
+
+template <typename T>
+int dalloc(tinympc_solver *s, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
+    if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", sizeof(T) * count, hipGetErrorString(e));
+    s->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return TINYMPC_OK;
+}
+
+// ---- tinympc_handle.hip
+int bind_device(tinympc_solver *s);   // every verb that touches the device passes through here first (ends an open session)
+bool rows_constant(const double *m, int rows, int cols);
+int upload(tinympc_solver *s, double *dst, const double *src, size_t count);
+int download(tinympc_solver *s, void *dst, const void *src, size_t bytes);
+int fill_host_upload(tinympc_solver *s, double *dst, size_t count, double value);
+int check_handle(const tinympc_solver *s);
+int run_precompute(tinympc_solver *s);
+int flush_host_refs(tinympc_solver *s);
+int refresh_derived(tinympc_solver *s);
+FamilyStructure family_structure(const tinympc_solver *s, double *mu = nullptr);
+int refresh_families(tinympc_solver *s);
+void destroy(tinympc_solver *s);
+
+// ---- tinympc_plan.hip: the kernel of a launch, decided in ONE place
+enum class KernelId { M, D_COMPILED, D_JIT, E, F, C, FAM_A, ADAPT_A, B, A };
+struct LaunchPlan {
+    KernelId kernel = KernelId::A;
+    char layout = 'A';                       // what tinympc_get_layout reports
+    bool families = false, adaptive = false;  // variant bits of the launch
+    bool jit = false;                        // a run-time specialisation (tinympc_jit.hip) rather than a compiled-in kernel
+    bool host_exchange = false;              // the kernel serves the pinned-host paths (x0 in, solution / completion stamp out)
+    int workgroups = 0;
+    size_t lds_bytes = 0;
+    bool tables_in_lds = false;
+};
+LaunchPlan current_plan(const tinympc_solver *s);  // from what has been decided so far (compiles nothing)
+int resolve_plan(tinympc_solver *s);               // decide (and, where needed, specialise) the variants of the current configuration
+int launch(tinympc_solver *s, bool timed);
+
+// ---- tinympc_session.hip
+int end_session(tinympc_solver *s);
+
+}  // namespace host
+}  // namespace tinympc

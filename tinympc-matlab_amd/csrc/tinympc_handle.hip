@@ -1,0 +1,261 @@
+// tinympc_handle.hip -- host-side helpers of the solver handle (tinympc_handle.h): device buffers and copies, the lazily rebuilt
+// operators / per-knot tables, the per-lane description of the cone / linear families. No solver arithmetic happens here.
+#include "tinympc_handle.h"
+
+#include <cstdarg>
+#include <cstring>
+#include <limits>
+
+namespace tinympc {
+
+std::string &last_error_slot() {
+    thread_local std::string slot;
+    return slot;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+
+namespace host {
+
+// Every verb that touches the device passes through here first: a resident session kernel would make it wait forever
+// on the handle's stream, so the session is ended (its state is in HBM after every tick) before anything else happens.
+int bind_device(tinympc_solver *s) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->session_active) return end_session(s);
+    return TINYMPC_OK;
+}
+
+// true if every row of the column-major rows x cols matrix holds one value (bit-wise; inf == inf)
+bool rows_constant(const double *m, int rows, int cols) {
+    for (int c = 1; c < cols; ++c)
+        for (int r = 0; r < rows; ++r)
+            if (!(m[r + (size_t)c * rows] == m[r])) return false;
+    return true;
+}
+
+int upload(tinympc_solver *s, double *dst, const double *src, size_t count) {
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // the caller keeps ownership of src: copy completes inside the call
+    return TINYMPC_OK;
+}
+
+int download(tinympc_solver *s, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
+int fill_host_upload(tinympc_solver *s, double *dst, size_t count, double value) {
+    std::vector<double> h(count, value);
+    return upload(s, dst, h.data(), count);
+}
+
+int check_handle(const tinympc_solver *s) {
+    if (!s) return fail(TINYMPC_ERR_NOT_INITIALIZED, "Solver not initialized");
+    return TINYMPC_OK;
+}
+
+int run_precompute(tinympc_solver *s) {
+    PrecomputeParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.rho = s->rho;
+    p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
+    p.Kinf = s->dKinf; p.Pinf = s->dPinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
+    p.info = s->dinfo; p.scratch = s->dscratch;
+    p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
+    HIP_TRY(launch_precompute(p, s->stream));
+    s->ops_dirty = true;
+    s->tables_dirty = true;
+    return TINYMPC_OK;
+}
+
+// References left in pinned host memory by set_x_ref / set_u_ref -> device copies, the ordinary way.
+int flush_host_refs(tinympc_solver *s) {
+    int rc;
+    if ((rc = upload(s, s->dXref, s->h_xref, s->X()))) return rc;
+    if (s->U() && (rc = upload(s, s->dUref, s->h_uref, s->U()))) return rc;
+    s->refs_on_host = false;
+    s->tables_dirty = true;
+    return TINYMPC_OK;
+}
+
+int refresh_derived(tinympc_solver *s) {
+    if (s->ops_dirty) {
+        OperatorParams p{};
+        p.nx = s->nx; p.nu = s->nu; p.W = s->W; p.KT = s->KT;
+        p.A = s->dA; p.B = s->dB; p.fdyn = s->dfdyn; p.Qd = s->dQd; p.Rd = s->dRd;
+        p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
+        p.ops = s->dops;
+        HIP_TRY(launch_build_operators(p, s->stream));
+        if (s->c_tables) {  // powers of the sweep operators for the chunked kernel
+            ChunkTableParams c{};
+            c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->chunk_len; c.Lc = s->chunk_levels;
+            c.ops = s->dops; c.out = s->dctab;
+            HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        }
+        s->dctab_e_len = 0;  // (layout E's and F's carry matrices are rebuilt on demand, below)
+        s->dctab_f_len = 0;
+        s->ops_dirty = false;
+        s->tables_dirty = true;
+    }
+    if (s->e_ok && s->dctab_e && s->dctab_e_len != s->e_chunk_len) {  // Phi^S, Psi^S for layout E's chunk length
+        ChunkTableParams c{};
+        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->e_chunk_len; c.Lc = 1;
+        c.ops = s->dops; c.out = s->dctab_e;
+        HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        s->dctab_e_len = s->e_chunk_len;
+    }
+    if (s->f_ok && s->dctab_f && s->dctab_f_len != s->f_chunk_len) {  // powers S .. 4S for layout F's chunk length
+        ChunkTableParams c{};
+        c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->f_chunk_len; c.Lc = 4;
+        c.ops = s->dops; c.out = s->dctab_f;
+        HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        s->dctab_f_len = s->f_chunk_len;
+    }
+    if (s->tables_dirty) {
+        TableParams p{};
+        p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.W = s->W; p.KT = s->KT;
+        p.en_state_bound = s->st.en_state_bound; p.en_input_bound = s->st.en_input_bound;
+        p.x_min = s->dxmin; p.x_max = s->dxmax; p.u_min = s->dumin; p.u_max = s->dumax;
+        p.Xref = s->dXref; p.Uref = s->dUref; p.Pinf = s->dPinf; p.ops = s->dops; p.tables = s->dtables;
+        HIP_TRY(launch_build_tables(p, s->stream));
+        s->tables_dirty = false;
+    }
+    return TINYMPC_OK;
+}
+
+// The ACTIVE cones in list order (state cones, then input cones) with their rounds, and the linear rows per side: what layout E
+// is specialised on (FamilyStructure, tinympc_device.h). `mu` receives the slopes in the same order.
+FamilyStructure family_structure(const tinympc_solver *s, double *mu) {
+    FamilyStructure fs;
+    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
+    unsigned long long used = 0;  // lanes taken by the cones of the current round
+    auto add = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
+        if (!on) return;
+        for (size_t k = 0; k < Ac.size() && fs.ncone < MAX_CONES; ++k) {
+            const int first = base + Ac[k], last = first + qc[k] - 1;
+            unsigned long long lanes = 0;
+            for (int r = first; r <= last; ++r) lanes |= 1ull << (r & 63);
+            if (fs.ncone == 0) fs.nround = 1;
+            if (lanes & used) {  // overlaps an earlier cone of this round: upstream projects one after the other
+                fs.nround += 1;
+                used = 0;
+            }
+            used |= lanes;
+            fs.cone[fs.ncone][0] = fs.nround - 1;
+            fs.cone[fs.ncone][1] = first;
+            fs.cone[fs.ncone][2] = last;
+            if (mu) mu[fs.ncone] = c[k];
+            fs.ncone += 1;
+        }
+    };
+    add(cone_x, s->Acx, s->qcx, s->cx, 0);
+    add(cone_u, s->Acu, s->qcu, s->cu, s->nx);
+    fs.nlx = (s->st.en_state_linear && s->n_lin_x > 0) ? s->n_lin_x : 0;
+    fs.nlu = (s->st.en_input_linear && s->n_lin_u > 0) ? s->n_lin_u : 0;
+    return fs;
+}
+
+// Per-lane description of the cone / linear families for k_admm_solve_fam (layout: fam_doubles()).
+// Masks and user coefficients only -- no solver arithmetic happens here.
+int refresh_families(tinympc_solver *s) {
+    const int W = s->W, KT = s->KT, nx = s->nx, nu = s->nu, nxu = nx + nu;
+    if (!s->dfam) {
+        int rc;
+        if ((rc = dalloc(s, &s->dfam, fam_doubles(W, KT)))) return rc;
+        if ((rc = dalloc(s, &s->dGC, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dGL, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dLX, s->v_doubles()))) return rc;
+        HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
+        s->fam_dirty = true;
+    }
+    if (!s->fam_dirty) return TINYMPC_OK;
+    std::vector<double> f(fam_doubles(W, KT), 0.0);
+    double *role = f.data(), *mu = role + W, *famc = mu + W, *faml = famc + W;
+    double *Cn = faml + W, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT, *lin = Ty + (size_t)W * KT;
+    const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
+    const bool lin_x = s->st.en_state_linear && s->n_lin_x > 0, lin_u = s->st.en_input_linear && s->n_lin_u > 0;
+    for (int r = 0; r < nxu; ++r) {
+        const bool is_x = r < nx;
+        famc[r] = (is_x ? cone_x : cone_u) ? 1.0 : 0.0;
+        faml[r] = (is_x ? lin_x : lin_u) ? 1.0 : 0.0;
+        for (int k = 0; k < nxu; ++k)
+            if ((k < nx) == is_x) Ty[(size_t)r * KT + k] = 1.0;
+    }
+    // cones, round by round (family_structure: cones of one round are pairwise disjoint): round 0 into the arrays every kernel
+    // reads, later rounds -- they exist only where cones share rows -- behind them for the kernels that walk rounds
+    {
+        std::vector<double> cmu(MAX_CONES, 0.0);
+        const FamilyStructure fs = family_structure(s, cmu.data());
+        f[fam_nround_offset(W, KT)] = (double)(fs.nround > 0 ? fs.nround : 1);
+        for (int c = 0; c < fs.ncone; ++c) {
+            const int q = fs.cone[c][0], first = fs.cone[c][1], last = fs.cone[c][2];
+            double *rl = role, *m = mu, *cn = Cn, *ct = Ct;
+            if (q >= 1) {
+                rl = f.data() + fam_round_offset(W, KT, q);
+                m = rl + W;
+                cn = m + W;
+                ct = cn + (size_t)W * KT;
+            }
+            for (int r = first; r <= last; ++r) {
+                rl[r] = (r == last) ? 2.0 : 1.0;
+                m[r] = cmu[c];
+                for (int k = first; k < last; ++k) cn[(size_t)r * KT + k] = 1.0;
+                ct[(size_t)r * KT + last] = 1.0;
+            }
+        }
+    }
+    (void)cone_x;
+    (void)cone_u;
+    const int nlx = lin_x ? s->n_lin_x : 0, nlu = lin_u ? s->n_lin_u : 0;
+    const int nl = nlx > nlu ? nlx : nlu;
+    lin[0] = (double)nl;
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+        double *ak = lin + 1 + (size_t)(3 * k + 0) * W, *bk = ak + W, *nk = bk + W;
+        double nrm_x = 0.0, nrm_u = 0.0;
+        if (k < nlx) for (int c = 0; c < nx; ++c) { const double a = s->Alin_x[k + (size_t)c * s->n_lin_x]; nrm_x += a * a; }
+        if (k < nlu) for (int c = 0; c < nu; ++c) { const double a = s->Alin_u[k + (size_t)c * s->n_lin_u]; nrm_u += a * a; }
+        for (int r = 0; r < W; ++r) {
+            ak[r] = 0.0; bk[r] = inf; nk[r] = 1.0;
+            if (r < nx && k < nlx) { ak[r] = s->Alin_x[k + (size_t)r * s->n_lin_x]; bk[r] = s->blin_x[k]; nk[r] = nrm_x; }
+            if (r >= nx && r < nxu && k < nlu) { ak[r] = s->Alin_u[k + (size_t)(r - nx) * s->n_lin_u]; bk[r] = s->blin_u[k]; nk[r] = nrm_u; }
+        }
+    }
+    (void)family_structure(s, f.data() + fam_cone_mu_offset(W, KT));  // slopes of the active cones, in list order (layout E)
+    int rc = upload(s, s->dfam, f.data(), f.size());
+    if (rc) return rc;
+    s->fam_dirty = false;
+    return TINYMPC_OK;
+}
+
+void destroy(tinympc_solver *s) {
+    if (!s) return;
+    // teardown is best effort: errors here have nowhere useful to go
+    (void)hipSetDevice(s->device);
+    if (s->session_active) (void)end_session(s);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void *q : s->allocs) (void)hipFree(q);
+    if (s->h_sol) (void)hipHostFree(s->h_sol);
+    if (s->h_mail) (void)hipHostFree(s->h_mail);
+    if (s->h_xref) (void)hipHostFree(s->h_xref);
+    if (s->h_uref) (void)hipHostFree(s->h_uref);
+    if (s->h_x0) (void)hipHostFree(s->h_x0);
+    if (s->h_u0) (void)hipHostFree(s->h_u0);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // namespace host
+}  // namespace tinympc

@@ -1,0 +1,156 @@
+// tinympc_session.hip -- the closed-loop SESSION (tinympc_session_begin / _step / _end, include/tinympc_hip.h): the latency kernel of
+// layout C stays resident and takes its ticks from a mailbox in pinned host memory (SolveParams::mail) instead of being launched
+// per tick. Host side only: the mailbox protocol, the (re)start of the resident kernel, the verbs.
+#include "tinympc_handle.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
+using namespace tinympc;
+using namespace tinympc::host;
+
+namespace {
+
+// ---- closed-loop session ------------------------------------------------------------------------------------
+constexpr double kSessionIdleSeconds = 2.0;  // the resident kernel leaves on its own after this long without a command
+
+void write_command(tinympc_solver *s, int flags, const double *x0) {
+    // payload: 0 flags | x0 (nx) | new last column of x_ref (flag 4) | new last column of u_ref (flag 8); line l = [7 payload |
+    // stamp]. Payload before stamp, line by line (x86 keeps the order of stores; the fences keep the compiler from
+    // reordering them).
+    double pay[56];
+    int npay = 0;
+    pay[npay++] = (double)flags;
+    for (int i = 0; i < s->nx; ++i) pay[npay++] = x0 ? x0[i] : 0.0;
+    if (flags & 4) for (int i = 0; i < s->nx; ++i) pay[npay++] = s->h_xref[(size_t)(s->N - 1) * s->nx + i];
+    if (flags & 8) for (int i = 0; i < s->nu; ++i) pay[npay++] = s->h_uref[(size_t)(s->N - 2) * s->nu + i];
+    volatile double *m = s->h_mail;
+    const double stamp = (double)(++s->session_seq);
+    const int nlines = (npay + 6) / 7;
+    for (int l = 0; l < nlines; ++l) {
+        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = pay[q];
+        std::atomic_thread_fence(std::memory_order_release);
+        m[8 * l + 7] = stamp;
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+int launch_session_kernel(tinympc_solver *s) {
+    int rc = refresh_derived(s);
+    if (rc) return rc;
+    const bool fam = s->families_active();
+    if (fam && (rc = refresh_families(s))) return rc;
+    SolveParams p{};
+    p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = 1;
+    p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
+    p.rho = s->rho; p.abs_pri_tol = s->st.abs_pri_tol; p.abs_dua_tol = s->st.abs_dua_tol;
+    p.ops = s->dops; p.tables = s->dtables; p.x0 = s->dx0; p.x0_mirror = s->dx0;
+    p.groups = s->groups;
+    p.G = s->dG; p.V = s->dV; p.V2 = s->dV2; p.D = s->dD; p.sol_x = s->dsolx; p.sol_u = s->dsolu;
+    p.istats = s->distats; p.dstats = s->ddstats;
+    p.fam = s->dfam; p.GC = s->dGC; p.GL = s->dGL; p.LX = s->dLX;
+    p.const_tables = s->tables_const() ? 1 : 0;
+    p.host_sol = s->h_sol;
+    p.href_x = s->h_xref; p.href_u = s->h_uref; p.dXref = s->dXref; p.dUref = s->dUref; p.Pinf = s->dPinf;  // (re-read on request)
+    s->refs_on_host = false;  // the prologue stages them
+    s->xref_shift = s->uref_shift = false;
+    p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
+    p.families = fam ? 1 : 0;
+    p.mail = s->h_mail;
+    p.session_expect = (double)(s->session_seq + 1);
+    p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
+    HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
+    return TINYMPC_OK;
+}
+
+}  // namespace
+
+int tinympc::host::end_session(tinympc_solver *s) {
+    if (!s->session_active) return TINYMPC_OK;
+    write_command(s, 1, nullptr);  // stop
+    s->session_active = false;     // (before anything that could come back here)
+    if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
+    s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TINYMPC_OK;
+}
+
+extern "C" {
+
+int tinympc_session_begin(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;  // (ends a session that is still open)
+    if (!s->host_path() || !(s->layout_c || (s->families_active() && s->fam_c)))
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles on the latency kernel only (batch 1, nx+nu <= 16, N <= 129)");
+    if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
+    if (s->families_active() && s->chunk_len > 4)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
+    if (s->families_active() && family_structure(s).nround > 1)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows are not supported by the resident kernel");
+    if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
+    if (!s->h_mail) {
+        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
+        std::memset(s->h_mail, 0, sizeof(double) * 64);
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = launch_session_kernel(s))) return rc;
+    s->session_active = true;
+    s->flag_pending = false;
+    return TINYMPC_OK;
+}
+
+int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
+    if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
+    HIP_TRY(hipSetDevice(s->device));  // (the restart path below launches; a multi-GPU caller may have another device current)
+    int flags = 0;
+    if (s->refs_on_host) flags = 2;  // full re-read (covers any pending shift: the pinned copies are current)
+    else flags = (s->xref_shift ? 4 : 0) | (s->uref_shift ? 8 : 0);
+    if (flags & 12) s->session_refs_shifted = true;
+    s->refs_on_host = s->xref_shift = s->uref_shift = false;
+    write_command(s, flags, x0);
+    const volatile double *done = s->h_sol + s->X() + s->U() + 6;
+    double want = (double)s->session_seq;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        if (*done == want) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0xffff) {
+            // Nothing for a while: has the kernel left (idle time-out)? Then start it again; it waits for exactly the
+            // command that is pending. A stream error or 30 s without an answer end the session with an error.
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) {
+                // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
+                // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
+                rc = launch_session_kernel(s);  // waits for session_seq + 1
+                if (rc) { s->session_active = false; return rc; }
+                write_command(s, 0, x0);
+                want = (double)s->session_seq;
+            } else if (q != hipErrorNotReady) {
+                s->session_active = false;
+                return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
+            }
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
+                (void)end_session(s);
+                return fail(TINYMPC_ERR_HIP, "session_step: no answer from the resident kernel within 30 s");
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->host_sol_state = 2;
+    std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
+    return TINYMPC_OK;
+}
+
+int tinympc_session_end(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    return end_session(s);
+}
+
+}  // extern "C"

@@ -30,7 +30,7 @@ def build():
     hipcc = "/opt/rocm/bin/hipcc"
     objs = []
     for src in ge.HIP_SOURCES:
-        if src in ("tinympc_solve_d.hip", "tinympc_capi.hip"):
+        if src in ("tinympc_solve_d.hip", "tinympc_capi.hip", "tinympc_plan.hip"):
             obj = os.path.join(OUT, src.replace(".hip", ".o"))
             extra = [a for a in sys.argv[2:] if a.startswith("-D")]  # (experiments: -DTINY_PRIO_SHIFT=.. -DTINY_PRIO_EVERY=.. -DTINY_PRIO_OFF)
             cmd = [hipcc] + ge.HIP_CFLAGS + ["-DTINY_CLOCK_STAMP=1"] + extra + ["-c", os.path.join(ge.CSRC, src), "-o", obj]
