@@ -59,7 +59,6 @@ def test_plan_table(pkg, monkeypatch, case):
     extra = dict(adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0) if variant == "adaptive" else {}
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=getattr(prob, "fdyn", None), **settings, **extra)
     s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-    orc = O.OraclePort(prob)
     if variant in ("families", "overlap"):
         if variant == "overlap":
             prob.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.2, 0.3], Acu=[0], qcu=[3], cu=[0.25])
@@ -87,7 +86,7 @@ def test_plan_table(pkg, monkeypatch, case):
         assert info["workgroups"] == workgroups, (name, info)
     s.solve()
     assert s.launch_info()["layout"] == layout
-    orc = orc.load_problem(prob, settings)
+    orc = O.OraclePort(prob).load_problem(prob, settings)  # (the checker takes the families from `prob` when it is constructed)
     if variant == "adaptive":
         orc.set_adaptive_rho(True, 0.2, 40.0, True)
         orc.set_sensitivity(dK, dP)
