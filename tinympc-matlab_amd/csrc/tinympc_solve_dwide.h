@@ -1,0 +1,421 @@
+// tinympc_solve_dwide.h -- layout D for WIDE systems, ONE body for both widths: W = 32 lanes per instance (16 < nx+nu <= 32, two
+// instances per wavefront; front end tinympc_solve_dw.hip, chain blocks tinympc_solve_dw_chain.h) and W = 64 (32 < nx+nu <= 64,
+// one instance per wavefront; tinympc_solve_dx.hip, tinympc_solve_dx_chain.h). (Round 2 kept two copies of this body, 80 %
+// line-identical.)
+//
+// Same plan as tinympc_solve_d.hip -- horizon a compile-time constant, both sweeps fully unrolled, the duals g|y in registers
+// (2*(N-1)+2 VGPRs), the slack v|z split between registers and LDS, LDS otherwise only for the feed-forward d and one copy
+// of the two sweep operators per workgroup, <= 256 VGPRs -> two wavefronts per SIMD -- and the same reference semantics
+// (per-instance termination, `iter % check_termination`, solution = vnew / znew, stale v|z after a converged solve:
+// admm.cpp:109-207). What differs is the mat-vec: an instance spans W / 16 DPP rows, so each step first replicates the operand
+// vector across them (cross-row swaps, tinympc_sweep.h) and then runs the fused DPP chain in W / 16 blocks of 16 columns -- the
+// width-specific part, behind WideStep<W, NX, NU> (defined by the front ends from their chain headers):
+//   Operand                                    the replicated operand vector (2 or 4 registers)
+//   replicate(w, op)                           cross-row swaps
+//   fwd_head(op, m, cf) -> a                   a = cf + the first blocks of the chain
+//   fwd_tail_reg / fwd_tail_lds(a, op, ...)    the last block + the row-local phase (slack in a register / in LDS)
+//   bwd(a, op, ...), bwd_last(a, op, m)        the backward step (+ the tail that prepares the next ones)
+#pragma once
+#include <type_traits>
+
+#include "tinympc_device.h"
+#include "tinympc_sweep.h"
+
+namespace tinympc {
+
+template <int W, int NX, int NU>
+struct WideStep;  // specialised per (W, nx, nu) by tinympc_solve_dw.hip / tinympc_solve_dx.hip
+
+namespace {
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for_w(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_w<I + 1, E>(f);
+    }
+}
+
+constexpr int WIDE_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
+constexpr int WIDE_LDS_PER_CU = 160 * 1024;
+// ---- LDS plan per workgroup, in doubles: operators [2][W k][W r] | tables (!ct) | per wave: V[VL][64], D[(N-1) * (64 / W) * nu]
+__host__ __device__ constexpr int wide_ops_doubles(int W) { return 2 * W * W; }
+__host__ __device__ constexpr int wide_d_doubles(int W, int nu, int N) { return ((N - 1) * (64 / W) * nu + 1) & ~1; }
+__host__ __device__ constexpr int wide_tab_doubles(int W, int N) { return 3 * (N + 2) * W + W; }  // the workgroup's copy of the per-knot tables (!CT)
+// number of slack slots in LDS; -1 if the shape does not fit the plan (cu_waves wavefronts per CU: 8, or 4 with 512 registers each)
+__host__ __device__ constexpr int wide_vl(int W, int vreg_max, int nu, int N, bool ct, int wpg, int cu_waves = 8) {
+    const int ns = N - 1;
+    const int wg_doubles = WIDE_LDS_PER_CU / 8 * wpg / cu_waves - wide_ops_doubles(W) - (ct ? 0 : wide_tab_doubles(W, N));
+    const int wave_doubles = wg_doubles / wpg - wide_d_doubles(W, nu, N);
+    if (wave_doubles < 0) return -1;
+    const int vlmax = wave_doubles / 64;
+    const int want = ns > vreg_max ? ns - vreg_max : 0;
+    return want <= vlmax ? want : -1;
+}
+__host__ __device__ constexpr size_t wide_lds_bytes(int W, int nu, int N, bool ct, int wpg, int vl) {
+    return sizeof(double) * ((size_t)wide_ops_doubles(W) + (ct ? 0 : wide_tab_doubles(W, N)) + (size_t)wpg * (vl * 64 + wide_d_doubles(W, nu, N)));
+}
+
+typedef __attribute__((address_space(3))) double lds_double_w;
+__device__ __forceinline__ unsigned lds_addr_w(const double *p) { return (unsigned)(size_t)(const lds_double_w *)p; }
+template <int OFF>
+__device__ __forceinline__ double lds_read_async_w(unsigned addr) {  // the value is valid after the next s_waitcnt lgkmcnt(0)
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_async_w(unsigned addr, double v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_masked_w(unsigned addr, double v, unsigned long long mask) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "ds_write_b64 %[a], %[v] offset:%[o]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved)
+                 : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ void lds_wait_w() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the lanes that
+// are still iterating. True if some live instance (W lanes) has no bad lane.
+template <int W>
+__device__ __forceinline__ bool wave_may_converge_w(unsigned long long bad, unsigned long long live) {
+    constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 64 / W; ++j) {
+        const unsigned long long b = (bad >> (j * W)) & ones, l = (live >> (j * W)) & ones;
+        any = any || (l != 0ull && b == 0ull);
+    }
+    return any;
+}
+}  // namespace
+
+template <int W, int NX, int NU, int N, bool CT, int WPG, int VL>
+__device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, double *smem) {
+    constexpr int IPW = 64 / W, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
+    constexpr int KT = W;  // row stride of p.ops (choose_geometry)
+    constexpr int TOFF = (N + 2) * W;
+    static_assert((W == 32 || W == 64) && NS >= 3 && VL >= 0 && VL <= NS && NXU > W / 2 && NXU <= W, "wide layout D: N >= 4, W / 2 < nx+nu <= W");
+    using Step = WideStep<W, NX, NU>;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane / W, r = lane % W;
+    const long grp = (long)blockIdx.x * WPG + wv;
+    const bool grp_ok = grp < p.groups;
+    const long inst = grp * IPW + j;
+    const bool is_x = r < NX;
+    const bool is_u = (r >= NX) && (r < NXU);
+    const bool inst_ok = grp_ok && inst < p.batch;
+    const int koff = is_x ? 1 : 0;  // slot s = knot s+1 on state lanes, knot s on input lanes
+
+    double *sOps = smem;
+    double *sT = smem + wide_ops_doubles(W);
+    double *sV = sT + (CT ? 0 : wide_tab_doubles(W, N)) + (size_t)wv * (VL * 64 + wide_d_doubles(W, NU, N));
+    double *sD = sV + VL * 64;
+
+    // ---- workgroup-shared: the two sweep operators, transposed to [k][r] (conflict-free row reads), and the tables
+    for (int i = threadIdx.x; i < wide_ops_doubles(W); i += 64 * WPG) {
+        const int which = i / (W * W), k = (i / W) % W, rr = i % W;
+        sOps[i] = p.ops[(size_t)which * W * KT + (size_t)rr * KT + k];
+    }
+    if constexpr (!CT)
+        for (int i = threadIdx.x; i < wide_tab_doubles(W, N); i += 64 * WPG) sT[i] = p.tables[i];
+
+    const size_t g0 = grp_ok ? (size_t)grp : 0;
+    double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
+    double *const gD = p.D + g0 * (size_t)(NS * DS);
+    double *const gV0 = p.V + (g0 * v_rows(N) + V_PAD) * 64 + lane;    // canonical v|z, knot 0
+    double *const gV1u = p.V2 + (g0 * v_rows(N) + V_PAD) * 64;         // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset)
+    const unsigned voff = (unsigned)(lane + koff * 64);
+    double *const sVl = sV + lane;
+    if (grp_ok) {
+        for (int i = lane; i < NS * DS; i += 64) sD[i] = gD[i];
+        static_for_w<0, VL>([&](auto S) { sVl[S.value * 64] = gV0[(S.value + koff) * 64]; });
+    }
+    __syncthreads();  // the only workgroup-wide barrier: from here on the waves are independent
+    if (!grp_ok) return;
+
+    // ---- register-resident state
+    double G[NS], G0, Vr[NVR > 0 ? NVR : 1], V0;
+    static_for_w<0, NS>([&](auto S) { G[S.value] = gG[(S.value + koff) * 64]; });
+    static_for_w<0, NVR>([&](auto S) { Vr[S.value] = gV0[(VL + S.value + koff) * 64]; });
+    G0 = gG[0];
+    V0 = gV0[0];
+
+    const double cf = p.ops[(size_t)2 * W * KT + r];
+    const double cb = p.ops[(size_t)2 * W * KT + W + r];
+    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    const double rho = p.rho, nrho = -p.rho;
+    const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
+    const double rhom = is_x ? nrho : 0.0;
+    const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+    const int dIdx = j * NU + (is_u ? r - NX : 0);
+    const double *const sDr = sD + dIdx;
+    double *const sDw = sD + dIdx;
+    const double *const sTl = sT + koff * W + r;  // (!CT) row of slot s: sTl[(s + 1) * W]
+    const double *const sMf = sOps + r, *const sMb = sOps + W * W + r;
+    const unsigned aV = lds_addr_w(sVl), aD = lds_addr_w(sDr), aT = lds_addr_w(sTl);
+    const int ct = p.check_termination;
+
+    // Control: an instance that converges stops being `active` but its lanes keep iterating as a zombie (the sweeps are
+    // unconditional for all 64 lanes -- no EXEC-masked region around the unrolled body). Its state is written back at
+    // the top of the next round, before the next forward sweep touches G and V; the backward sweep in between leaves
+    // G and V alone and skips a zombie's d. Instances that hit max_iter are written back by the same code in round
+    // `max_iter`, which does nothing else.
+    bool active = inst_ok;
+    bool pending = false;  // converged in the previous round: state not yet written back
+    int it_done = 0;
+    int status = 11;  // TINY_UNSOLVED (admm.cpp:114)
+    bool res_valid = false;
+    double snap_pri = 0.0, snap_dua = 0.0;
+
+    auto load_ops = [&](const double *src, double (&m)[W]) {
+        static_for_w<0, W>([&](auto K) { m[K.value] = src[(K.value < NXU ? K.value : 0) * W]; });
+    };
+    auto vget = [&](auto S) -> double {
+        if constexpr (decltype(S)::value >= VL) return Vr[decltype(S)::value - VL];
+        else return sVl[decltype(S)::value * 64];
+    };
+
+    const int simd_slot = simd_slot_id();
+    const int max_iter = p.max_iter;
+    for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129
+        // (readfirstlane: keeps the loop counter and everything derived from it in SGPRs, so that the branches below
+        // are scalar branches and not EXEC-masked regions)
+        const int it0 = __builtin_amdgcn_readfirstlane(it);
+        const bool final_round = it0 >= max_iter;
+        fair_share_priority<(W / 16) * NS>(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
+        // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
+        // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
+        const bool wb = pending || (final_round && active);
+        if (__ballot(wb) != 0ull) {
+            // Rare path (once per instance and solve), kept small in registers rather than fast: addresses are rebuilt
+            // here from the kernel arguments (the opaque copy of `lane` keeps the compiler from hoisting them out of
+            // the iteration loop, where they would occupy registers the unrolled sweeps need).
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int r_o = lane_o % W, j_o = lane_o / W;
+            const bool x_o = r_o < NX;
+            if (wb && r_o < NXU) {
+                const int ko = x_o ? 1 : 0;
+                const size_t inst_o = (size_t)grp * IPW + j_o;
+                double *const wG = p.G + (size_t)grp * (N + 1) * 64 + lane_o + ko * 64;                // slot 0
+                double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;   // slot 0
+                double *const wS = x_o ? p.sol_x + (inst_o * N + 1) * NX + r_o : p.sol_u + inst_o * NS * NU + (r_o - NX);  // slot 0
+                const int sst = x_o ? NX : NU;
+                if (x_o) {  // knot 0
+                    wG[-64] = G0;
+                    wV[-64] = V0;
+                    wS[-NX] = V0;
+                }
+                static_for_w<0, NS>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    const double vn = vget(S);
+                    wG[s * 64] = G[s];
+                    wV[s * 64] = vn;
+                    wS[s * sst] = vn;
+                });
+                if (!x_o) {
+                    double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
+                    for (int i = 0; i < NS; ++i) wD[i * DS] = sDw[i * DS];
+                }
+            }
+            pending = false;
+        }
+        if (final_round || __ballot(active) == 0ull) break;
+        const int it1 = it0 + 1;
+        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91 (iter already incremented, :143)
+
+        double pri = 0.0, dua = 0.0;
+        bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
+        double m[W];
+        load_ops(sMf, m);
+        // ---------------- knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
+        {
+            const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
+            if (may && is_x) gV1u[(unsigned)lane] = V0;
+            const double s = x0v + G0;
+            const double snew = fmin(hi0, fmax(lo0, s));
+            G0 = s - snew;
+            pri = is_x ? fabs(x0v - snew) : 0.0;
+            dua = is_x ? fabs(V0 - snew) : 0.0;
+            V0 = snew;
+        }
+        // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
+        // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
+        // PREVIOUS step's block and retired by that block's trailing s_waitcnt.
+        double xcur = x0v;
+        double dcur = lds_read_async_w<0>(aD), vcur = 0.0;
+        if constexpr (VL > 0) vcur = lds_read_async_w<0>(aV);
+        // (!CT: bounds that vary over the horizon come from the workgroup's LDS copy of the tables, one step ahead like d)
+        double locur = lo_c, hicur = hi_c;
+        if constexpr (!CT) {
+            locur = lds_read_async_w<W * 8>(aT);
+            hicur = lds_read_async_w<(TOFF + W) * 8>(aT);
+        }
+        lds_wait_w();
+        auto fstep = [&](auto S) {
+            constexpr int q = decltype(S)::value;
+            double dn = 0.0, vn = 0.0, lon = lo_c, hin = hi_c;
+            if constexpr (q + 1 < NS) dn = lds_read_async_w<(q + 1) * DS * 8>(aD);
+            if constexpr (q + 1 < VL) vn = lds_read_async_w<(q + 1) * 512>(aV);
+            if constexpr (!CT && q + 1 < NS) {
+                lon = lds_read_async_w<(q + 2) * W * 8>(aT);
+                hin = lds_read_async_w<(TOFF + (q + 2) * W) * 8>(aT);
+            }
+            // operand vector [x_q; d_q]: one entry per lane, replicated across the instance's two DPP rows
+            typename Step::Operand op;
+            Step::replicate(is_x ? xcur : dcur, op);  // the operand vector on every DPP row of the instance
+            double a = Step::fwd_head(op, m, cf);
+            if constexpr (q >= VL) {
+                Step::fwd_tail_reg(a, op, m, locur, hicur, G[q], Vr[q - VL], pri, dua);
+            } else {
+                double vnew;
+                Step::fwd_tail_lds(a, op, m, locur, hicur, G[q], vcur, vnew, pri, dua);
+                lds_write_async_w<q * 512>(aV, vnew);
+            }
+            xcur = a;
+            dcur = dn;
+            vcur = vn;
+            if constexpr (!CT) {
+                locur = lon;
+                hicur = hin;
+            }
+        };
+        constexpr int NG = (NS + WIDE_GROUP - 1) / WIDE_GROUP;
+        static_for_w<0, NG>([&](auto Gi) {
+            constexpr int s0 = Gi.value * WIDE_GROUP, s1 = (s0 + WIDE_GROUP < NS) ? s0 + WIDE_GROUP : NS;
+            if (may) {
+                // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
+                // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does
+                // not keep one pointer per slot alive across the iteration loop.
+                if constexpr (s0 > 0) {
+                    const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                    may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_w<W>(__ballot(bad), __ballot(active))) != 0;
+                }
+                if (may) {
+                    unsigned vo = voff;
+                    double *base = gV1u;
+                    asm volatile("" : "+v"(vo), "+s"(base));
+                    static_for_w<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
+                }
+            }
+            static_for_w<s0, s1>([&](auto S) { fstep(S); });
+        });
+        if (active) it_done = it1;  // admm.cpp:143
+
+        // ---------------- R1: termination (admm.cpp:93-101), decided element-wise: one ballot, no reductions
+        if (check) {
+            const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
+            constexpr unsigned long long ones = (W == 64) ? ~0ull : ((1ull << (W % 64)) - 1ull);
+            const bool conv = ((__ballot(below) >> (j * W)) & ones) == ones;
+            if (active) {
+                snap_pri = pri;
+                snap_dua = dua;
+                res_valid = true;
+                if (conv) {
+                    status = 1;  // TINY_SOLVED: this instance stops before the backward pass (admm.cpp:181-192)
+                    active = false;
+                    pending = true;
+                }
+            }
+        }
+
+        // ---------------- backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) recomputed from V, G
+        {
+            const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
+            load_ops(sMb, m);
+            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type)
+                if constexpr (CT) return lr_c;
+                else return sTl[2 * TOFF + (S.value + 1) * W];
+            };
+            double px, rcur, rnext, acc;
+            {   // p_{N-1} (state lanes, admm.cpp:81-82) | r_{N-2} (input lanes) share slot NS-1; then slot NS-2
+                const double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
+                const double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
+                const double lrmc2 = is_x ? lr2 + cb : cb;
+                const double v1 = vget(std::integral_constant<int, NS - 1>{}), v2 = vget(std::integral_constant<int, NS - 2>{});
+                double t;
+                asm("v_add_f64 %[t], %[v1], -%[g1]\n\t"
+                    "v_fma_f64 %[px], %[nrho], %[t], %[lrT]\n\t"
+                    "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+                    "v_fma_f64 %[acc], %[rhom], %[t], %[lrmc]\n\t"
+                    "v_fma_f64 %[rn], %[nrho], %[t], %[lr]"
+                    : [t] "=&v"(t), [px] "=&v"(px), [acc] "=&v"(acc), [rn] "=&v"(rnext)
+                    : [v1] "v"(v1), [g1] "v"(G[NS - 1]), [v2] "v"(v2), [g2] "v"(G[NS - 2]), [nrho] "s"(nrho), [lrT] "v"(lrT),
+                      [rhom] "v"(rhom), [lrmc] "v"(lrmc2), [lr] "v"(lr2));
+                rcur = px;
+            }
+            // slack operand of a block's tail: a register, or an LDS read issued one block ahead
+            auto vreq = [&](auto S) -> double {
+                if constexpr (decltype(S)::value >= VL) return Vr[decltype(S)::value - VL];
+                else return lds_read_async_w<decltype(S)::value * 512>(aV);
+            };
+            double v2cur = vreq(std::integral_constant<int, (NS >= 3 ? NS - 3 : 0)>{});
+            lds_wait_w();
+            static_for_w<0, NS - 1>([&](auto I) {
+                constexpr int s = NS - 1 - I.value;           // NS-1 .. 1
+                constexpr int s2 = s >= 2 ? s - 2 : 0;        // slot feeding the tail (s = 1: any finite t will do)
+                constexpr int s3 = s >= 3 ? s - 3 : 0;        // ... of the next block
+                // (an asynchronous read MUST be consumed after its wait: the destination of a dead one would be handed to
+                // the block's outputs while the read is still in flight)
+                double v2n = 0.0;
+                if constexpr (s >= 2) v2n = vreq(std::integral_constant<int, s3>{});
+                const double lr2 = lr_of(std::integral_constant<int, s2>{});
+                const double lrmc2 = is_x ? lr2 + cb : cb;
+                double a = acc, an, rn;
+                typename Step::Operand op;
+                Step::replicate(is_x ? px : rcur, op);  // [p_{s+1}; r_s]
+                Step::bwd(a, op, m, v2cur, G[s2], rhom, lrmc2, nrho, lr2, an, rn);
+                lds_write_masked_w<s * DS * 8>(aD, a, wr_d);  // d_s
+                px = a;
+                rcur = rnext;
+                rnext = rn;
+                acc = an;
+                v2cur = v2n;
+            });
+            {
+                double a = acc;
+                typename Step::Operand op;
+                Step::replicate(is_x ? px : rcur, op);
+                Step::bwd_last(a, op, m);
+                lds_write_masked_w<0>(aD, a, wr_d);  // d_0
+            }
+        }
+    }
+    lds_wait_w();
+
+    // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
+    // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
+    if (inst_ok && status == 1 && r < NXU) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const int rows = is_x ? N : NS;
+        double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane;
+        const double *const wV2 = p.V2 + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane;
+        for (int kn = 0; kn < rows; ++kn) wV[kn * 64] = wV2[kn * 64];
+    }
+
+    const double res_px = group_max<W>(is_x ? snap_pri : 0.0), res_pu = group_max<W>(is_u ? snap_pri : 0.0);
+    const double res_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, res_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
+
+    if (inst_ok && r == 0) {
+        p.istats[inst * 2 + 0] = it_done;
+        p.istats[inst * 2 + 1] = status;
+        if (res_valid) {
+            p.dstats[inst * 4 + 0] = res_px;
+            p.dstats[inst * 4 + 1] = res_dx;
+            p.dstats[inst * 4 + 2] = res_pu;
+            p.dstats[inst * 4 + 3] = res_du;
+        }
+    }
+}
+
+}  // namespace tinympc
