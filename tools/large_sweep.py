@@ -15,7 +15,10 @@ import pyoracle as O  # noqa: E402  (checker)
 pkg = g.load_package()
 P = pkg.problems
 ITERS = 50
-for nx, nu, N, batch in ((60, 10, 20, 4096), (96, 32, 20, 1024), (96, 32, 20, 4096), (96, 32, 20, 8192), (112, 16, 30, 4096)):
+SHAPES = ((60, 10, 20, 4096), (96, 32, 20, 1024), (96, 32, 20, 4096), (96, 32, 20, 8192), (112, 16, 30, 4096))
+if "--one" in sys.argv:
+    SHAPES = ((96, 32, 20, 4096),)
+for nx, nu, N, batch in SHAPES:
     rng = np.random.default_rng(nx)
     A = np.eye(nx) * 0.98 + 0.015 * rng.standard_normal((nx, nx))
     B = 0.08 * rng.standard_normal((nx, nu))
