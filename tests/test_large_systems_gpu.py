@@ -1,6 +1,6 @@
-"""Large systems, 64 < nx+nu <= 128 (the reference takes any nx, nu: types.hpp:16-17): the step of sixteen instances is a
+"""Large systems, 64 < nx+nu <= 256 (the reference takes any nx, nu: types.hpp:16-17): the step of sixteen instances is a
 GEMM on the FP64 matrix cores (tinympc_solve_m.hip, v_mfma_f64_16x16x4_f64), the ADMM state streams through HBM in the
-tile's own layout. Against the oracle: caches, per-instance termination inside a tile, ragged last tile, warm starts after
+tile's own layout; beyond 128 rows a wavefront owns two row tiles and streams its operator tiles from L2. Against the oracle: caches, per-instance termination inside a tile, ragged last tile, warm starts after
 converged and unconverged solves, bounds and references that vary over the horizon."""
 from __future__ import annotations
 
@@ -73,6 +73,42 @@ def test_large_systems_match_the_oracle(pkg, nx, nu, N, varying):
                 ob = orc[b].stats()
                 np.testing.assert_allclose(st["residuals"][:, b], [ob["pri_x"], ob["dua_x"], ob["pri_u"], ob["dua_u"]], rtol=1e-6, atol=1e-10)
         s.reset()
+
+
+@pytest.mark.parametrize("nx,nu,N,varying", [(130, 14, 6, False), (160, 32, 8, True), (224, 32, 5, False)])
+def test_systems_beyond_128_rows(pkg, nx, nu, N, varying):
+    """R = 9, 12, 16 row tiles: two per wavefront, operator tiles streamed (the nx=160, nu=32 case). One oracle per
+    checked instance (first tile, tile edge, ragged last tile); cold start and two warm starts."""
+    prob = _system(pkg, nx, nu, N, nx + nu, varying)
+    rng = np.random.default_rng(7)
+    prob.A = 0.95 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))  # (spectral radius ~ 1: see the edge-width test below)
+    batch = 19
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.02, 1.2, batch)[None, :]
+    checked = (0, 15, 16, batch - 1)
+    for settings in (dict(max_iter=150, abs_pri_tol=1e-3, abs_dua_tol=1e-3), dict(max_iter=20, abs_pri_tol=0.0, abs_dua_tol=0.0, check_termination=3)):
+        s = _solver(pkg, prob, settings, batch)
+        assert s.launch_info()["layout"] == "M"
+        c = s.get_cache()
+        orc = {b: O.OraclePort(prob).load_problem(prob, settings) for b in checked}
+        for n in ("Kinf", "Pinf", "Quu_inv", "AmBKt"):
+            assert rel_err(c[n], orc[0].get(n)) < 1e-9, n
+        for rnd in range(3):
+            xs = x0s * (1.0 - 0.35 * rnd)
+            s.set_x0_batch(xs)
+            s.solve()
+            sol, st = s.get_solution_batch(), s.get_stats_batch()
+            for b in checked:
+                orc[b].set_x0(xs[:, b])
+                orc[b].solve()
+                ob = orc[b].stats()
+                assert st["iter"][b] == ob["iter"] and st["status"][b] == ob["status"], (rnd, b)
+                assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL, (rnd, b)
+                assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+                np.testing.assert_allclose(st["residuals"][:, b], [ob["pri_x"], ob["dua_x"], ob["pri_u"], ob["dua_u"]], rtol=1e-6, atol=1e-10)
+        s.reset()
+    with pytest.raises(pkg.TinyMPCError) as ei:  # beyond 256 rows: refused, and says so
+        pkg.TinyMPC().setup(np.eye(250), np.ones((250, 8)), np.eye(250), np.eye(8), 5, batch=1)
+    assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
 def test_large_system_single_instance_and_unsupported_features(pkg):

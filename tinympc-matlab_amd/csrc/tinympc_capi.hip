@@ -35,9 +35,9 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     int W = 0, KT = 0;
     const bool large = solve_m_supported(nx, nu);
     if (large) {
-        W = KT = 128;  // geometry of the operators / tables; the kernel works on 16-instance tiles
+        W = KT = solve_m_geometry(nx, nu);  // geometry of the operators / tables (128, or 256 beyond 128 rows); the kernel works on 16-instance tiles
     } else if (!choose_geometry(nx, nu, &W, &KT)) {
-        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d: systems beyond 128 rows are not supported by this build", nx + nu);
+        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d: systems beyond 256 rows are not supported by this build", nx + nu);
     }
     int ndev = tinympc_device_count();
     if (ndev < 1) return fail(TINYMPC_ERR_NO_DEVICE, "no HIP device visible: the HIP path has no CPU fallback");
@@ -167,6 +167,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
     TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));
     if (s->c_tables) TRY(dalloc(s, &s->dctab, chunk_table_doubles(nx, s->chunk_levels)));
+    if (large && solve_m_tiled_ops_doubles(nx, nu)) TRY(dalloc(s, &s->dctab, solve_m_tiled_ops_doubles(nx, nu)));  // layout M beyond 128 rows: tile-major operators
     TRY(dalloc(s, &s->dlqr_scratch, lqr_scratch_doubles(nx, nu) + 8)); TRY(dalloc(s, &s->dlqr_out, 3 * s->cache_doubles()));
     TRY(dalloc(s, &s->dxmin, X)); TRY(dalloc(s, &s->dxmax, X)); TRY(dalloc(s, &s->dumin, U)); TRY(dalloc(s, &s->dumax, U));
     TRY(dalloc(s, &s->dXref, X)); TRY(dalloc(s, &s->dUref, U));

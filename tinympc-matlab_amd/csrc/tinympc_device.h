@@ -305,6 +305,9 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cach
 
 // Large systems (64 < nx+nu <= 128) on the FP64 matrix cores, 16 instances per tile (tinympc_solve_m.hip)
 bool solve_m_supported(int nx, int nu);
+int solve_m_geometry(int nx, int nu);
+size_t solve_m_tiled_ops_doubles(int nx, int nu);  // beyond 128 rows: the tile-major copy of the operators the kernel streams (0 otherwise)
+hipError_t launch_tile_operators_m(const double *ops, double *out, int nx, int nu, hipStream_t stream);  // W = KT of the operators / tables of a large system: 128, or 256 beyond 128 rows
 size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with

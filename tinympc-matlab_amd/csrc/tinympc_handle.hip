@@ -94,6 +94,7 @@ int refresh_derived(tinympc_solver *s) {
         p.Kinf = s->dKinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
         p.ops = s->dops;
         HIP_TRY(launch_build_operators(p, s->stream));
+        if (s->layout_m && s->dctab) HIP_TRY(launch_tile_operators_m(s->dops, s->dctab, s->nx, s->nu, s->stream));  // (beyond 128 rows)
         if (s->c_tables) {  // powers of the sweep operators for the chunked kernel
             ChunkTableParams c{};
             c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->chunk_len; c.Lc = s->chunk_levels;

@@ -280,6 +280,7 @@ int launch(tinympc_solver *s, bool timed) {
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     switch (pl.kernel) {
         case KernelId::M:
+            p.ctab = s->dctab;  // (beyond 128 rows: the tile-major copy of the operators; NULL otherwise)
             HIP_TRY(launch_solve_m(p, s->stream));
             break;
         case KernelId::D_JIT:  // (box path, families with everything in registers, or adaptive rho per lane)

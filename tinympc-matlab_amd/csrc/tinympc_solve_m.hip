@@ -1,4 +1,4 @@
-// tinympc_solve_m.hip -- k_admm_solve_m ("layout M"): LARGE systems, 64 < nx+nu <= 128, on the FP64 matrix cores.
+// tinympc_solve_m.hip -- k_admm_solve_m ("layout M"): LARGE systems, 64 < nx+nu <= 256, on the FP64 matrix cores.
 //
 // Same algorithm as the other solve kernels (tinympc_solve.hip has the reference citations: M1 solve admm.cpp:109-207 = F1
 // :25-35, S1 :43-59, D1 :65-69, L1 :75-83, R1 :89-107, C1 :196-197, B1 :13-20). Up to 64 rows an instance fits the lanes of
@@ -50,23 +50,39 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles) {
     const int R = (nx + nu + 15) / 16;
     return (size_t)tiles * N * m_knot_doubles(R);
 }
-bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 128 && nx >= 1 && nu >= 1; }
+bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 256 && nx >= 1 && nu >= 1; }
+// geometry (W = KT) of the operators and tables these sizes are built with
+__host__ __device__ constexpr int m_geometry(int R) { return R > 8 ? 256 : 128; }
+int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 
-// CT: bounds and references are the same at every knot (p.const_tables): they are served from a 3 KB LDS copy instead of
+// CT: bounds and references are the same at every knot (p.const_tables): they are served from an LDS copy instead of
 // the L2-resident per-knot tables -- 24 L2 round trips less behind every GEMM. (A compile-time switch: as a run-time one it
 // pushed the kernel over its register file. Likewise, requesting the state a whole step ahead instead of right before the
 // step's own GEMM, and interleaving two instance tiles per workgroup over shared operator tiles, both cost more in spills
-// than they hid in latency.)
+// than they hid in latency; round 3's software-pipelined form is in tools/experiments, its measurements in
+// profiles/r03_large_m_experiments.txt.)
+//
+// R <= 8 (nx+nu <= 128): one row tile per wavefront, its operator tiles register-resident (above).
+// R = 9..16 (nx+nu <= 256, round 3): TWO row tiles per wavefront (t = w and w + 8), handled one after the other inside a step --
+// state in, GEMM, row-local phase, state out, twice, then the one barrier -- and the operator tiles STREAMED from L2 a batch
+// ahead of the matrix instructions that consume them: 2 x 4R doubles per lane no longer fit any register file, but a step
+// reads each operator tile once per workgroup (<= 512 KB per operator, L2-resident) while the matrix pipe works 2 x 4R x 64
+// cycles on it, so the stream costs bandwidth the kernel has (the state streams through HBM at a lower rate per flop than at
+// R <= 8: arithmetic intensity ~ nxu / 20).
 template <int R, bool CT>
 __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
-    constexpr int KB = 4 * R;  // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
+    constexpr int KB = 4 * R;            // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
+    constexpr int TPW = R > 8 ? 2 : 1;   // row tiles per wavefront
+    constexpr bool STREAM = R > 8;       // operator tiles from L2 instead of registers
+    constexpr int GW = m_geometry(R);    // ops / tables geometry of these sizes: W = KT
     __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
     __shared__ unsigned sFlag[2][M_WAVES];                          // per-wave "instance still below tolerance" masks
-    __shared__ double sTab[CT ? 3 : 1][128];                        // CT: lo | hi | linref of every row
+    __shared__ double sTab[CT ? 3 : 1][GW];                         // CT: lo | hi | linref of every row
+    __shared__ double sC[STREAM ? 2 : 1][STREAM ? GW : 1];          // two row tiles per wavefront: the sweep constants cf | cb
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (an SGPR: branches on it are scalar branches, not EXEC-masked regions)
     const int nx = p.nx, nu = p.nu, N = p.N, nxu = nx + nu, T = N - 1;
-    const int W = 128, KT = 128;  // ops / tables geometry of these sizes (choose_geometry_m)
+    const int W = GW, KT = GW;
     const long tile = blockIdx.x;
     const int jn = lane & 15, kq = lane >> 4;  // instance within the tile, row within a k-block / result quad
     const long inst = tile * M_INST + jn;
@@ -80,69 +96,93 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     double *const gVb = p.V2 + (size_t)tile * N * KD;
     double *const gD = p.D + (size_t)tile * N * KD;
 
-    // this wave's result entries: e = 0..3 <-> reg = e, row = 16 wv + kq + 4 e. Rows and their kind are recomputed from
-    // `rowbase` where they are needed (cheap integer work) instead of living in masks.
-    const int rowbase = 16 * wv + kq;
-    const bool has_tile = (R == M_WAVES) || wv < R;  // (uniform) this wave owns a row tile
-    auto row_of = [&](int e) -> int { return rowbase + 4 * e; };
-    auto kind_of = [&](int e) -> int { const int r = row_of(e); return !has_tile ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
-    auto slot = [&](int e) -> unsigned { return (unsigned)((4 * wv + e) * 64 + lane); };  // offset of entry e inside a knot
-    bool isx[4], isu[4];
-    int kx[4];  // state rows own knot i + 1 of step i, input rows knot i
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        isx[e] = kind_of(e) == 1;
-        isu[e] = kind_of(e) == 2;
-        kx[e] = isx[e] ? 1 : 0;
-    }
+    // this wave's result entries of its row tile tw (t = wv + 8 tw): e = 0..3 <-> reg = e, row = 16 t + kq + 4 e. Rows and their
+    // kind are recomputed from the tile index where they are needed (cheap integer work) instead of living in masks.
+    auto tile_of = [&](int tw) -> int { return wv + M_WAVES * tw; };
+    auto has_tile = [&](int tw) -> bool { return (R == M_WAVES * TPW) || tile_of(tw) < R; };  // (uniform) this wave owns row tile tw
+    auto row_of = [&](int tw, int e) -> int { return 16 * tile_of(tw) + kq + 4 * e; };
+    auto kind_of = [&](int tw, int e) -> int { const int r = row_of(tw, e); return !has_tile(tw) ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
+    auto slot = [&](int tw, int e) -> unsigned { return (unsigned)((4 * tile_of(tw) + e) * 64 + lane); };  // offset of entry e inside a knot
+    auto is_x = [&](int tw, int e) -> bool { return kind_of(tw, e) == 1; };
+    auto is_u = [&](int tw, int e) -> bool { return kind_of(tw, e) == 2; };
+    auto k_x = [&](int tw, int e) -> int { return is_x(tw, e) ? 1 : 0; };  // state rows own knot i + 1 of step i, input rows knot i
     const double rho = p.rho;
     const int ct = p.check_termination;
     // lo / hi / linref of (row, knot): table row kn + 1
     if constexpr (CT) {
-        for (int i = tid; i < 3 * 128; i += 64 * M_WAVES) sTab[i / 128][i % 128] = p.tables[(unsigned)((i / 128) * TOFF + W + (i % 128))];
+        for (int i = tid; i < 3 * GW; i += 64 * M_WAVES) sTab[i / GW][i % GW] = p.tables[(unsigned)((i / GW) * TOFF + W + (i % GW))];
         __syncthreads();
     }
-    auto tab = [&](int which, int kn, int e) -> double {
-        if constexpr (CT) return sTab[which][row_of(e)];
-        else return p.tables[(unsigned)(which * TOFF + (kn + 1) * W + row_of(e))];  // (uniform base + 32-bit offset)
+    auto tab = [&](int which, int kn, int tw, int e) -> double {
+        if constexpr (CT) return sTab[which][row_of(tw, e)];
+        else return p.tables[(unsigned)(which * TOFF + (kn + 1) * W + row_of(tw, e))];  // (uniform base + 32-bit offset)
     };
     const double *const cf_tab = p.ops + (size_t)2 * W * KT, *const cb_tab = cf_tab + W;
-
-    // A tiles of the sweep operator `which` (0: Mf, 1: Mb), register-resident for one sweep
-    double A0[KB];
-    auto load_A = [&](int which) {
-        const double *M = p.ops + (size_t)which * W * KT;
+    if constexpr (STREAM) {
+        for (int i = tid; i < 2 * GW; i += 64 * M_WAVES) sC[i / GW][i % GW] = cf_tab[i];
+        __syncthreads();
+    }
+    // the constant term of a sweep's rows: in registers for the sweep (one row tile per wavefront), or from LDS at each step
+    double start0[4] = {0.0, 0.0, 0.0, 0.0};
+    auto load_start = [&](int which) {
+        if constexpr (!STREAM) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) A0[kb] = has_tile ? M[(size_t)(16 * wv + jn) * KT + 4 * kb + kq] : 0.0;
+            for (int e = 0; e < 4; ++e) start0[e] = kind_of(0, e) ? (which ? cb_tab : cf_tab)[row_of(0, e)] : 0.0;
+        }
     };
-    // out[e] = start[e] + (operator) * (operand vector in sX[buf]). Two accumulation chains per wavefront (even / odd
-    // k-blocks), i.e. four per SIMD: a dependent FP64 MFMA only issues when its predecessor has left the pipe.
-    auto gemm = [&](int buf, const double (&start)[4], double (&out)[4]) {
+    auto start_of = [&](int which, int tw, int e) -> double {
+        if constexpr (STREAM) return kind_of(tw, e) ? sC[which][row_of(tw, e)] : 0.0;
+        else return start0[e];
+    };
+
+    // A tiles of the sweep operator `which` (0: Mf, 1: Mb): register-resident for one sweep (R <= 8), or streamed (R > 8)
+    double A0[STREAM ? 1 : KB];
+    auto load_A = [&](int which) {
+        if constexpr (!STREAM) {
+            const double *M = p.ops + (size_t)which * W * KT;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) A0[kb] = has_tile(0) ? M[(size_t)(16 * wv + jn) * KT + 4 * kb + kq] : 0.0;
+        }
+    };
+    // out[e] = start[e] + (rows of tile tw of the operator) * (operand vector in sX[buf]). Two accumulation chains per wavefront
+    // (even / odd k-blocks), i.e. four per SIMD: a dependent FP64 MFMA only issues when its predecessor has left the pipe.
+    auto gemm = [&](int buf, int which, int tw, const double (&start)[4], double (&out)[4]) {
         double4_m c0 = {start[0], start[1], start[2], start[3]}, d0 = {0.0, 0.0, 0.0, 0.0};
-        if (has_tile) {
+        if (has_tile(tw)) {
             // operand reads run a batch of eight k-blocks ahead of the matrix instructions that consume them (left to the
             // scheduler they ran two ahead, and an MFMA issued every 78 cycles instead of every 64)
-            constexpr int BATCH = CT ? 8 : (R == 8 ? 2 : 4);  // (per-knot tables: fewer registers to spare)
+            constexpr int BATCH = STREAM ? (CT ? 8 : 4) : (CT ? 8 : (R == 8 ? 2 : 4));  // (per-knot tables: fewer registers to spare)
             static_assert(KB % 4 == 0, "k-blocks come in fours");
-            double b[2][BATCH];
+            double b[2][BATCH], a[2][STREAM ? BATCH : 1];
+            // (streamed: the tile-major copy of the operators, one 512-byte line per (row tile, k-block) -- read row-major, an
+            // instruction touched 16 rows x 32 bytes, every cache line came in four times and the stream ran at the L2 -> CU limit)
+            const double *Arow = p.ctab + ((size_t)(which * R + (STREAM ? tile_of(tw) : 0)) * KB) * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < BATCH; ++q) b[0][q] = q < KB ? sX[buf][q][lane] : 0.0;
+            for (int q = 0; q < BATCH; ++q) {
+                b[0][q] = q < KB ? sX[buf][q][lane] : 0.0;
+                if constexpr (STREAM) a[0][q] = q < KB ? Arow[64 * q] : 0.0;
+            }
 #pragma unroll
             for (int k0 = 0; k0 < KB; k0 += BATCH) {
                 const int cur = (k0 / BATCH) & 1;
 #pragma unroll
                 for (int q = 0; q < BATCH; ++q)
-                    if (k0 + BATCH + q < KB) b[cur ^ 1][q] = sX[buf][k0 + BATCH + q][lane];
+                    if (k0 + BATCH + q < KB) {
+                        b[cur ^ 1][q] = sX[buf][k0 + BATCH + q][lane];
+                        if constexpr (STREAM) a[cur ^ 1][q] = Arow[64 * (k0 + BATCH + q)];
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < BATCH; q += 2) {
                     if (k0 + q < KB) {
+                        const double a_e = STREAM ? a[STREAM ? cur : 0][STREAM ? q : 0] : A0[STREAM ? 0 : k0 + q];
+                        const double a_o = STREAM ? a[STREAM ? cur : 0][STREAM ? q + 1 : 0] : A0[STREAM ? 0 : k0 + q + 1];
 #if TINY_EXP_M == 2  // timing experiment: the operand reads without the matrix instructions
-                        c0[0] += A0[k0 + q] * b[cur][q];
-                        d0[0] += A0[k0 + q + 1] * b[cur][q + 1];
+                        c0[0] += a_e * b[cur][q];
+                        d0[0] += a_o * b[cur][q + 1];
 #else
-                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[k0 + q], b[cur][q], c0, 0, 0, 0);
-                        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[k0 + q + 1], b[cur][q + 1], d0, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_e, b[cur][q], c0, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_o, b[cur][q + 1], d0, 0, 0, 0);
 #endif
                     }
                 }
@@ -151,10 +191,6 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = c0[q] + d0[q];
-    };
-    // entry e of the next operand vector goes to k-block 4 t + reg, same lane
-    auto put = [&](int buf, int e, double v) {
-        if (has_tile) sX[buf][4 * wv + e][lane] = v;
     };
 
     bool active = inst_ok;      // (per lane: its instance is still iterating)
@@ -172,108 +208,88 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 
         // ================= forward sweep (F1) with S1 + D1 + R1 fused in =================
         load_A(0);
-        double start[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) start[e] = kind_of(e) ? cf_tab[row_of(e)] : 0.0;
+        load_start(0);
         // operand of step 0: [x_0; d_0]; and knot 0 of the state rows: x_0 is given, only projected
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int kd = kind_of(e);
-            double w = 0.0;
-            if (kd == 1) {
-                const double x0 = inst_ok ? p.x0[inst * nx + row_of(e)] : 0.0;
-                const double g = gG[slot(e)], vold = Vr[slot(e)];
-                const double s = x0 + g;
-                const double snew = fmin(tab(1, 0, e), fmax(tab(0, 0, e), s));
-                pri_x = fmax(pri_x, fabs(x0 - snew));
-                dua_x = fmax(dua_x, fabs(vold - snew));
-                if (active) {
-                    gG[slot(e)] = s - snew;
-                    Vw[slot(e)] = snew;
+        for (int tw = 0; tw < TPW; ++tw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kd = kind_of(tw, e);
+                double w = 0.0;
+                if (kd == 1) {
+                    const double x0 = inst_ok ? p.x0[inst * nx + row_of(tw, e)] : 0.0;
+                    const double g = gG[slot(tw, e)], vold = Vr[slot(tw, e)];
+                    const double s = x0 + g;
+                    const double snew = fmin(tab(1, 0, tw, e), fmax(tab(0, 0, tw, e), s));
+                    pri_x = fmax(pri_x, fabs(x0 - snew));
+                    dua_x = fmax(dua_x, fabs(vold - snew));
+                    if (active) {
+                        gG[slot(tw, e)] = s - snew;
+                        Vw[slot(tw, e)] = snew;
+                    }
+                    w = x0;
+                } else if (kd == 2) {
+                    w = gD[slot(tw, e)];
                 }
-                w = x0;
-            } else if (kd == 2) {
-                w = gD[slot(e)];
+                if (has_tile(tw)) sX[buf][4 * tile_of(tw) + e][lane] = w;
             }
-            put(buf, e, w);
         }
         __syncthreads();
         // The row-local operands of a step (dual, old slack, the next step's feed-forward entry) do not depend on its GEMM: they
         // are requested in front of it and arrive while the matrix cores work -- the state streams through HBM at these sizes
         // (the kernel without its MFMAs runs at the HBM roof), and a step that waited for its operands AFTER its MFMAs ran at
-        // a fifth of this speed. (Requesting them a whole step ahead, behind the previous step's row-local phase, was measured
-        // too: no faster, and it spills.)
+        // a fifth of this speed.
         // BRANCH-FREE on purpose: every lane of a wavefront that owns a row tile loads and stores all four of its entries
         // (padding rows have slots of their own; lanes without a feed-forward entry all read one dummy address). With the
         // loads inside `if (row is real)` regions the compiler put an s_waitcnt vmcnt(0) in front of every entry's address
         // arithmetic -- four serialised HBM round trips per step instead of one.
-        double pg[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0}, pd[4] = {0.0, 0.0, 0.0, 0.0};
-        auto fetch_fwd = [&](int i) {
-            if (has_tile && TINY_EXP_M != 1) {
+        for (int i = 0; i < T; ++i) {
+#pragma nounroll
+            for (int tw = 0; tw < TPW; ++tw) {  // (one copy of the code: unrolled, the second tile's addresses were hoisted and spilled)
+                if (!has_tile(tw)) continue;
+                double pg[4], pv[4], pd[4], start[4];
                 const bool more = i + 1 < T;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const unsigned o = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
-                    pg[e] = gG[o];
-                    pv[e] = Vr[o];
-                    pd[e] = gD[(isu[e] && more) ? (unsigned)((i + 1) * (int)KD) + slot(e) : 0u];
+                    start[e] = start_of(0, tw, e);
+                    if (TINY_EXP_M != 1) {
+                        const unsigned o = (unsigned)((i + k_x(tw, e)) * (int)KD) + slot(tw, e);
+                        pg[e] = gG[o];
+                        pv[e] = Vr[o];
+                        pd[e] = gD[(is_u(tw, e) && more) ? (unsigned)((i + 1) * (int)KD) + slot(tw, e) : 0u];
+                    } else {
+                        pg[e] = pv[e] = pd[e] = 0.0;
+                    }
                 }
-            }
-        };
-        for (int i = 0; i < T; ++i) {
-#if TINY_EXP_M == 3  // timing experiment: where does a forward step spend its cycles (tools/large_pmc.py prints the stamps)
-            const bool stamp = it == 5 && i == 7 && blockIdx.x == 1;
-            unsigned long long t_top = 0, t_gemm = 0, t_ops = 0, t_end = 0, t_bar = 0;
-            if (stamp) t_top = __builtin_readcyclecounter();
-#endif
-            fetch_fwd(i);
-            double out[4];
-            gemm(buf, start, out);  // state rows: x_{i+1}; input rows: u_i
-#if TINY_EXP_M == 3
-            if (stamp) { asm volatile("s_nop 0" :: "v"(out[0]), "v"(out[3])); t_gemm = __builtin_readcyclecounter(); }
-#endif
-            if (has_tile) {
+                double out[4];
+                gemm(buf, 0, tw, start, out);  // state rows: x_{i+1}; input rows: u_i
                 double gn[4], sn[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kn = i + kx[e];
+                    const int kn = i + k_x(tw, e);
                     const double s = out[e] + pg[e];
-                    const double snew = fmin(tab(1, kn, e), fmax(tab(0, kn, e), s));  // (bounds: LDS copy, or the L2-resident table)
+                    const double snew = fmin(tab(1, kn, tw, e), fmax(tab(0, kn, tw, e), s));  // (bounds: LDS copy, or the L2-resident table)
                     const double tp = fabs(out[e] - snew), td = fabs(pv[e] - snew);
-                    pri_x = fmax(pri_x, isx[e] ? tp : 0.0);
-                    dua_x = fmax(dua_x, isx[e] ? td : 0.0);
-                    pri_u = fmax(pri_u, isu[e] ? tp : 0.0);
-                    dua_u = fmax(dua_u, isu[e] ? td : 0.0);
+                    pri_x = fmax(pri_x, is_x(tw, e) ? tp : 0.0);
+                    dua_x = fmax(dua_x, is_x(tw, e) ? td : 0.0);
+                    pri_u = fmax(pri_u, is_u(tw, e) ? tp : 0.0);
+                    dua_u = fmax(dua_u, is_u(tw, e) ? td : 0.0);
                     gn[e] = s - snew;
                     sn[e] = snew;
-#if TINY_EXP_M == 3
-                    if (stamp && e == 3) { asm volatile("s_nop 0" :: "v"(gn[0]), "v"(gn[3])); t_ops = __builtin_readcyclecounter(); }
-#endif
                     // next operand: state rows carry x_{i+1}, input rows bring d_{i+1}, padding rows stay zero
-                    sX[buf ^ 1][4 * wv + e][lane] = isu[e] ? pd[e] : (isx[e] ? out[e] : 0.0);
+                    sX[buf ^ 1][4 * tile_of(tw) + e][lane] = is_u(tw, e) ? pd[e] : (is_x(tw, e) ? out[e] : 0.0);
                 }
                 if (active && TINY_EXP_M != 1) {  // (one masked region, stores only)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const unsigned o = (unsigned)((i + kx[e]) * (int)KD) + slot(e);
+                        const unsigned o = (unsigned)((i + k_x(tw, e)) * (int)KD) + slot(tw, e);
                         gG[o] = gn[e];
                         Vw[o] = sn[e];
                     }
                 }
             }
             buf ^= 1;
-#if TINY_EXP_M == 3
-            if (stamp) { asm volatile("s_nop 0" :: "v"(pri_x), "v"(dua_u)); t_end = __builtin_readcyclecounter(); }
-#endif
             lds_exchange_barrier();
-#if TINY_EXP_M == 3
-            if (stamp) {
-                t_bar = __builtin_readcyclecounter();
-                if (lane == 0)
-                    printf("wave %d: top %llu | gemm done +%llu | operands arrived, row-local math +%llu | stores issued, residuals +%llu | barrier +%llu\n", wv,
-                           t_top, t_gemm - t_top, t_ops - t_gemm, t_end - t_ops, t_bar - t_end);
-            }
-#endif
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
@@ -307,55 +323,57 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 
         // ================= backward sweep (B1, admm.cpp:13-20); linear cost (L1, :77-82) from V (just written), G =================
         load_A(1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) start[e] = kind_of(e) ? cb_tab[row_of(e)] : 0.0;
+        load_start(1);
         double *const Vn = par_read ? gVa : gVb;  // the slack written by this iteration's forward sweep
-        {   // operand of step N-2: [p_{N-1}; r_{N-2}]
+#pragma unroll
+        for (int tw = 0; tw < TPW; ++tw) {  // operand of step N-2: [p_{N-1}; r_{N-2}]
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int kd = kind_of(e);
+                const int kd = kind_of(tw, e);
                 double w = 0.0;
                 if (kd == 1) {
-                    const unsigned o = (unsigned)((N - 1) * (int)KD) + slot(e);
-                    w = p.tables[(size_t)3 * TOFF + row_of(e)] - rho * (Vn[o] - gG[o]);  // p_{N-1}, admm.cpp:81-82
+                    const unsigned o = (unsigned)((N - 1) * (int)KD) + slot(tw, e);
+                    w = p.tables[(size_t)3 * TOFF + row_of(tw, e)] - rho * (Vn[o] - gG[o]);  // p_{N-1}, admm.cpp:81-82
                 } else if (kd == 2) {
-                    const unsigned o = (unsigned)((N - 2) * (int)KD) + slot(e);
-                    w = tab(2, N - 2, e) - rho * (Vn[o] - gG[o]);  // r_{N-2}, admm.cpp:77-78
+                    const unsigned o = (unsigned)((N - 2) * (int)KD) + slot(tw, e);
+                    w = tab(2, N - 2, tw, e) - rho * (Vn[o] - gG[o]);  // r_{N-2}, admm.cpp:77-78
                 }
-                put(buf, e, w);
+                if (has_tile(tw)) sX[buf][4 * tile_of(tw) + e][lane] = w;
             }
         }
         __syncthreads();
         // q_i (state rows, knot i) and r_{i-1} (input rows, knot i-1) from V, G and the table: requested before the GEMM like the
         // forward operands (branch-free: padding rows and the input rows of step 0 load their own slot and drop it)
-        double lv[4] = {0.0, 0.0, 0.0, 0.0}, lg[4] = {0.0, 0.0, 0.0, 0.0};
-        auto fetch_bwd = [&](int i) {
-            if (has_tile && TINY_EXP_M != 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kn = (isu[e] && i >= 1) ? i - 1 : i;
-                    const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
-                    lv[e] = Vn[o];
-                    lg[e] = gG[o];
-                }
-            }
-        };
         for (int i = T - 1; i >= 0; --i) {
-            fetch_bwd(i);
-            double out[4];
-            gemm(buf, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
-            if (has_tile) {
+#pragma nounroll
+            for (int tw = 0; tw < TPW; ++tw) {
+                if (!has_tile(tw)) continue;
+                double lv[4], lg[4], start[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kn = (isu[e] && i >= 1) ? i - 1 : i;
-                    const bool real = isx[e] || (isu[e] && i >= 1);
-                    const double lin = (real && TINY_EXP_M != 1) ? tab(2, kn, e) - rho * (lv[e] - lg[e]) : 0.0;  // admm.cpp:77-80
-                    sX[buf ^ 1][4 * wv + e][lane] = isx[e] ? lin + out[e] : lin;                                   // p_i = q_i + ...
+                    start[e] = start_of(1, tw, e);
+                    if (TINY_EXP_M != 1) {
+                        const int kn = (is_u(tw, e) && i >= 1) ? i - 1 : i;
+                        const unsigned o = (unsigned)(kn * (int)KD) + slot(tw, e);
+                        lv[e] = Vn[o];
+                        lg[e] = gG[o];
+                    } else {
+                        lv[e] = lg[e] = 0.0;
+                    }
+                }
+                double out[4];
+                gemm(buf, 1, tw, start, out);  // state rows: AmBKt p_{i+1} - Kinf' r_i (+ APf); input rows: d_i
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kn = (is_u(tw, e) && i >= 1) ? i - 1 : i;
+                    const bool real = is_x(tw, e) || (is_u(tw, e) && i >= 1);
+                    const double lin = (real && TINY_EXP_M != 1) ? tab(2, kn, tw, e) - rho * (lv[e] - lg[e]) : 0.0;  // admm.cpp:77-80
+                    sX[buf ^ 1][4 * tile_of(tw) + e][lane] = is_x(tw, e) ? lin + out[e] : lin;                             // p_i = q_i + ...
                 }
                 if (active && TINY_EXP_M != 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (isu[e]) gD[(unsigned)(i * (int)KD) + slot(e)] = out[e];  // d_i (a converged instance keeps its last real d)
+                        if (is_u(tw, e)) gD[(unsigned)(i * (int)KD) + slot(tw, e)] = out[e];  // d_i (a converged instance keeps its last real d)
                 }
             }
             buf ^= 1;
@@ -365,26 +383,28 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 
     // ---- canonical slack: an instance that stopped at max_iter has v <- vnew (admm.cpp:196-197): the buffer `par` now points
     // at; a converged one keeps the previous iterate: the buffer it READ in its last iteration. Both must end up in p.V.
-    // Lanes remember: which buffer holds (a) the canonical slack, (b) the solution vnew (the one written last).
-    // par was flipped after every forward sweep this lane's instance took part in... but `par` is block-uniform, so track
-    // per lane through the iteration count instead: after k forward sweeps the last-written buffer is V2 if k is odd, V if even.
+    // `par` is block-uniform, so a lane goes by its own iteration count: after k forward sweeps the last-written buffer is V2 if
+    // k is odd, V if even.
     if (p.max_iter > 0 && inst_ok) {
         const bool last_written_is_b = (it_done & 1) != 0;
         double *const Vsol = last_written_is_b ? gVb : gVa;
         double *const Vold = last_written_is_b ? gVa : gVb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int kd = kind_of(e), rw = row_of(e);
-            if (kd == 0) continue;
-            const int knots = kd == 1 ? N : N - 1;
-            for (int kn = 0; kn < knots; ++kn) {
-                const unsigned o = (unsigned)(kn * (int)KD) + slot(e);
-                const double sol = Vsol[o];
-                if (kd == 1) p.sol_x[((size_t)inst * N + kn) * nx + rw] = sol;
-                else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (rw - nx)] = sol;
-                const double canon = (status == 1) ? Vold[o] : sol;
-                if (it_done > 0) {
-                    gVa[o] = canon;  // p.V is the canonical copy between solves (both stores are by this lane, in order)
+        for (int tw = 0; tw < TPW; ++tw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kd = kind_of(tw, e), rw = row_of(tw, e);
+                if (kd == 0) continue;
+                const int knots = kd == 1 ? N : N - 1;
+                for (int kn = 0; kn < knots; ++kn) {
+                    const unsigned o = (unsigned)(kn * (int)KD) + slot(tw, e);
+                    const double sol = Vsol[o];
+                    if (kd == 1) p.sol_x[((size_t)inst * N + kn) * nx + rw] = sol;
+                    else p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (rw - nx)] = sol;
+                    const double canon = (status == 1) ? Vold[o] : sol;
+                    if (it_done > 0) {
+                        gVa[o] = canon;  // p.V is the canonical copy between solves (both stores are by this lane, in order)
+                    }
                 }
             }
         }
@@ -416,6 +436,28 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     }
 }
 
+// Tile-major copy of the two sweep operators for R > 8 (see gemm): out[which][row tile t][k-block kb][lane] = the MFMA A operand
+// of that lane, M_which[16 t + (lane & 15)][4 kb + (lane >> 4)].
+__global__ void __launch_bounds__(256) k_tile_operators_m(const double *ops, double *out, int R, int KT) {
+    const size_t total = (size_t)2 * R * 4 * R * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const size_t blk = i >> 6;
+        const int kb = (int)(blk % (4 * R)), t = (int)((blk / (4 * R)) % R), which = (int)(blk / ((size_t)4 * R * R));
+        out[i] = ops[(size_t)which * KT * KT + (size_t)(16 * t + (lane & 15)) * KT + 4 * kb + (lane >> 4)];
+    }
+}
+size_t solve_m_tiled_ops_doubles(int nx, int nu) {
+    const int R = (nx + nu + 15) / 16;
+    return R > 8 ? (size_t)2 * R * 4 * R * 64 : 0;
+}
+hipError_t launch_tile_operators_m(const double *ops, double *out, int nx, int nu, hipStream_t stream) {
+    const int R = (nx + nu + 15) / 16;
+    if (R <= 8) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_operators_m, dim3(64), dim3(256), 0, stream, ops, out, R, m_geometry(R));
+    return hipGetLastError();
+}
+
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
     const int R = (p.nx + p.nu + 15) / 16;
     const int tiles = (p.batch + M_INST - 1) / M_INST;
@@ -429,6 +471,14 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
         TINY_M_LAUNCH(6)
         TINY_M_LAUNCH(7)
         TINY_M_LAUNCH(8)
+        TINY_M_LAUNCH(9)
+        TINY_M_LAUNCH(10)
+        TINY_M_LAUNCH(11)
+        TINY_M_LAUNCH(12)
+        TINY_M_LAUNCH(13)
+        TINY_M_LAUNCH(14)
+        TINY_M_LAUNCH(15)
+        TINY_M_LAUNCH(16)
         default: return hipErrorInvalidValue;
     }
 #undef TINY_M_LAUNCH
