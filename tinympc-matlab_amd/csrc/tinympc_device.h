@@ -86,6 +86,17 @@ struct TableParams {
     double *tables;
 };
 
+// Stamp of a session-mailbox line: the command's sequence number plus a 12-bit checksum of the line's seven payload words
+// (xor of their bit patterns, folded), as a fraction -- exact in a double for every sequence number below 2^40. Host and
+// kernel compute it the same way; the kernel accepts a line only if the stamp fits the payload it read with it.
+__host__ __device__ inline double mail_stamp(double seq, unsigned long long payload_xor) {
+    unsigned long long x = payload_xor;
+    x ^= x >> 32;
+    x ^= x >> 16;
+    x ^= x >> 8;
+    return seq + (double)(unsigned)(x & 0xfffull) * (1.0 / 4096.0);
+}
+
 struct SolveParams {
     int nx, nu, N, batch;
     int max_iter, check_termination;
@@ -137,8 +148,9 @@ struct SolveParams {
     // Closed-loop SESSION (tinympc_session_begin / _step / _end; layout C, single instance): the kernel stays resident
     // and polls a mailbox in pinned host memory for the next tick's command instead of being launched per tick. The
     // mailbox is an array of 64-byte lines [7 payload doubles | stamp]; payload 0 = flags (1: stop, 2: references changed),
-    // payloads 1.. = x0. The host writes a line's payload before its stamp, so a line whose stamp equals the expected
-    // sequence number is complete. NULL = an ordinary one-shot launch.
+    // payloads 1.. = x0. The host writes a line's payload before its stamp, and the stamp is mail_stamp(sequence number,
+    // payload): a line is complete when its stamp fits the expected sequence number AND the payload read with it.
+    // NULL = an ordinary one-shot launch.
     const double *mail;
     double session_expect;             // stamp of the first command to wait for
     unsigned long long session_idle;   // exit after this many 100 MHz ticks without a command (the exit every wave reaches)

@@ -18,7 +18,8 @@ constexpr double kSessionIdleSeconds = 2.0;  // the resident kernel leaves on it
 void write_command(tinympc_solver *s, int flags, const double *x0) {
     // payload: 0 flags | x0 (nx) | new last column of x_ref (flag 4) | new last column of u_ref (flag 8); line l = [7 payload |
     // stamp]. Payload before stamp, line by line (x86 keeps the order of stores; the fences keep the compiler from
-    // reordering them).
+    // reordering them); the stamp also carries a checksum of its line's payload, so that a reader which caught the line
+    // between two of these stores -- or torn in any other way -- rejects it and polls again.
     double pay[56];
     int npay = 0;
     pay[npay++] = (double)flags;
@@ -26,12 +27,19 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
     if (flags & 4) for (int i = 0; i < s->nx; ++i) pay[npay++] = s->h_xref[(size_t)(s->N - 1) * s->nx + i];
     if (flags & 8) for (int i = 0; i < s->nu; ++i) pay[npay++] = s->h_uref[(size_t)(s->N - 2) * s->nu + i];
     volatile double *m = s->h_mail;
-    const double stamp = (double)(++s->session_seq);
+    const double seq = (double)(++s->session_seq);
     const int nlines = (npay + 6) / 7;
+    for (int q = npay; q < 7 * nlines; ++q) pay[q] = 0.0;  // (every word of a used line is written: the stamp covers all seven)
     for (int l = 0; l < nlines; ++l) {
-        for (int q = 7 * l; q < 7 * l + 7 && q < npay; ++q) m[8 * l + q % 7] = pay[q];
+        unsigned long long x = 0ull;
+        for (int q = 7 * l; q < 7 * l + 7; ++q) {
+            m[8 * l + q % 7] = pay[q];
+            unsigned long long bits;
+            std::memcpy(&bits, &pay[q], sizeof bits);
+            x ^= bits;
+        }
         std::atomic_thread_fence(std::memory_order_release);
-        m[8 * l + 7] = stamp;
+        m[8 * l + 7] = tinympc::mail_stamp(seq, x);  // (sequence number + checksum of the line's payload, see tinympc_device.h)
     }
     std::atomic_thread_fence(std::memory_order_seq_cst);
 }

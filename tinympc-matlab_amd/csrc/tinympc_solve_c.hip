@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     for (;;) {
     if constexpr (SESSION) {
         // Poll the mailbox: lanes 0..23 fetch its three lines in one load, everybody sees them through LDS and takes
-        // the same decision. A command is complete when the stamp of every line it uses equals `expect`. The poller's
+        // the same decision. A command is complete when the stamp of every line it uses matches `expect`. The poller's
         // clock ends the session after p.session_idle ticks without a command -- the exit every wavefront reaches
         // even if the host process is gone.
         const unsigned long long t_idle0 = __builtin_amdgcn_s_memrealtime();
@@ -477,10 +477,19 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             if (tid < 56) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (tid == 0) sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
             __syncthreads();
-            go = sMail[7] == expect;  // line 0 carries the flags, which say how many lines the command uses
+            // A line is accepted when its stamp is `expect` plus the checksum of the seven payload words READ WITH IT
+            // (mail_stamp, tinympc_device.h): a poll that caught a line half-written -- the 64 bytes come in one load, but
+            // nothing in PCIe promises they are one snapshot -- fails the test and is simply repeated.
+            auto line_ok = [&](int l) -> bool {
+                unsigned long long x = 0ull;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) x ^= (unsigned long long)__double_as_longlong(sMail[8 * l + q]);
+                return sMail[8 * l + 7] == mail_stamp(expect, x);
+            };
+            go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
             const int f0 = go ? (int)sMail[0] : 0;
             const int npay = 1 + nx + ((f0 & 4) ? nx : 0) + ((f0 & 8) ? nu : 0), nlines = (npay + 6) / 7;
-            for (int l = 1; l < nlines; ++l) go = go && (sMail[8 * l + 7] == expect);
+            for (int l = 1; l < nlines; ++l) go = go && line_ok(l);
             quit = !go && sMail[56] != 0.0;
             __syncthreads();  // (the next poll overwrites sMail)
         }
