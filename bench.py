@@ -405,7 +405,7 @@ def main() -> int:
                             tj.get("source"), tj.get("library_hash"), library_hash())
             except (OSError, ValueError):
                 traffic = None
-        kname = {"A": "k_admm_solve", "B": "k_admm_solve_b", "C": "k_admm_solve_c", "D": "k_admm_solve_d"}.get(info.get("layout"), "k_admm_solve")
+        kname = {"A": "k_admm_solve", "B": "k_admm_solve_b", "C": "k_admm_solve_c", "D": "k_admm_solve_d", "E": "k_admm_solve_e (tinympc_jit_solve)", "F": "k_admm_solve_f (tinympc_jit_solve)", "M": "k_admm_solve_m"}.get(info.get("layout"), "k_admm_solve")
         out = {
             "metric": "ADMM iterations/s, batched quadrotor nx=12 nu=4 N=%d (instance-iterations/s, whole job)" % prob.N,
             "value": value, "unit": "ADMM iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
