@@ -283,7 +283,7 @@ int tinympc_get_launch_info(tinympc_solver *s, int *lanes_per_instance, int *ins
  * chunks; batches up to 768 and every single solve), 'D' (horizon unrolled at compile time, state in registers; large
  * batches), 'E' (as D with the horizon cut across the wavefronts of a workgroup: cone / linear families at long horizons),
  * 'F' (the latency kernel specialised at run time: up to 32 chunks on two wavefronts per SIMD; the families at small batches),
- * 'M' (64 < nx+nu <= 256 on the FP64 matrix cores). The environment variable TINYMPC_LAYOUT=A|B|C|D|E|F overrides the choice.
+ * 'M' (64 < nx+nu <= 512 on the FP64 matrix cores). The environment variable TINYMPC_LAYOUT=A|B|C|D|E|F overrides the choice.
  * 0 for a NULL handle. */
 int tinympc_get_layout(tinympc_solver *s);
 

@@ -60,7 +60,7 @@ def test_setup_validation_needs_no_gpu(pkg):
     p = a.ctypes.data_as(L.c_double_p)
     assert lib.tinympc_setup(C.byref(h), p, p, None, p, p, 1.0, 2, 2, 1, 0) == L.ERR_INVALID_INPUT  # N >= 2
     assert lib.tinympc_setup(C.byref(h), None, p, None, p, p, 1.0, 2, 2, 5, 0) == L.ERR_INVALID_INPUT
-    assert lib.tinympc_setup(C.byref(h), p, p, None, p, p, 1.0, 240, 20, 5, 0) == L.ERR_UNSUPPORTED  # nx+nu > 256
+    assert lib.tinympc_setup(C.byref(h), p, p, None, p, p, 1.0, 500, 20, 5, 0) == L.ERR_UNSUPPORTED  # nx+nu > 512
     assert not h
 
 

@@ -1,6 +1,6 @@
-"""Large systems, 64 < nx+nu <= 256 (the reference takes any nx, nu: types.hpp:16-17): the step of sixteen instances is a
+"""Large systems, 64 < nx+nu <= 512 (the reference takes any nx, nu: types.hpp:16-17): the step of sixteen instances is a
 GEMM on the FP64 matrix cores (tinympc_solve_m.hip, v_mfma_f64_16x16x4_f64), the ADMM state streams through HBM in the
-tile's own layout; beyond 128 rows a wavefront owns two row tiles and streams its operator tiles from L2. Against the oracle: caches, per-instance termination inside a tile, ragged last tile, warm starts after
+tile's own layout; beyond 128 rows a wavefront owns two to four row tiles and streams its operator tiles from L2. Against the oracle: caches, per-instance termination inside a tile, ragged last tile, warm starts after
 converged and unconverged solves, bounds and references that vary over the horizon."""
 from __future__ import annotations
 
@@ -75,13 +75,15 @@ def test_large_systems_match_the_oracle(pkg, nx, nu, N, varying):
         s.reset()
 
 
-@pytest.mark.parametrize("nx,nu,N,varying", [(130, 14, 6, False), (160, 32, 8, True), (224, 32, 5, False)])
+@pytest.mark.parametrize("nx,nu,N,varying", [(130, 14, 6, False), (160, 32, 8, True), (224, 32, 5, False), (300, 20, 5, True), (480, 32, 4, False)])
 def test_systems_beyond_128_rows(pkg, nx, nu, N, varying):
-    """R = 9, 12, 16 row tiles: two per wavefront, operator tiles streamed (the nx=160, nu=32 case). One oracle per
+    """R = 9, 12, 16, 20, 32 row tiles: two to four per wavefront, operator tiles streamed (the nx=160, nu=32 case). One oracle per
     checked instance (first tile, tile edge, ragged last tile); cold start and two warm starts."""
     prob = _system(pkg, nx, nu, N, nx + nu, varying)
     rng = np.random.default_rng(7)
     prob.A = 0.95 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))  # (spectral radius ~ 1: see the edge-width test below)
+    if nx >= 256:  # (a faster-contracting system: the oracle's Riccati iteration at 0.95 takes minutes at nx = 480)
+        prob.A = 0.6 * np.eye(nx) + (0.1 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
     batch = 19
     x0s = rng.standard_normal((nx, batch)) * np.linspace(0.02, 1.2, batch)[None, :]
     checked = (0, 15, 16, batch - 1)
@@ -106,8 +108,8 @@ def test_systems_beyond_128_rows(pkg, nx, nu, N, varying):
                 assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
                 np.testing.assert_allclose(st["residuals"][:, b], [ob["pri_x"], ob["dua_x"], ob["pri_u"], ob["dua_u"]], rtol=1e-6, atol=1e-10)
         s.reset()
-    with pytest.raises(pkg.TinyMPCError) as ei:  # beyond 256 rows: refused, and says so
-        pkg.TinyMPC().setup(np.eye(250), np.ones((250, 8)), np.eye(250), np.eye(8), 5, batch=1)
+    with pytest.raises(pkg.TinyMPCError) as ei:  # beyond 512 rows: refused, and says so
+        pkg.TinyMPC().setup(np.eye(510), np.ones((510, 8)), np.eye(510), np.eye(8), 5, batch=1)
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
 
 

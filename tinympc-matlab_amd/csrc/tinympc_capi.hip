@@ -35,9 +35,9 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     int W = 0, KT = 0;
     const bool large = solve_m_supported(nx, nu);
     if (large) {
-        W = KT = solve_m_geometry(nx, nu);  // geometry of the operators / tables (128, or 256 beyond 128 rows); the kernel works on 16-instance tiles
+        W = KT = solve_m_geometry(nx, nu);  // geometry of the operators / tables (128, 256 or 512); the kernel works on 16-instance tiles
     } else if (!choose_geometry(nx, nu, &W, &KT)) {
-        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d: systems beyond 256 rows are not supported by this build", nx + nu);
+        return fail(TINYMPC_ERR_UNSUPPORTED, "nx+nu = %d: systems beyond 512 rows are not supported by this build", nx + nu);
     }
     int ndev = tinympc_device_count();
     if (ndev < 1) return fail(TINYMPC_ERR_NO_DEVICE, "no HIP device visible: the HIP path has no CPU fallback");

@@ -319,7 +319,7 @@ inline hipError_t ensure_dynamic_lds(const void *fn, size_t bytes, size_t (&cach
 bool solve_m_supported(int nx, int nu);
 int solve_m_geometry(int nx, int nu);
 size_t solve_m_tiled_ops_doubles(int nx, int nu);  // beyond 128 rows: the tile-major copy of the operators the kernel streams (0 otherwise)
-hipError_t launch_tile_operators_m(const double *ops, double *out, int nx, int nu, hipStream_t stream);  // W = KT of the operators / tables of a large system: 128, or 256 beyond 128 rows
+hipError_t launch_tile_operators_m(const double *ops, double *out, int nx, int nu, hipStream_t stream);  // W = KT of the operators / tables of a large system: 128, 256 (beyond 128 rows) or 512 (beyond 256)
 size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with

@@ -1,4 +1,4 @@
-// tinympc_solve_m.hip -- k_admm_solve_m ("layout M"): LARGE systems, 64 < nx+nu <= 256, on the FP64 matrix cores.
+// tinympc_solve_m.hip -- k_admm_solve_m ("layout M"): LARGE systems, 64 < nx+nu <= 512, on the FP64 matrix cores.
 //
 // Same algorithm as the other solve kernels (tinympc_solve.hip has the reference citations: M1 solve admm.cpp:109-207 = F1
 // :25-35, S1 :43-59, D1 :65-69, L1 :75-83, R1 :89-107, C1 :196-197, B1 :13-20). Up to 64 rows an instance fits the lanes of
@@ -50,9 +50,9 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles) {
     const int R = (nx + nu + 15) / 16;
     return (size_t)tiles * N * m_knot_doubles(R);
 }
-bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 256 && nx >= 1 && nu >= 1; }
+bool solve_m_supported(int nx, int nu) { return nx + nu > 64 && nx + nu <= 512 && nx >= 1 && nu >= 1; }
 // geometry (W = KT) of the operators and tables these sizes are built with
-__host__ __device__ constexpr int m_geometry(int R) { return R > 8 ? 256 : 128; }
+__host__ __device__ constexpr int m_geometry(int R) { return R > 16 ? 512 : R > 8 ? 256 : 128; }
 int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 
 // CT: bounds and references are the same at every knot (p.const_tables): they are served from an LDS copy instead of
@@ -63,7 +63,7 @@ int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 // profiles/r03_large_m_experiments.txt.)
 //
 // R <= 8 (nx+nu <= 128): one row tile per wavefront, its operator tiles register-resident (above).
-// R = 9..16 (nx+nu <= 256, round 3): TWO row tiles per wavefront (t = w and w + 8), handled one after the other inside a step --
+// R = 9..32 (nx+nu <= 512, round 3): TWO to FOUR row tiles per wavefront (t = w, w + 8, ...), handled one after the other inside a step --
 // state in, GEMM, row-local phase, state out, twice, then the one barrier -- and the operator tiles STREAMED from L2 a batch
 // ahead of the matrix instructions that consume them: 2 x 4R doubles per lane no longer fit any register file, but a step
 // reads each operator tile once per workgroup (<= 512 KB per operator, L2-resident) while the matrix pipe works 2 x 4R x 64
@@ -72,7 +72,7 @@ int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 template <int R, bool CT>
 __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;            // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
-    constexpr int TPW = R > 8 ? 2 : 1;   // row tiles per wavefront
+    constexpr int TPW = (R + 7) / 8;     // row tiles per wavefront (1 .. 4)
     constexpr bool STREAM = R > 8;       // operator tiles from L2 instead of registers
     constexpr int GW = m_geometry(R);    // ops / tables geometry of these sizes: W = KT
     __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         if (has_tile(tw)) {
             // operand reads run a batch of eight k-blocks ahead of the matrix instructions that consume them (left to the
             // scheduler they ran two ahead, and an MFMA issued every 78 cycles instead of every 64)
-            constexpr int BATCH = STREAM ? (CT ? 8 : 4) : (CT ? 8 : (R == 8 ? 2 : 4));  // (per-knot tables: fewer registers to spare)
+            constexpr int BATCH = STREAM ? 4 : (CT ? 8 : (R == 8 ? 2 : 4));  // (per-knot tables: fewer registers to spare)
             static_assert(KB % 4 == 0, "k-blocks come in fours");
             double b[2][BATCH], a[2][STREAM ? BATCH : 1];
             // (streamed: the tile-major copy of the operators, one 512-byte line per (row tile, k-block) -- read row-major, an
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         load_A(0);
         load_start(0);
         // operand of step 0: [x_0; d_0]; and knot 0 of the state rows: x_0 is given, only projected
-#pragma unroll
+#pragma nounroll
         for (int tw = 0; tw < TPW; ++tw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         load_A(1);
         load_start(1);
         double *const Vn = par_read ? gVa : gVb;  // the slack written by this iteration's forward sweep
-#pragma unroll
+#pragma nounroll
         for (int tw = 0; tw < TPW; ++tw) {  // operand of step N-2: [p_{N-1}; r_{N-2}]
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         const bool last_written_is_b = (it_done & 1) != 0;
         double *const Vsol = last_written_is_b ? gVb : gVa;
         double *const Vold = last_written_is_b ? gVa : gVb;
-#pragma unroll
+#pragma nounroll
         for (int tw = 0; tw < TPW; ++tw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -479,6 +479,22 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
         TINY_M_LAUNCH(14)
         TINY_M_LAUNCH(15)
         TINY_M_LAUNCH(16)
+        TINY_M_LAUNCH(17)
+        TINY_M_LAUNCH(18)
+        TINY_M_LAUNCH(19)
+        TINY_M_LAUNCH(20)
+        TINY_M_LAUNCH(21)
+        TINY_M_LAUNCH(22)
+        TINY_M_LAUNCH(23)
+        TINY_M_LAUNCH(24)
+        TINY_M_LAUNCH(25)
+        TINY_M_LAUNCH(26)
+        TINY_M_LAUNCH(27)
+        TINY_M_LAUNCH(28)
+        TINY_M_LAUNCH(29)
+        TINY_M_LAUNCH(30)
+        TINY_M_LAUNCH(31)
+        TINY_M_LAUNCH(32)
         default: return hipErrorInvalidValue;
     }
 #undef TINY_M_LAUNCH

@@ -1,4 +1,4 @@
-"""Large systems (64 < nx+nu <= 256) on the FP64 matrix cores (tinympc_solve_m.hip): kernel time, fraction of the FP64 peak,
+"""Large systems (64 < nx+nu <= 512) on the FP64 matrix cores (tinympc_solve_m.hip): kernel time, fraction of the FP64 peak,
 algorithmic HBM bytes per second, and a parity check of the same run against the oracle.
 Usage (GPU box): python tools/large_sweep.py > gpurun_out/large_sweep.txt"""
 import os
@@ -16,14 +16,17 @@ pkg = g.load_package()
 P = pkg.problems
 ITERS = 50
 SHAPES = ((60, 10, 20, 4096), (96, 32, 20, 1024), (96, 32, 20, 4096), (96, 32, 20, 8192), (112, 16, 30, 4096),
-          (130, 14, 20, 4096), (160, 32, 20, 4096), (224, 32, 20, 4096))  # beyond 128 rows: two row tiles per wavefront, operator tiles streamed
+          (130, 14, 20, 4096), (160, 32, 20, 4096), (160, 32, 20, 8192), (224, 32, 20, 4096), (300, 20, 20, 4096),
+          (480, 32, 20, 4096))  # beyond 128 rows: two to four row tiles per wavefront, operator tiles streamed
 if "--one" in sys.argv:
     SHAPES = ((96, 32, 20, 4096),)
+if "--two" in sys.argv:  # enough tiles for two workgroups per CU
+    SHAPES = ((96, 32, 20, 8192), (96, 32, 20, 16384), (160, 32, 20, 8192), (160, 32, 20, 16384), (224, 32, 20, 8192))
 if "--big" in sys.argv:
     SHAPES = tuple(sh for sh in SHAPES if sh[0] + sh[1] > 128)
 for nx, nu, N, batch in SHAPES:
     rng = np.random.default_rng(nx)
-    A = np.eye(nx) * 0.98 + 0.015 * rng.standard_normal((nx, nx)) if nx + nu <= 128 else 0.95 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    A = np.eye(nx) * 0.98 + 0.015 * rng.standard_normal((nx, nx)) if nx + nu <= 128 else (0.95 if nx < 256 else 0.6) * np.eye(nx) + ((0.15 if nx < 256 else 0.1) / np.sqrt(nx)) * rng.standard_normal((nx, nx))
     B = 0.08 * rng.standard_normal((nx, nu))
     prob = P.Problem("large", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
     x0s = np.asfortranarray(np.random.default_rng(1).standard_normal((nx, batch)))
