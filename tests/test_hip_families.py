@@ -574,3 +574,41 @@ def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch
             res = np.array([[o.stats()[k] for k in ("pri_x", "dua_x", "pri_u", "dua_u")] for o in orc]).T
             assert rel_err(s.get_stats_batch()["residuals"], res) < 1e-6
     s.reset()
+
+
+@pytest.mark.parametrize("nx,nu,N,batch", [(20, 4, 12, 37), (24, 8, 10, 5), (40, 10, 8, 9), (48, 16, 6, 3)])
+def test_families_on_wide_systems(pkg, kernel_layout, monkeypatch, nx, nu, N, batch):
+    """32 and 64 lanes per instance (k_admm_solve_fam's reduction form: a cone's ||w||^2 is a group sum over its tail rows, t one
+    lane read, a linear row two group sums -- no mask rows in registers): a cone inside one DPP row, one that straddles the
+    boundary between two rows of 16 lanes, two cones that share a row (a second round), an input cone, linear rows on both
+    sides and fdyn. Against the restatement: identical iteration counts, 1e-9 on the trajectories, over a cold and a warm start."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    rng = np.random.default_rng(nx * 100 + nu)
+    A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    Bm = 0.3 * rng.standard_normal((nx, nu))
+    prob = P.Problem("widefam", A, Bm, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 1.5, rng.standard_normal(nx))
+    prob.x_min, prob.x_max = np.full(nx, -3.0), np.full(nx, 3.0)
+    prob.u_min, prob.u_max = np.full(nu, -1.0), np.full(nu, 1.0)
+    prob.fdyn = 0.01 * rng.standard_normal(nx)
+    prob.cones = dict(Acx=[0, 13, 15], qcx=[3, 5, 3], cx=[0.8, 0.6, 1.1], Acu=[0], qcu=[3], cu=[0.7])  # rows 0-2 | 13-17 | 15-17 (shares rows)
+    prob.linear = dict(Alin_x=rng.standard_normal((3, nx)), blin_x=rng.uniform(0.5, 1.5, 3), Alin_u=rng.standard_normal((2, nu)), blin_u=rng.uniform(0.3, 0.8, 2))
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    s = make(pkg, prob, settings, batch=batch)
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.1, 1.0, batch)[None, :]
+    checked = sorted({0, batch // 2, batch - 1})
+    orc = {b: oracle(prob, settings) for b in checked}
+    for rnd in range(2):
+        xs = x0s * (1.0 - 0.3 * rnd)
+        s.set_x0_batch(xs)
+        s.solve()
+        assert s.launch_info()["layout"] == "A"
+        sol, st = s.get_solution_batch(), s.get_stats_batch()
+        for b in checked:
+            orc[b].set_x0(xs[:, b])
+            orc[b].solve()
+            assert st["iter"][b] == orc[b].stats()["iter"] and st["status"][b] == orc[b].stats()["status"], (rnd, b)
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+    s.reset()

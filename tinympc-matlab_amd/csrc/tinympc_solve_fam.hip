@@ -73,13 +73,44 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
         for (int i = lane; i < tn; i += 64) sT[i] = p.tables[i];
     }
 
-    double mf[KT], mb[KT], cn[KT], ct[KT], ty[KT];
+    // RED (wide systems, 32 / 64 lanes per instance): the cross-row quantities come from group REDUCTIONS instead of mat-vecs with
+    // 0/1 mask rows. Three mask rows of KT doubles per lane next to the two operator rows are 640 VGPRs at 64 lanes: the kernel
+    // lived in scratch (nx=48, nu=16 with one cone and two linear rows: 2.0 M iterations/s against 131 M on the box path). What
+    // the masks encode is small: per round a lane's cone is known by its LAST row (the t entry, Ct's one column), its role says
+    // whether it belongs to the tail; a cone's ||w||^2 is one group sum over its tail rows, t one lane read, a linear row's a'x and
+    // a'u two group sums.
+    constexpr bool RED = W > 16;
+    double mf[KT], mb[KT], cn[RED ? 1 : KT], ct[RED ? 1 : KT], ty[RED ? 1 : KT];
     {
         const double *Mf = p.ops + (size_t)r * KT, *Mb = p.ops + (size_t)W * KT + (size_t)r * KT;
         const double *Cn = p.fam + 4 * W + (size_t)r * KT, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            mf[k] = Mf[k]; mb[k] = Mb[k]; cn[k] = Cn[k]; ct[k] = Ct[k]; ty[k] = Ty[k];
+            mf[k] = Mf[k]; mb[k] = Mb[k];
+            if constexpr (!RED) { cn[k] = Cn[k]; ct[k] = Ct[k]; ty[k] = Ty[k]; }
+        }
+    }
+    // RED: per round q -- this lane's role / slope / last row of its cone (-1: in no cone of the round), and the set of last rows
+    // (= of cones) of the round as a wave-uniform bit mask of group-relative lane numbers
+    int r_role[MAX_ROUNDS], r_head[MAX_ROUNDS];
+    double r_mu[MAX_ROUNDS], r_imu[MAX_ROUNDS];
+    unsigned long long r_cones[MAX_ROUNDS];
+    if constexpr (RED) {
+        const int nrounds = (int)p.fam[fam_nround_offset(W, KT)];
+#pragma unroll
+        for (int q = 0; q < MAX_ROUNDS; ++q) {
+            r_role[q] = 0; r_head[q] = -1; r_mu[q] = 0.0; r_imu[q] = 0.0; r_cones[q] = 0ull;
+            if (q < nrounds) {  // (uniform)
+                const double *rd = q == 0 ? p.fam : p.fam + fam_round_offset(W, KT, q);
+                const double *ctq = q == 0 ? p.fam + 4 * W + (size_t)W * KT : rd + 2 * W + (size_t)W * KT;
+                r_role[q] = (int)rd[r];
+                r_mu[q] = rd[W + r];
+                r_imu[q] = (r_mu[q] != 0.0) ? 1.0 / r_mu[q] : 0.0;
+                for (int k = 0; k < nxu; ++k)
+                    if (ctq[(size_t)r * KT + k] != 0.0) r_head[q] = k;
+                const unsigned long long heads = __ballot(r_head[q] == r);
+                r_cones[q] = (W == 64) ? heads : (heads & ((1ull << (W % 64)) - 1ull));  // (every instance of the wave has the same cones)
+            }
         }
     }
     const int role = (int)p.fam[r];
@@ -92,7 +123,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
     // ten) read the rest from the family buffer (L2) where they are used
     double ak[FAM_REG_ROWS], bk[FAM_REG_ROWS], ink[FAM_REG_ROWS];  // ink = 1 / ||a_k||^2
 #pragma unroll
-    for (int k = 0; k < FAM_REG_ROWS; ++k) {
+    for (int k = 0; k < (RED ? 0 : FAM_REG_ROWS); ++k) {
         ak[k] = lin[1 + (size_t)(3 * k + 0) * W + r];
         bk[k] = lin[1 + (size_t)(3 * k + 1) * W + r];
         ink[k] = 1.0 / lin[1 + (size_t)(3 * k + 2) * W + r];
@@ -119,6 +150,49 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
         double lx = 0.0;
         gc_new = gc_old;
         gl_new = gl_old;
+        if constexpr (RED) {
+            if (any_cone) {
+                const double sv = val + gc_old;  // vcnew = x + gc (all rows of an enabled side)
+                double vc = sv;
+#pragma unroll
+                for (int q = 0; q < MAX_ROUNDS; ++q) {
+                    if (q < nround) {  // (uniform)
+                        double a2 = 0.0;
+                        for (unsigned long long m = r_cones[q]; m != 0ull; m &= m - 1ull) {  // one cone of the round after the other (uniform)
+                            const int hc = __builtin_ctzll(m);
+                            const bool mine = r_head[q] == hc;
+                            const double tail2 = group_sum<W>((mine && r_role[q] == 1) ? vc * vc : 0.0);  // ||w||^2 of that cone
+                            a2 = mine ? tail2 : a2;
+                        }
+                        const double t = __shfl(vc, r_head[q] >= 0 ? r_head[q] : r, W);  // last entry of the row's cone
+                        vc = soc_project_element(vc, a2, t, r_mu[q], r_imu[q], r_role[q]);
+                    }
+                }
+                const double gcn = sv - vc;  // gc + x - vcnew
+                if (famc) {
+                    gc_new = gcn;
+                    lx -= rho * (vc - gcn);
+                }
+            }
+            if (any_lin) {
+                const double s0 = val + gl_old;
+                double sv = s0;
+#pragma unroll 1
+                for (int k = 0; k < nl; ++k) {  // (uniform trip count; the rows' coefficients from the family buffer in L2)
+                    const double a_k = lin[1 + (size_t)(3 * k + 0) * W + r], b_k = lin[1 + (size_t)(3 * k + 1) * W + r];
+                    const double in_k = 1.0 / lin[1 + (size_t)(3 * k + 2) * W + r];
+                    const double prod = a_k * sv;
+                    const double dx = group_sum<W>(is_x ? prod : 0.0), du = group_sum<W>(is_u ? prod : 0.0);  // a_k' x | a_k' u
+                    sv = halfspace_project_element(sv, is_x ? dx : du, a_k, b_k, in_k);
+                }
+                const double gln = s0 - sv;
+                if (faml) {
+                    gl_new = gln;
+                    lx -= rho * (sv - gln);
+                }
+            }
+            return lx;
+        } else {
         if (any_cone) {
             const double sv = val + gc_old;                              // vcnew = x + gc (all rows of an enabled side)
             const double a2 = group_matvec<W, KT>(cn, sv * sv, 0.0);     // ||w||^2 of the row's cone
@@ -169,6 +243,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_fam(const SolveParams p) {
             }
         }
         return lx;
+        }
     };
 
     bool active = inst_ok;

@@ -307,6 +307,27 @@ __device__ __forceinline__ void fair_share_priority(int it0, int simd_slot) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
+// Sum over the W lanes of a group, the same bit pattern in every lane (a symmetric butterfly: both partners of an exchange add
+// the same two numbers): four DPP exchanges inside a 16-lane row (64-bit DPP knows row_newbcast only, so the halves move
+// separately), then one / two cross-row exchanges.
+template <int CTRL>
+__device__ __forceinline__ double dpp_exchange(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(W == 16 || W == 32 || W == 64, "groups of 16, 32 or 64 lanes");
+    v += dpp_exchange<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_exchange<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_exchange<0x141>(v);  // row_half_mirror: the other quad of the half row
+    v += dpp_exchange<0x140>(v);  // row_mirror: the other half of the row
+    if constexpr (W >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (W == 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 template <int W>
 __device__ __forceinline__ double group_max(double v) {
 #pragma unroll
