@@ -164,15 +164,18 @@ def test_device_adaptive_rho_batch_with_computed_sensitivities(pkg, which):
 
 @pytest.mark.gpu
 def test_device_adaptive_rho_wide_system_and_long_horizon(pkg):
-    """W = 32 lanes per instance (nx + nu = 20) and a horizon whose state lives in HBM scratch (GMEM variant)."""
+    """W = 32 and 64 lanes per instance (nx + nu = 20 and 46; the 64-lane form rebuilds its one operator row array at every sweep)
+    and a horizon whose state lives in HBM scratch (GMEM variant)."""
     rng = np.random.default_rng(5)
-    nx, nu = 14, 6
-    A = np.eye(nx) + 0.05 * rng.normal(size=(nx, nx))
-    A *= 0.97 / max(1.0, np.abs(np.linalg.eigvals(A)).max())
-    B = 0.2 * rng.normal(size=(nx, nu))
-    P = pkg.problems.Problem(name="wide", A=A, B=B, Q=np.diag(rng.uniform(1, 5, nx)), R=np.diag(rng.uniform(0.5, 2, nu)), N=12,
-                             rho=2.0, x0=rng.normal(size=nx), u_min=np.full(nu, -0.4), u_max=np.full(nu, 0.4))
-    for prob, iters in ((P, 40), (pkg.problems.cartpole(300, True), 25)):
+
+    def wide(nx, nu):
+        A = np.eye(nx) + 0.05 * rng.normal(size=(nx, nx))
+        A *= 0.97 / max(1.0, np.abs(np.linalg.eigvals(A)).max())
+        B = 0.2 * rng.normal(size=(nx, nu))
+        return pkg.problems.Problem(name="wide", A=A, B=B, Q=np.diag(rng.uniform(1, 5, nx)), R=np.diag(rng.uniform(0.5, 2, nu)), N=12,
+                                    rho=2.0, x0=rng.normal(size=nx), u_min=np.full(nu, -0.4), u_max=np.full(nu, 0.4))
+
+    for prob, iters in ((wide(14, 6), 40), (wide(36, 10), 40), (pkg.problems.cartpole(300, True), 25)):
         settings = dict(max_iter=iters, abs_pri_tol=0.0, abs_dua_tol=0.0)
         s = _solver(pkg, prob, batch=3, adaptive_rho=True, adaptive_rho_min=0.5, adaptive_rho_max=20.0, **settings)
         dK, dP, dC1, dC2 = s.compute_sensitivity_autograd()

@@ -124,17 +124,32 @@ __global__ void __launch_bounds__(64) k_admm_solve_adapt(const SolveParams p) {
     const double dpnref = p.adapt[5 * M + r];
     const double rho0 = p.rho;
     double rho = inst_ok ? p.rho_inst[inst] : rho0;  // persists across solves like cache->rho
-    double mf[KT], mb[KT], mt[KT];
-    auto load_operators = [&](double delta) {
+    // 64 lanes per instance: three operator rows of 64 doubles are 384 VGPRs and, with the adaptation's Pinf row, more than a
+    // wavefront has -- the kernel spilled 200 of them. A sweep needs ONE operator (Mf forward, Mb backward; [A'; B'] only in the
+    // sweeps that adapt), so RELOAD keeps one row array and rebuilds it from L2 at the start of each sweep (layout D does the
+    // same from LDS); the narrower forms keep all three resident.
+    constexpr bool RELOAD = W == 64;
+    double mf[KT], mb_store[RELOAD ? 1 : KT], mt[KT];
+    double (&mb)[KT] = *reinterpret_cast<double (*)[KT]>(RELOAD ? &mf[0] : &mb_store[0]);  // (RELOAD: the one array, Mb during the backward sweep)
+    auto load_forward = [&](double delta) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            mf[k] = fma(delta, dMf[k], Mf0[k]);
-            mb[k] = fma(delta, dMb[k], Mb0[k]);
+        for (int k = 0; k < KT; ++k) mf[k] = fma(delta, dMf[k], Mf0[k]);
+    };
+    auto load_backward = [&](double delta) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) mb[k] = fma(delta, dMb[k], Mb0[k]);
+    };
+    auto load_operators = [&](double delta) {
+        if constexpr (!RELOAD) {
+            load_forward(delta);
+            load_backward(delta);
         }
     };
     load_operators(rho - rho0);
+    if constexpr (!RELOAD) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) mt[k] = Mt[k];
+        for (int k = 0; k < KT; ++k) mt[k] = Mt[k];
+    }
     const double cf = p.ops[2 * M + r];
     const double cb = p.ops[2 * M + W + r];
     const double dgr = p.ops[2 * M + 2 * W + r];  // Q + rho0 / R + rho0 diagonal of this row (tiny_api.cpp:90-91)
@@ -162,6 +177,13 @@ __global__ void __launch_bounds__(64) k_admm_solve_adapt(const SolveParams p) {
         double a_pr = 0.0, a_pn = 0.0, a_dr = 0.0, a_dn = 0.0;  // adaptation: primal res / norm, dual res / norm
         double x_last = x0v, g_last = 0.0;
 
+        if constexpr (RELOAD) {
+            load_forward(rho - rho0);
+            if (adapt) {  // (uniform)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) mt[k] = Mt[k];
+            }
+        }
         {   // knot 0, state lanes
             const bool on = st && is_x;
             const double g = sG[64 + lane], vold = sV[64 + lane];
@@ -261,6 +283,7 @@ __global__ void __launch_bounds__(64) k_admm_solve_adapt(const SolveParams p) {
         }
 
         {   // backward sweep: linear cost with the rho / Pinf of update_linear_cost, operators with the new Kinf
+            if constexpr (RELOAD) load_backward(rho - rho0);
             const bool stb = active && row_ok && is_u;
             const double *pb = sG + N * 64 + lane;
             double pcur = pnref_lin - rho_lin * (pb[VOFF] - pb[0]);
