@@ -186,3 +186,27 @@ def test_layout_f_specialisations_have_no_dpp_hazard_and_no_scratch(nx, nu, N, c
     checked, bad = _lint(text)
     assert checked > 100 and not bad, bad[:3]
     assert ".private_segment_fixed_size: 0" in text and "vgpr_spill_count: 0" in text, "the specialisation spills"
+
+
+def test_compiled_in_kernels_do_not_live_in_scratch():
+    """Register arrays that outgrow the register file end up in scratch memory silently (round 3 found the 64-lane forms of the
+    families and adaptive-rho kernels there: 200 spilled registers, 10-60x slower). The build keeps the device assembly of every
+    object it links; its kernel descriptors say how much scratch each kernel uses. Allowed: nothing, except the entries below."""
+    import re
+
+    import __graft_entry__ as ge
+    allowed = {
+        # k_admm_solve_fam<64, 64, false, false>: 14 registers in the variant that reads its tables from L2 (44 bytes per lane)
+        ("tinympc_solve_fam.hip", "_ZN7tinympc16k_admm_solve_famILi64ELi64ELb0ELb0EEEvNS_11SolveParamsE"): 64,
+    }
+    seen = 0
+    for source in ge.HIP_SOURCES:
+        built = ge.device_asm_path(source)
+        if not os.path.exists(built):
+            pytest.skip("no build assembly (run __graft_entry__.build())")
+        text = open(built).read()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            seen += 1
+            size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+            assert size <= allowed.get((source, m.group(1)), 0), f"{source}: {m.group(1)} uses {size} bytes of scratch per lane"
+    assert seen > 50
