@@ -590,7 +590,7 @@ def main() -> int:
                                    "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"],
                                    **leg_counters("long_horizon", hB * hit / (med * 1e-3))}
             longh.reset()
-            # Large systems (64 < nx+nu <= 128): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
+            # Large systems (64 < nx+nu <= 512): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
             # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
             lnx, lnu, lN, lB, lit = 96, 32, 20, 4096, 50
             rng = np.random.default_rng(lnx)
@@ -619,6 +619,28 @@ def main() -> int:
                                                "the kernel moves about 2/3",
                                    "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)", **lmeas}
             big.reset()
+            # ... and beyond 256 rows (round 3): four row tiles per wavefront, the operator tiles streamed from a tile-major copy in L2;
+            # with nxu / 20 flop per byte of state this one is priced on the matrix pipe
+            vnx, vnu, vN, vB, vit = 480, 32, 20, 4096, 20
+            rng = np.random.default_rng(7)
+            vA = 0.6 * np.eye(vnx) + (0.1 / np.sqrt(vnx)) * rng.standard_normal((vnx, vnx))
+            vp = P.Problem("very_large", vA, 0.08 * rng.standard_normal((vnx, vnu)), np.diag(rng.uniform(1, 10, vnx)), np.diag(rng.uniform(0.5, 2, vnu)), vN, 2.0,
+                           rng.standard_normal(vnx))
+            vbig = pkg.TinyMPC()
+            vbig.setup(vp.A, vp.B, vp.Q, vp.R, vp.N, batch=vB, device=local_rank, rho=vp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=vit)
+            vbig.set_bound_constraints(np.full(vnx, -2.0), np.full(vnx, 2.0), np.full(vnu, -0.3), np.full(vnu, 0.3))
+            vbig.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((vnx, vB))))
+            ms = []
+            for k in range(3):
+                vbig.reset_workspace()
+                ms.append(vbig.solve_timed())
+            med = sorted(ms[1:])[0]
+            vtf = vB * vit * vp.flops_per_iteration() / (med * 1e-3) / 1e12
+            out["very_large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (vnx, vnu, vN, vB, vit),
+                                        "iters_per_s": vB * vit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": vtf, "fp64_frac": vtf / PEAK_FP64_TFLOPS,
+                                        "layout": vbig.launch_info()["layout"], "kernel": "k_admm_solve_m<32> (four row tiles per wavefront, streamed operator tiles)",
+                                        **leg_counters("very_large_system", vB * vit / (med * 1e-3))}
+            vbig.reset()
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
             tick = {}

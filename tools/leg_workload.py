@@ -3,7 +3,7 @@
 extra legs, a few launches each, nothing else in the process (no torch import: numpy + the C ABI only).
 
     python tools/leg_workload.py <leg> [launches]
-legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, adaptive_rho_batch, single_instance
+legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance
 Prints one JSON line: leg, kernel layout, launches, iterations per launch, instances, median kernel ms (HIP events)."""
 import json
 import os
@@ -72,6 +72,8 @@ def build(leg):
         return quadrotor(100, 8192, 100), 8192, 100
     if leg == "large_system":
         return synthetic(96, 32, 20, 4096, 50, 96, 0.015, 0.08, 0.98), 4096, 50
+    if leg == "very_large_system":  # (beyond 256 rows: four row tiles per wavefront, operator tiles streamed)
+        return synthetic(480, 32, 20, 4096, 20, 7, 0.1 / np.sqrt(480.0), 0.08, 0.6), 4096, 20
     if leg == "adaptive_rho_batch":
         s = quadrotor(50, 8192, 100, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0)
         s.set_sensitivity_matrices(*s.compute_sensitivity_autograd())
