@@ -34,7 +34,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 PEAK_FP64_TFLOPS = 78.6    # MI355X FP64 vector peak (spec)
 
@@ -183,6 +183,22 @@ def usable_cpus():
             pass
     return cpus, quota, src
 
+
+
+def _dbg_tick(pkg, prob, label):
+    import time as _t
+    import numpy as np
+    tk = pkg.TinyMPC()
+    tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    x = prob.x0.copy(); acc = 0.0; d = []
+    for k in range(120):
+        t0 = _t.perf_counter(); u0 = tk.mpc_step(x)[:, 0]; dt = _t.perf_counter() - t0
+        if k >= 20: acc += dt; d.append(dt * 1e6)
+        x = prob.A @ x + prob.B @ u0
+    d = np.array(d)
+    print("DBG tick after %-22s mean %7.1f median %7.1f min %7.1f max %9.1f n>100us %d first10 %s" % (label, d.mean(), np.median(d), d.min(), d.max(), int((d > 100).sum()), np.round(d[:10]).tolist()), file=sys.stderr, flush=True)
+    tk.reset()
 
 def leg_counters(leg: str, iters_per_s: float) -> dict:
     """What rocprofv3 measured for this leg's kernel (profiles/r03_<leg>_pmc.json, tools/profile_legs.sh + collect_leg_profiles.py):
@@ -464,6 +480,7 @@ def main() -> int:
                                          "fp64_frac": nb * args.iters * flops_iter / (sum(kms) / 3 * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                                          "prefix_matches_8192_run": (bool(np.array_equal(u_first, sol["controls"])) if parity else None)}
             big.reset()
+            _dbg_tick(pkg, prob, "line 480 big.reset()")
         if not args.no_single:
             one = pkg.TinyMPC()
             one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho,
@@ -480,6 +497,7 @@ def main() -> int:
                                       "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                       "layout": one.launch_info()["layout"], **leg_counters("single_instance", args.iters / (med * 1e-3))}
             one.reset()
+            _dbg_tick(pkg, prob, "line 496 one.reset()")
             # BASELINE config 4: one rocket-landing instance, N=100, second-order cones + a linear row + fdyn
             rk = P.rocket(100)
             one = pkg.TinyMPC()
@@ -504,6 +522,7 @@ def main() -> int:
                                       "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None,
                                       **leg_counters("rocket_instance", args.iters / (med * 1e-3))}
             one.reset()
+            _dbg_tick(pkg, prob, "line 520 one.reset()")
             # ... and batches of it: N=100 (BASELINE config 4's horizon: the latency kernel, one workgroup per instance) and
             # N=10 (the horizon of examples/rocket_landing_constraints.m:14: layout D with the families in registers)
             rb = {}
@@ -528,6 +547,7 @@ def main() -> int:
                                    "box_part_fp64_frac": rB * rit * rkb.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                                    **(leg_counters("rocket_batch", rB * rit / (med * 1e-3)) if rN == 100 else {})}
                 many.reset()
+                _dbg_tick(pkg, prob, "line 544 many.reset()")
             out["rocket_batch"] = dict(workload="4096 rocket-landing instances (cones + linear row + fdyn) x 100 forced iterations", **rb)
             # Adaptive rho (admm.cpp:117-174) on a batch: rho, its operator rows and pNref per instance, layout D's ADAPT variant
             ad = pkg.TinyMPC()
@@ -548,6 +568,7 @@ def main() -> int:
                                          "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))],
                                          **leg_counters("adaptive_rho_batch", aB * ait / (med * 1e-3))}
             ad.reset()
+            _dbg_tick(pkg, prob, "line 564 ad.reset()")
         if not args.no_single:
             # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
             # cross-row swaps + fused DPP chain. Synthetic stable system, box constraints, 100 forced iterations.
@@ -571,6 +592,7 @@ def main() -> int:
                                   "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"],
                                   **leg_counters("wide_system", wB * wit / (med * 1e-3))}
             wide.reset()
+            _dbg_tick(pkg, prob, "line 587 wide.reset()")
             # Long horizon: the quadrotor at N = 100. The duals of 99 knots do not fit 256 registers, so layout D runs its second
             # plan (one wavefront per SIMD with all 512 registers; the kernel is specialised at run time by tinympc_jit.hip).
             hp = P.quadrotor(100)
@@ -590,6 +612,7 @@ def main() -> int:
                                    "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"],
                                    **leg_counters("long_horizon", hB * hit / (med * 1e-3))}
             longh.reset()
+            _dbg_tick(pkg, prob, "line 606 longh.reset()")
             # Large systems (64 < nx+nu <= 512): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
             # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
             lnx, lnu, lN, lB, lit = 96, 32, 20, 4096, 50
@@ -619,6 +642,7 @@ def main() -> int:
                                                "the kernel moves about 2/3",
                                    "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)", **lmeas}
             big.reset()
+            _dbg_tick(pkg, prob, "line 635 big.reset()")
             # ... and beyond 256 rows (round 3): four row tiles per wavefront, the operator tiles streamed from a tile-major copy in L2;
             # with nxu / 20 flop per byte of state this one is priced on the matrix pipe
             vnx, vnu, vN, vB, vit = 480, 32, 20, 4096, 20
@@ -641,19 +665,9 @@ def main() -> int:
                                         "layout": vbig.launch_info()["layout"], "kernel": "k_admm_solve_m<32> (four row tiles per wavefront, streamed operator tiles)",
                                         **leg_counters("very_large_system", vB * vit / (med * 1e-3))}
             vbig.reset()
+            _dbg_tick(pkg, prob, "line 657 vbig.reset()")
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
-            # (A throwaway handle first: the first single-instance handle created after the batch legs above sometimes runs its
-            # whole life at ~200-400 us per tick instead of ~21 -- seen in 4 of 6 runs of this file, never on a second handle and
-            # never in a process that only ticks (tools/tick_probe.py, tools/bench_tick_debug.py); cause not identified. The
-            # legs report mean, median and maximum of the 200 timed ticks so that such a run shows.)
-            warm = pkg.TinyMPC()
-            warm.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
-            warm.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-            xw = prob.x0.copy()
-            for k in range(100):
-                xw = prob.A @ xw + prob.B @ warm.mpc_step(xw)[:, 0]
-            warm.reset()
             tick = {}
             for mode in ("launch", "session"):
                 tk = pkg.TinyMPC()
@@ -662,20 +676,18 @@ def main() -> int:
                 if mode == "session":
                     tk.session_begin()
                 x = prob.x0.copy()
-                t_acc, its, dts = 0.0, 0, []
+                t_acc, its = 0.0, 0
                 for k in range(220):
                     t0 = time.perf_counter()
                     u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
                     dt = time.perf_counter() - t0
                     if k >= 20:
                         t_acc += dt
-                        dts.append(dt)
                         its += int(tk.get_stats()["iter"])
                     x = prob.A @ x + prob.B @ u0
                 if mode == "session":
                     tk.session_end()
-                tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick_max": 1e6 * float(np.max(dts)),
-                              "iterations_per_tick": its / 200}
+                tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "iterations_per_tick": its / 200}
                 tk.reset()
             out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
         if cpu is not None:
