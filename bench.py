@@ -643,17 +643,10 @@ def main() -> int:
             vbig.reset()
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
-            # (A throwaway handle first: the first single-instance handle created after the batch legs above sometimes runs its
-            # whole life at ~200-400 us per tick instead of ~21 -- seen in 4 of 6 runs of this file, never on a second handle and
-            # never in a process that only ticks (tools/tick_probe.py, tools/bench_tick_debug.py); cause not identified. The
-            # legs report mean, median and maximum of the 200 timed ticks so that such a run shows.)
-            warm = pkg.TinyMPC()
-            warm.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
-            warm.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-            xw = prob.x0.copy()
-            for k in range(100):
-                xw = prob.A @ xw + prob.B @ warm.mpc_step(xw)[:, 0]
-            warm.reset()
+            # (Mean, median and maximum of the 200 timed ticks: one tick in a few thousand takes milliseconds -- 41 ms once in this
+            # file's run -- and moves the mean of 200 by a factor of ten. tools/tick_outliers.py (20,000 ticks, the library's own
+            # split per outlier via tinympc_debug_tick_timing): the launch call and the wait of such a tick are the usual
+            # 5 + 18 us; the time goes to the calling thread being descheduled, outside the library.)
             tick = {}
             for mode in ("launch", "session"):
                 tk = pkg.TinyMPC()

@@ -5,6 +5,7 @@
 #include "tinympc_handle.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -356,10 +357,13 @@ int tinympc_synchronize(tinympc_solver *s) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 s->flag_pending = false;
                 s->host_sol_state = 2;
+                s->dbg_tick[2] = (double)spin;
+                s->dbg_tick[3] = 0.0;
                 return TINYMPC_OK;
             }
             __builtin_ia32_pause();
         }
+        s->dbg_tick[3] = 1.0;  // the polling budget ran out
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->flag_pending = false;
@@ -416,10 +420,15 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.
         s->zero_copy_tick = true;
+        const auto t_a = std::chrono::steady_clock::now();
         rc = launch(s, false);
+        const auto t_b = std::chrono::steady_clock::now();
         s->zero_copy_tick = false;
         if (rc) return rc;
         if ((rc = tinympc_synchronize(s))) return rc;  // (single instance: polls the completion flag in pinned memory)
+        const auto t_c = std::chrono::steady_clock::now();
+        s->dbg_tick[0] = std::chrono::duration<double, std::micro>(t_b - t_a).count();  // launch
+        s->dbg_tick[1] = std::chrono::duration<double, std::micro>(t_c - t_b).count();  // wait
     } else {
         HIP_TRY(hipMemcpyAsync(s->dx0, s->h_x0, sizeof(double) * nx0, hipMemcpyHostToDevice, s->stream));
         if ((rc = launch(s, false))) return rc;
@@ -433,6 +442,14 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
 
 
 
+
+// (diagnostic: where the last zero-copy tick spent its time -- launch us, wait us, polls, 1 if the polling budget ran out)
+int tinympc_debug_tick_timing(tinympc_solver *s, double *out4) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) out4[i] = s->dbg_tick[i];
+    return TINYMPC_OK;
+}
 
 int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, int first, int count) {
     int rc = check_handle(s);

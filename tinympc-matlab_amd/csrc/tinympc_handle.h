@@ -87,6 +87,7 @@ struct tinympc_solver {
     // own layout (tinympc_solve_m.hip). The only kernel for these sizes: box path, batched or single, no families /
     // adaptive rho / session.
     bool layout_m = false;
+    double dbg_tick[4] = {0.0, 0.0, 0.0, 0.0};  // tinympc_debug_tick_timing
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
     int d_adapt = -1;       // ... and with adaptive rho
     int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
