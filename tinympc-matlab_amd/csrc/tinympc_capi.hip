@@ -163,7 +163,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     TRY(dalloc(s, &s->dKinf, (size_t)nu * nx)); TRY(dalloc(s, &s->dPinf, (size_t)nx * nx));
     TRY(dalloc(s, &s->dQuu, (size_t)nu * nu)); TRY(dalloc(s, &s->dAmBKt, (size_t)nx * nx));
     TRY(dalloc(s, &s->dAPf, nx)); TRY(dalloc(s, &s->dBPf, nu)); TRY(dalloc(s, &s->dinfo, 4));
-    TRY(dalloc(s, &s->dscratch, precompute_scratch_doubles(nx, nu) + 8));
+    TRY(dalloc(s, &s->dscratch, (large ? precompute_large_scratch_doubles(nx, nu) : precompute_scratch_doubles(nx, nu)) + 8));
     TRY(dalloc(s, &s->dQfull, (size_t)nx * nx)); TRY(dalloc(s, &s->dRfull, (size_t)nu * nu));
     TRY(dalloc(s, &s->ddK, (size_t)nu * nx)); TRY(dalloc(s, &s->ddP, (size_t)nx * nx));
     TRY(dalloc(s, &s->dadapt, adapt_doubles(W, KT))); TRY(dalloc(s, &s->drho_inst, batch));

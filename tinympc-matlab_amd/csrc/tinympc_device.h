@@ -262,6 +262,10 @@ hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream);  // asynchronous constant fill
 size_t lqr_scratch_doubles(int nx, int nu);
+// The same precompute for large systems (nx+nu > 64; tinympc_precompute_large.hip): every matrix product of an iteration its own
+// launch on the FP64 matrix cores; blocks on the stream while it looks at the data-dependent iteration count.
+size_t precompute_large_scratch_doubles(int nx, int nu);
+hipError_t launch_precompute_large(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_build_operators(const OperatorParams &p, hipStream_t stream);
 hipError_t launch_build_tables(const TableParams &p, hipStream_t stream);
 // Layout A: one wavefront per workgroup, all ADMM state in LDS (lowest latency, 2 waves per CU).

@@ -70,7 +70,8 @@ int run_precompute(tinympc_solver *s) {
     p.Kinf = s->dKinf; p.Pinf = s->dPinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
     p.info = s->dinfo; p.scratch = s->dscratch;
     p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
-    HIP_TRY(launch_precompute(p, s->stream));
+    if (s->layout_m) HIP_TRY(launch_precompute_large(p, s->stream));  // (large systems: one launch per matrix product, on the matrix cores)
+    else HIP_TRY(launch_precompute(p, s->stream));
     s->ops_dirty = true;
     s->tables_dirty = true;
     return TINYMPC_OK;

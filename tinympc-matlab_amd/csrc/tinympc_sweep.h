@@ -312,9 +312,11 @@ __device__ __forceinline__ void fair_share_priority(int it0, int simd_slot) {
 // separately), then one / two cross-row exchanges.
 template <int CTRL>
 __device__ __forceinline__ double dpp_exchange(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    // (compiler builtins only: this header is also compiled by hiprtc, whose built-in headers lack __double2loint and friends)
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)bits, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {
