@@ -43,6 +43,15 @@ __device__ __forceinline__ void lds_exchange_barrier() { asm volatile("s_waitcnt
 
 constexpr int M_INST = 16;       // instances per tile (the N dimension of the MFMA)
 constexpr int M_WAVES = 8;       // one 16-row output tile per wavefront (R <= 8)
+// wavefronts per workgroup: eight up to 128 rows; R of them for 9 <= R <= 16 row tiles (one tile each: no wavefront carries two
+// while its neighbours carry one), sixteen beyond
+__host__ __device__ constexpr int m_waves(int R) {
+#ifdef TINY_M_EIGHT_WAVES
+    return 8;
+#else
+    return R <= 8 ? 8 : (R <= 16 ? R : 16);
+#endif
+}
 
 // doubles per (tile, knot) of a state array
 __host__ __device__ constexpr size_t m_knot_doubles(int R) { return (size_t)4 * R * 64; }
@@ -63,20 +72,23 @@ int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 // profiles/r03_large_m_experiments.txt.)
 //
 // R <= 8 (nx+nu <= 128): one row tile per wavefront, its operator tiles register-resident (above).
-// R = 9..32 (nx+nu <= 512, round 3): TWO to FOUR row tiles per wavefront (t = w, w + 8, ...), handled one after the other inside a step --
-// state in, GEMM, row-local phase, state out, twice, then the one barrier -- and the operator tiles STREAMED from L2 a batch
-// ahead of the matrix instructions that consume them: 2 x 4R doubles per lane no longer fit any register file, but a step
-// reads each operator tile once per workgroup (<= 512 KB per operator, L2-resident) while the matrix pipe works 2 x 4R x 64
-// cycles on it, so the stream costs bandwidth the kernel has (the state streams through HBM at a lower rate per flop than at
-// R <= 8: arithmetic intensity ~ nxu / 20).
+// R = 9..32 (nx+nu <= 512, round 3): the operator tiles are STREAMED from L2 a batch ahead of the matrix instructions that consume
+// them -- 4R doubles per lane and row tile no longer fit next to anything else -- from a tile-major copy of the operators
+// (k_tile_operators_m: one 512-byte line per load). Up to sixteen row tiles a workgroup has R wavefronts with ONE tile each
+// (nine tiles on eight wavefronts left seven of them waiting for the one that carried two); beyond, sixteen wavefronts carry two
+// tiles each, handled one after the other inside a step -- state in, GEMM, row-local phase, state out, twice, then the one
+// barrier. Sixteen wavefronts are four per SIMD: 128 registers, which the streamed form meets (123-128) because its tile loops
+// are never unrolled and never start from a constant the compiler can see (see the body). A step reads each operator tile once
+// per workgroup (<= 2 MB per operator, L2-resident) while the matrix pipe works 4R x 64 cycles per tile on it.
 template <int R, bool CT>
-__global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams p) {
+__global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;            // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
-    constexpr int TPW = (R + 7) / 8;     // row tiles per wavefront (1 .. 4)
+    constexpr int NW = m_waves(R);                 // wavefronts per workgroup
+    constexpr int TPW = (R + NW - 1) / NW;          // row tiles per wavefront (1 or 2)
     constexpr bool STREAM = R > 8;       // operator tiles from L2 instead of registers
     constexpr int GW = m_geometry(R);    // ops / tables geometry of these sizes: W = KT
     __shared__ __attribute__((aligned(16))) double sX[2][KB][64];  // operand vector of the step, double-buffered
-    __shared__ unsigned sFlag[2][M_WAVES];                          // per-wave "instance still below tolerance" masks
+    __shared__ unsigned sFlag[2][NW];                          // per-wave "instance still below tolerance" masks
     __shared__ double sTab[CT ? 3 : 1][GW];                         // CT: lo | hi | linref of every row
     __shared__ double sC[STREAM ? 2 : 1][STREAM ? GW : 1];          // two row tiles per wavefront: the sweep constants cf | cb
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,8 +110,8 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
 
     // this wave's result entries of its row tile tw (t = wv + 8 tw): e = 0..3 <-> reg = e, row = 16 t + kq + 4 e. Rows and their
     // kind are recomputed from the tile index where they are needed (cheap integer work) instead of living in masks.
-    auto tile_of = [&](int tw) -> int { return wv + M_WAVES * tw; };
-    auto has_tile = [&](int tw) -> bool { return (R == M_WAVES * TPW) || tile_of(tw) < R; };  // (uniform) this wave owns row tile tw
+    auto tile_of = [&](int tw) -> int { return wv + NW * tw; };
+    auto has_tile = [&](int tw) -> bool { return (R == NW * TPW) || tile_of(tw) < R; };  // (uniform) this wave owns row tile tw
     auto row_of = [&](int tw, int e) -> int { return 16 * tile_of(tw) + kq + 4 * e; };
     auto kind_of = [&](int tw, int e) -> int { const int r = row_of(tw, e); return !has_tile(tw) ? 0 : (r < nx ? 1 : (r < nxu ? 2 : 0)); };  // 1 state, 2 input, 0 padding
     auto slot = [&](int tw, int e) -> unsigned { return (unsigned)((4 * tile_of(tw) + e) * 64 + lane); };  // offset of entry e inside a knot
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     const int ct = p.check_termination;
     // lo / hi / linref of (row, knot): table row kn + 1
     if constexpr (CT) {
-        for (int i = tid; i < 3 * GW; i += 64 * M_WAVES) sTab[i / GW][i % GW] = p.tables[(unsigned)((i / GW) * TOFF + W + (i % GW))];
+        for (int i = tid; i < 3 * GW; i += 64 * NW) sTab[i / GW][i % GW] = p.tables[(unsigned)((i / GW) * TOFF + W + (i % GW))];
         __syncthreads();
     }
     auto tab = [&](int which, int kn, int tw, int e) -> double {
@@ -119,7 +131,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
     };
     const double *const cf_tab = p.ops + (size_t)2 * W * KT, *const cb_tab = cf_tab + W;
     if constexpr (STREAM) {
-        for (int i = tid; i < 2 * GW; i += 64 * M_WAVES) sC[i / GW][i % GW] = cf_tab[i];
+        for (int i = tid; i < 2 * GW; i += 64 * NW) sC[i / GW][i % GW] = cf_tab[i];
         __syncthreads();
     }
     // the constant term of a sweep's rows: in registers for the sweep (one row tile per wavefront), or from LDS at each step
@@ -151,7 +163,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         if (has_tile(tw)) {
             // operand reads run a batch of eight k-blocks ahead of the matrix instructions that consume them (left to the
             // scheduler they ran two ahead, and an MFMA issued every 78 cycles instead of every 64)
-            constexpr int BATCH = STREAM ? 4 : (CT ? 8 : (R == 8 ? 2 : 4));  // (per-knot tables: fewer registers to spare)
+            constexpr int BATCH = STREAM ? ((NW > 12 && (TPW == 1 || R == NW * TPW)) ? 2 : 4) : (CT ? 8 : (R == 8 ? 2 : 4));  // (streamed, sixteen wavefronts: 128 registers)  // (per-knot tables: fewer registers to spare)
             static_assert(KB % 4 == 0, "k-blocks come in fours");
             double b[2][BATCH], a[2][STREAM ? BATCH : 1];
             // (streamed: the tile-major copy of the operators, one 512-byte line per (row tile, k-block) -- read row-major, an
@@ -193,6 +205,10 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         for (int q = 0; q < 4; ++q) out[q] = c0[q] + d0[q];
     };
 
+    // (streamed kernels with ONE row tile per wavefront: the tile loops start from a zero the compiler cannot see through -- with a
+    // constant tile index it hoists every address of the sweeps out of them, 100+ registers, and spills)
+    int tw0 = 0;
+    if constexpr (STREAM && TPW == 1) asm volatile("" : "+s"(tw0));
     bool active = inst_ok;      // (per lane: its instance is still iterating)
     int it_done = 0, status = 11;
     bool res_valid = false;
@@ -211,7 +227,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         load_start(0);
         // operand of step 0: [x_0; d_0]; and knot 0 of the state rows: x_0 is given, only projected
 #pragma nounroll
-        for (int tw = 0; tw < TPW; ++tw) {
+        for (int tw = tw0; tw < TPW; ++tw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(tw, e);
@@ -245,7 +261,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         // arithmetic -- four serialised HBM round trips per step instead of one.
         for (int i = 0; i < T; ++i) {
 #pragma nounroll
-            for (int tw = 0; tw < TPW; ++tw) {  // (one copy of the code: unrolled, the second tile's addresses were hoisted and spilled)
+            for (int tw = tw0; tw < TPW; ++tw) {  // (one copy of the code: unrolled, the second tile's addresses were hoisted and spilled)
                 if (!has_tile(tw)) continue;
                 double pg[4], pv[4], pd[4], start[4];
                 const bool more = i + 1 < T;
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
             __syncthreads();
             unsigned all = 0xffffu;
 #pragma unroll
-            for (int w8 = 0; w8 < M_WAVES; ++w8) all &= sFlag[it & 1][w8];
+            for (int w8 = 0; w8 < NW; ++w8) all &= sFlag[it & 1][w8];
             conv = ((all >> jn) & 1u) != 0u;
             // the four inf-norms of this instance: maxima over its lanes in this wave now, over the waves after the loop
             if (active) {
@@ -326,7 +342,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         load_start(1);
         double *const Vn = par_read ? gVa : gVb;  // the slack written by this iteration's forward sweep
 #pragma nounroll
-        for (int tw = 0; tw < TPW; ++tw) {  // operand of step N-2: [p_{N-1}; r_{N-2}]
+        for (int tw = tw0; tw < TPW; ++tw) {  // operand of step N-2: [p_{N-1}; r_{N-2}]
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(tw, e);
@@ -346,7 +362,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         // forward operands (branch-free: padding rows and the input rows of step 0 load their own slot and drop it)
         for (int i = T - 1; i >= 0; --i) {
 #pragma nounroll
-            for (int tw = 0; tw < TPW; ++tw) {
+            for (int tw = tw0; tw < TPW; ++tw) {
                 if (!has_tile(tw)) continue;
                 double lv[4], lg[4], start[4];
 #pragma unroll
@@ -390,7 +406,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         double *const Vsol = last_written_is_b ? gVb : gVa;
         double *const Vold = last_written_is_b ? gVa : gVb;
 #pragma nounroll
-        for (int tw = 0; tw < TPW; ++tw) {
+        for (int tw = tw0; tw < TPW; ++tw) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kd = kind_of(tw, e), rw = row_of(tw, e);
@@ -429,7 +445,7 @@ __global__ void __launch_bounds__(64 * M_WAVES) k_admm_solve_m(const SolveParams
         if (res_valid) {
             for (int q = 0; q < 4; ++q) {
                 double v = 0.0;
-                for (int w8 = 0; w8 < M_WAVES; ++w8) v = fmax(v, sR[(w8 * 4 + q) * 16 + jn]);
+                for (int w8 = 0; w8 < NW; ++w8) v = fmax(v, sR[(w8 * 4 + q) * 16 + jn]);
                 p.dstats[inst * 4 + q] = (q == 1 || q == 3) ? v * rho : v;
             }
         }
@@ -463,8 +479,8 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
     const int tiles = (p.batch + M_INST - 1) / M_INST;
 #define TINY_M_LAUNCH(R_)                                                                                                \
     case R_:                                                                                                              \
-        if (p.const_tables) hipLaunchKernelGGL((k_admm_solve_m<R_, true>), dim3(tiles), dim3(64 * M_WAVES), 0, stream, p); \
-        else hipLaunchKernelGGL((k_admm_solve_m<R_, false>), dim3(tiles), dim3(64 * M_WAVES), 0, stream, p);              \
+        if (p.const_tables) hipLaunchKernelGGL((k_admm_solve_m<R_, true>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p); \
+        else hipLaunchKernelGGL((k_admm_solve_m<R_, false>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p);              \
         break;
     switch (R) {
         TINY_M_LAUNCH(5)
