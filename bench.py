@@ -641,6 +641,28 @@ def main() -> int:
                                         "layout": vbig.launch_info()["layout"], "kernel": "k_admm_solve_m<32> (four row tiles per wavefront, streamed operator tiles)",
                                         **leg_counters("very_large_system", vB * vit / (med * 1e-3))}
             vbig.reset()
+            # BASELINE config 1: cartpole nx=4 nu=1 N=20, box input constraints, 200 ADMM iterations -- one instance (the reference's
+            # example as it stands) and a batch of 8,192 (layout D's compiled-in cartpole shape)
+            cp = P.cartpole(20, True)
+            cart = {}
+            for cB in (1, 8192):
+                cs = pkg.TinyMPC()
+                cs.setup(cp.A, cp.B, cp.Q, cp.R, cp.N, batch=cB, device=local_rank, rho=cp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200)
+                cs.set_bound_constraints(cp.x_min, cp.x_max, cp.u_min, cp.u_max)
+                if cB == 1:
+                    cs.set_x0(cp.x0)
+                else:
+                    cs.set_x0_batch(np.asfortranarray(cp.x0[:, None] * np.linspace(0.5, 1.5, cB)[None, :]))
+                ms = []
+                for k in range(6):
+                    cs.reset_workspace()
+                    ms.append(cs.solve_timed())
+                med = sorted(ms[1:])[2]
+                key = "one_instance" if cB == 1 else "batch_8192"
+                cart[key] = {"kernel_ms": med, "iters_per_s": cB * 200 / (med * 1e-3), "us_per_iter": 1e3 * med / 200 if cB == 1 else None,
+                             "layout": cs.launch_info()["layout"], "fp64_frac": cB * 200 * cp.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
+                cs.reset()
+            out["cartpole"] = dict(workload="BASELINE config 1: cartpole nx=4 nu=1 N=20, box input constraints, 200 forced iterations", **cart)
             # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
             # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
             # (Mean, median and maximum of the 200 timed ticks: one tick in a few thousand takes milliseconds -- 41 ms once in this
