@@ -242,9 +242,11 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
  * tinympc_set_cone_constraints and tinympc_set_linear_constraints (the resident kernel carries the settings and
  * families it was launched with): call tinympc_session_begin again afterwards. The resident kernel leaves on its own
  * after 2 s without a command (a crashed host does not leave it spinning); the next step restarts it transparently.
- * While the resident kernel spins, calls that synchronise the whole DEVICE (hipFree / hipMalloc of another handle's
- * setup or reset, hipDeviceSynchronize, torch.cuda.synchronize) wait for it -- up to the 2 s idle time-out: end the
- * session before such calls. The resident kernel is layout C's: its results are identical, bit for bit, to the same
+ * While the resident kernel spins, calls that synchronise the whole DEVICE wait for it -- up to the 2 s idle time-out.
+ * This library's own such calls (tinympc_setup / tinympc_reset of ANOTHER handle on the device: hipMalloc / hipFree) first
+ * send the resident kernels of the device home; their sessions stay open and the next tinympc_session_step starts the
+ * kernel again (a few milliseconds, once). Calls from outside the library (hipDeviceSynchronize, torch.cuda.synchronize,
+ * somebody else's hipMalloc) cannot be seen coming: end the session before them. The resident kernel is layout C's: its results are identical, bit for bit, to the same
  * ticks issued as tinympc_mpc_step_batch calls on that kernel (with the cone / linear families a launched tick runs on
  * layout F by default, whose results differ in the last bits: the carries of its chunks round differently). */
 int tinympc_session_begin(tinympc_solver *s);

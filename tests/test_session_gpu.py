@@ -144,3 +144,43 @@ def test_receding_horizon_references_travel_as_one_column(pkg):
     np.testing.assert_array_equal(a.mpc_step(x)[:, 0], b.mpc_step(x)[:, 0])  # device copies / tables were restaged
     a.reset()
     b.reset()
+
+
+def test_setup_and_reset_of_another_handle_do_not_wait_for_the_resident_kernel(pkg):
+    """hipMalloc / hipFree synchronise the device; with a resident session kernel spinning they used to block until its idle
+    time-out (2 s). The library now sends the device's resident kernels home first; the session stays open, the next step
+    restarts the kernel and continues from the same ADMM state: the controls equal those of an undisturbed session."""
+    import time
+    prob = pkg.problems.quadrotor(20)
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+
+    def handle():
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, **settings)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        return s
+
+    a, ref = handle(), handle()
+    a.session_begin()
+    ref.session_begin()
+    x, us, ur = prob.x0.copy(), [], []
+    for k in range(12):
+        if k == 5:  # another handle comes and goes while `a`'s kernel is resident
+            t0 = time.perf_counter()
+            ref.session_end()  # (the reference session steps aside itself: this test is about `a`)
+            other = handle()
+            other.set_x0(prob.x0)
+            other.solve()
+            other.reset()
+            dt = time.perf_counter() - t0
+            assert dt < 1.0, f"setup + solve + reset of another handle took {dt:.2f} s with a session open"
+            ref.session_begin()
+        ua, ub = a.session_step(x), ref.session_step(x)
+        us.append(ua)
+        ur.append(ub)
+        x = prob.A @ x + prob.B @ ua
+    a.session_end()
+    ref.session_end()
+    np.testing.assert_array_equal(np.array(us), np.array(ur))
+    a.reset()
+    ref.reset()

@@ -78,6 +78,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     } while (0)
 
     HIP_TRY_S(hipSetDevice(s->device));
+    park_sessions_on_device(s->device, s);  // (the allocations below synchronise the device)
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY_S(hipEventCreate(&s->ev0));
     HIP_TRY_S(hipEventCreate(&s->ev1));

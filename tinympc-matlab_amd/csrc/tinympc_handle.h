@@ -223,6 +223,10 @@ int launch(tinympc_solver *s, bool timed);
 
 // ---- tinympc_session.hip
 int end_session(tinympc_solver *s);
+// Resident session kernels of OTHER handles on `device` are sent home before anything that synchronises the device (hipMalloc /
+// hipFree in setup and teardown): such a call would otherwise stall until the spinning kernel's idle time-out (2 s). Their
+// sessions stay open: the next session_step finds the kernel gone and starts it again (its restart path).
+void park_sessions_on_device(int device, const tinympc_solver *except);
 
 }  // namespace host
 }  // namespace tinympc

@@ -245,6 +245,7 @@ void destroy(tinympc_solver *s) {
     // teardown is best effort: errors here have nowhere useful to go
     (void)hipSetDevice(s->device);
     if (s->session_active) (void)end_session(s);
+    park_sessions_on_device(s->device, s);  // (hipFree synchronises the device: no other handle's resident kernel may be spinning)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
     if (s->h_sol) (void)hipHostFree(s->h_sol);

@@ -3,7 +3,10 @@
 // per tick. Host side only: the mailbox protocol, the (re)start of the resident kernel, the verbs.
 #include "tinympc_handle.h"
 
+#include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <chrono>
 #include <cstring>
 
@@ -74,8 +77,33 @@ int launch_session_kernel(tinympc_solver *s) {
 
 }  // namespace
 
+namespace {
+std::mutex g_sessions_mu;
+std::vector<tinympc_solver *> g_sessions;  // handles whose session is open
+void session_registry(tinympc_solver *s, bool open) {
+    std::lock_guard<std::mutex> lock(g_sessions_mu);
+    auto it = std::find(g_sessions.begin(), g_sessions.end(), s);
+    if (open && it == g_sessions.end()) g_sessions.push_back(s);
+    if (!open && it != g_sessions.end()) g_sessions.erase(it);
+}
+}  // namespace
+
+void tinympc::host::park_sessions_on_device(int device, const tinympc_solver *except) {
+    std::vector<tinympc_solver *> open;
+    {
+        std::lock_guard<std::mutex> lock(g_sessions_mu);
+        open = g_sessions;
+    }
+    for (tinympc_solver *o : open) {
+        if (o == except || o->device != device || !o->session_active) continue;
+        write_command(o, 1, nullptr);                 // stop: the kernel writes its state back and leaves
+        (void)hipStreamSynchronize(o->stream);        // (session_active stays set: session_step restarts the kernel)
+    }
+}
+
 int tinympc::host::end_session(tinympc_solver *s) {
     if (!s->session_active) return TINYMPC_OK;
+    session_registry(s, false);
     write_command(s, 1, nullptr);  // stop
     s->session_active = false;     // (before anything that could come back here)
     if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
@@ -105,6 +133,7 @@ int tinympc_session_begin(tinympc_solver *s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = launch_session_kernel(s))) return rc;
     s->session_active = true;
+    session_registry(s, true);
     s->flag_pending = false;
     return TINYMPC_OK;
 }
@@ -135,11 +164,12 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
                 // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
                 // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
                 rc = launch_session_kernel(s);  // waits for session_seq + 1
-                if (rc) { s->session_active = false; return rc; }
+                if (rc) { s->session_active = false; session_registry(s, false); return rc; }
                 write_command(s, 0, x0);
                 want = (double)s->session_seq;
             } else if (q != hipErrorNotReady) {
                 s->session_active = false;
+                session_registry(s, false);
                 return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
             }
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
