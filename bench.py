@@ -677,7 +677,12 @@ def main() -> int:
                 if mode == "session":
                     tk.session_begin()
                 x = prob.x0.copy()
-                t_acc, its, dts = 0.0, 0, []
+                t_acc, its, dts, slow = 0.0, 0, [], []
+                import ctypes as _C
+                _L = pkg.load_library()
+                _L.tinympc_debug_tick_timing.restype = _C.c_int
+                _L.tinympc_debug_tick_timing.argtypes = [_C.c_void_p, _C.POINTER(_C.c_double)]
+                split = (_C.c_double * 4)()
                 for k in range(220):
                     t0 = time.perf_counter()
                     u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
@@ -686,11 +691,17 @@ def main() -> int:
                         t_acc += dt
                         dts.append(dt)
                         its += int(tk.get_stats()["iter"])
+                        if dt > 1e-3 and mode == "launch" and len(slow) < 4:  # where did a millisecond tick spend its time?
+                            _L.tinympc_debug_tick_timing(tk._h, split)
+                            slow.append({"tick": k, "us": 1e6 * dt, "library_launch_call_us": split[0], "library_wait_us": split[1],
+                                         "polls": int(split[2]), "polling_budget_ran_out": bool(split[3])})
                     x = prob.A @ x + prob.B @ u0
                 if mode == "session":
                     tk.session_end()
                 tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick_max": 1e6 * float(np.max(dts)),
                               "iterations_per_tick": its / 200}
+                if slow:
+                    tick[mode]["ticks_above_1ms"] = slow
                 tk.reset()
             out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
         if cpu is not None:
