@@ -9,8 +9,8 @@
 // on v_mfma_f64_16x16x4_f64 tiles -- FP64 MFMA has the VALU's peak on MI355X (tools/microbench_mfma_f64.hip), but it shares
 // the operator tile between 16 instances and needs no per-column operand broadcast.
 //
-// One workgroup = 8 wavefronts = one tile of 16 instances. Wavefront w owns the 16-row output tile t = w (R = ceil(nxu / 16)
-// <= 8 tiles; wavefronts beyond R only take part in the barriers) and keeps its operator tiles register-resident for a whole
+// Up to 128 rows: one workgroup = 8 wavefronts = one tile of 16 instances. Wavefront w owns the 16-row output tile t = w (R =
+// ceil(nxu / 16) <= 8 tiles; wavefronts beyond R only take part in the barriers) and keeps its operator tiles register-resident for a whole
 // sweep: A[kb] = the 16 x 4 block (rows 16w.., columns 4kb..), one double per lane, 4R <= 32 doubles. (The first version gave
 // a wavefront two row tiles and a workgroup four wavefronts: 408 VGPRs, one wavefront per SIMD, and every wait for state or
 // for the exchange left its SIMD idle -- 18 M iterations/s at nx=96 against 22.5 M now. Half the rows per wavefront halve
@@ -29,7 +29,7 @@
 #include "tinympc_device.h"
 
 #ifndef TINY_EXP_M
-#define TINY_EXP_M 0  // timing experiments (tools/build_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs, 3 = cycle stamps of one forward step
+#define TINY_EXP_M 0  // timing experiments (tools/build_m_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs
 #endif
 
 namespace tinympc {
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
     }
     // residual norms of the last check: max over this instance's lanes in the wave, then over the wavefronts of the tile
     __syncthreads();
-    double *sR = &sX[0][0][0];  // reuse: [8 waves][4 norms][16 instances]
+    double *sR = &sX[0][0][0];  // reuse: [NW waves][4 norms][16 instances]
     {
         double v4[4] = {snap_pri_x, snap_dua_x, snap_pri_u, snap_dua_u};
 #pragma unroll
