@@ -448,7 +448,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
 }  // namespace tinympc
 
 // (two wavefronts per SIMD wherever the workgroup has more than four)
-extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, 2)))
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, (TINY_JIT_F_WPG + 3) / 4 > 2 ? (TINY_JIT_F_WPG + 3) / 4 : 2)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
     constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL);
