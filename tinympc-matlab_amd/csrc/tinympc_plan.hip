@@ -86,8 +86,9 @@ int decide_layout_f(tinympc_solver *s) {
     const bool fam = s->families_active();
     const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && !s->session_active && s->N >= 6;
     // Default: the families at small batches -- rocket landing N=100, one instance: 4.5 us per iteration against 6.55 on the
-    // round-1 latency kernel. The box path stays on layout C (quadrotor N=50: 2.9 us against 3.4 here: chunks of two slots leave the
-    // carry scans most of the iteration).
+    // round-1 latency kernel. The box path stays on layout C: with four wavefronts (plan_f) layout F is 4 % ahead there too
+    // (quadrotor N=50: 2.75 against 2.86 us), but layout C stages per-tick references from pinned memory inside the kernel, runs the
+    // resident session (bit-identical ticks) and needs no run-time specialisation for a new shape.
     bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin && s->fam_c;
     if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
     if (!want) {
