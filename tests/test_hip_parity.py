@@ -790,3 +790,56 @@ def test_chunked_layout_horizon_boundaries(pkg, kernel_layout, N):
             o.solve()
             assert st["iter"][b] == o.stats()["iter"], (N, b)
         s.reset()
+
+
+@pytest.mark.parametrize("shape", ["quadrotor50", "wide24"])
+def test_reset_workspace_is_a_contract_not_a_memset(pkg, monkeypatch, shape):
+    """tinympc_reset_workspace no longer writes zeros into G, V, D: layout D starts a cold solve from zero registers
+    (SolveParams::cold) and every other kernel gets the zeros written first (materialize_cold_state). Whatever runs between the
+    reset and the next real solve -- nothing, a solve of zero iterations (writes nothing back), a launch on another kernel -- the
+    cold solve must reproduce the handle's very first solve bit for bit, and a warm start behind it the first warm start."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    if shape == "quadrotor50":
+        prob, batch = P.quadrotor(50), 1300
+        x0s = np.asfortranarray(P.quadrotor_batch_x0(batch))
+    else:
+        rng = np.random.default_rng(0)
+        nx, nu, batch = 24, 8, 300
+        prob = P.Problem("wide", np.eye(nx) + 0.03 * rng.standard_normal((nx, nx)), 0.1 * rng.standard_normal((nx, nu)), np.diag(rng.uniform(1, 10, nx)),
+                         np.diag(rng.uniform(0.5, 2, nu)), 30, 2.0, rng.standard_normal(nx))
+        prob.x_min, prob.x_max, prob.u_min, prob.u_max = np.full(nx, -2.0), np.full(nx, 2.0), np.full(nu, -0.3), np.full(nu, 0.3)
+        x0s = np.asfortranarray(prob.x0[:, None] + 0.1 * rng.standard_normal((nx, batch)))
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, max_iter=25, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    s.set_x0_batch(x0s)
+    s.solve()
+    assert s.launch_info()["layout"] == "D"
+    cold = s.get_solution_batch()["controls"].copy()
+    s.solve()
+    warm = s.get_solution_batch()["controls"].copy()
+    assert not np.array_equal(cold, warm)
+    for between in ("nothing", "zero_iterations", "other_kernel"):
+        s.reset_workspace()
+        if between == "zero_iterations":
+            s.update_settings(max_iter=0)
+            s.solve()
+            assert np.all(s.get_solution_batch()["controls"] == 0.0)
+            s.update_settings(max_iter=25)
+        if between == "other_kernel":  # a zero-iteration... no: one real cold solve on layout B / A, then reset again and back to layout D
+            monkeypatch.setenv("TINYMPC_LAYOUT", "A")
+            t = pkg.TinyMPC()
+            t.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=8, rho=prob.rho, max_iter=25, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+            t.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            t.set_x0_batch(x0s[:, :8])
+            t.reset_workspace()
+            t.solve()
+            np.testing.assert_allclose(t.get_solution_batch()["controls"], cold[:, :, :8], rtol=0, atol=1e-9 * np.max(np.abs(cold)))
+            t.reset()
+            monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+        s.solve()
+        np.testing.assert_array_equal(s.get_solution_batch()["controls"], cold, err_msg=between)
+        s.solve()
+        np.testing.assert_array_equal(s.get_solution_batch()["controls"], warm, err_msg=between)
+    s.reset()

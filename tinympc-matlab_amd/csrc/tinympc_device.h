@@ -161,6 +161,10 @@ struct SolveParams {
     const double *href_x, *href_u;  // nx x N, nu x (N-1), column-major, pinned host
     double *dXref, *dUref;          // their device copies (kept current for the other kernels)
     const double *Pinf;             // for pNref (admm.cpp:81)
+    // Cold start without the traffic: the persistent state (G, V, D) is all zeros by CONTRACT (tinympc_reset_workspace, a fresh
+    // handle) and has not been materialised in HBM -- the kernel starts from zero registers / LDS instead of loading 14 KB of zeros
+    // per instance. Only set for kernels that honour it (layout D and its wide forms); the host zeroes the arrays for every other kernel.
+    int cold;
 };
 
 struct ChunkTableParams {

@@ -88,6 +88,7 @@ struct tinympc_solver {
     // adaptive rho / session.
     bool layout_m = false;
     double dbg_tick[4] = {0.0, 0.0, 0.0, 0.0};  // tinympc_debug_tick_timing
+    bool cold_state = false;  // G, V, D are zero by contract (reset_workspace) but NOT yet zeroed in HBM: see SolveParams::cold
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
     int d_adapt = -1;       // ... and with adaptive rho
     int d_fam = -1;         // layout D with the cone / linear families (run-time specialised, short horizons): -1 not asked yet, 0 no, 1 yes
@@ -227,6 +228,8 @@ int end_session(tinympc_solver *s);
 // hipFree in setup and teardown): such a call would otherwise stall until the spinning kernel's idle time-out (2 s). Their
 // sessions stay open: the next session_step finds the kernel gone and starts it again (its restart path).
 void park_sessions_on_device(int device, const tinympc_solver *except);
+// Writes the zeros of a pending cold start into G, V, D (for a kernel that loads its state from HBM whatever its value).
+int materialize_cold_state(tinympc_solver *s);
 
 }  // namespace host
 }  // namespace tinympc

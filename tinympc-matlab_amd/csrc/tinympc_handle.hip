@@ -63,6 +63,15 @@ int check_handle(const tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+int materialize_cold_state(tinympc_solver *s) {
+    if (!s->cold_state) return TINYMPC_OK;
+    HIP_TRY(hipMemsetAsync(s->dG, 0, sizeof(double) * s->state_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dV, 0, sizeof(double) * s->v_doubles(), s->stream));
+    HIP_TRY(hipMemsetAsync(s->dD, 0, sizeof(double) * s->d_doubles(), s->stream));
+    s->cold_state = false;
+    return TINYMPC_OK;
+}
+
 int run_precompute(tinympc_solver *s) {
     PrecomputeParams p{};
     p.nx = s->nx; p.nu = s->nu; p.rho = s->rho;

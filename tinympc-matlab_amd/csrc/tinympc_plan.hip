@@ -278,6 +278,12 @@ int launch(tinympc_solver *s, bool timed) {
     }
     p.adapt = s->dadapt; p.rho_inst = s->drho_inst;
     p.rho_min = s->st.adaptive_rho_min; p.rho_max = s->st.adaptive_rho_max; p.rho_clip = s->st.adaptive_rho_enable_clipping;
+    // a pending cold start: layout D's kernels start from zero registers; every other kernel loads its state from HBM
+    // (a solve of zero iterations writes nothing back: the zeros must then be in HBM)
+    const bool kernel_takes_cold = (pl.kernel == KernelId::D_COMPILED || pl.kernel == KernelId::D_JIT) && s->st.max_iter > 0;
+    if (s->cold_state && !kernel_takes_cold && (rc = materialize_cold_state(s))) return rc;
+    p.cold = s->cold_state ? 1 : 0;
+    s->cold_state = false;  // (the launch below writes the state back)
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     switch (pl.kernel) {
         case KernelId::M:

@@ -210,9 +210,15 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double *const gV1u = p.V2 + (g0 * v_rows(N) + V_PAD) * 64;         // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset)
     const unsigned voff = (unsigned)(lane + koff * 64);
     double *const sVl = sV + lane;
+    const bool cold = p.cold != 0;  // (uniform) the state is zero by contract and was never written to HBM: nothing to load
     if (grp_ok) {
-        for (int i = lane; i < NS * DS; i += 64) sD[i] = gD[i];
-        static_for<0, VL>([&](auto S) { sVl[S.value * 64] = gV0[(S.value + koff) * 64]; });
+        if (cold) {
+            for (int i = lane; i < NS * DS; i += 64) sD[i] = 0.0;
+            static_for<0, VL>([&](auto S) { sVl[S.value * 64] = 0.0; });
+        } else {
+            for (int i = lane; i < NS * DS; i += 64) sD[i] = gD[i];
+            static_for<0, VL>([&](auto S) { sVl[S.value * 64] = gV0[(S.value + koff) * 64]; });
+        }
     }
     __syncthreads();  // the only workgroup-wide barrier: from here on the waves are independent
     if (!grp_ok) return;
@@ -222,10 +228,17 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
     // ---- register-resident state
     double G[NS], G0, Vr[NVR > 0 ? NVR : 1], V0;
-    static_for<0, NS>([&](auto S) { G[S.value] = gG[(S.value + koff) * 64]; });
-    static_for<0, NVR>([&](auto S) { Vr[S.value] = gV0[(VL + S.value + koff) * 64]; });
-    G0 = gG[0];
-    V0 = gV0[0];
+    if (cold) {
+        static_for<0, NS>([&](auto S) { G[S.value] = 0.0; });
+        static_for<0, NVR>([&](auto S) { Vr[S.value] = 0.0; });
+        G0 = 0.0;
+        V0 = 0.0;
+    } else {
+        static_for<0, NS>([&](auto S) { G[S.value] = gG[(S.value + koff) * 64]; });
+        static_for<0, NVR>([&](auto S) { Vr[S.value] = gV0[(VL + S.value + koff) * 64]; });
+        G0 = gG[0];
+        V0 = gV0[0];
+    }
     // FAM state: slot s <-> knot s + koff, like G / V (the arrays GC / GL have V's shape)
     double GCr[FAM ? NS : 1], GLr[FAM ? NS : 1], LX[FAM ? NS : 1], GC0 = 0.0, GL0 = 0.0;
     double cn[KT], ct_[KT], ty[KT];
