@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-settle", action="store_true", help="time the K steps right behind the W warm-up steps (the GPU's clock is then still ramping up)")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the 65,536-instance single-GPU leg")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -336,6 +337,18 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Settle: this process has just spent ~30 s on the CPU baseline with the GPU idle, and the first launches after that run at a
+    # lower shader clock -- 1.81 ms per launch in the first 25, 1.72 from about the 50th on (in-kernel stamps: tools/clock_check.py).
+    # W = 5 warm-up steps end inside that ramp, so the step is repeated, untimed, until 0.4 s have passed; what the ramp looked
+    # like is reported (`settle`: kernel time of the first and of the last ten launches).
+    settle = {"launches": 0, "seconds": 0.0}
+    if not args.no_settle:
+        ts0 = time.perf_counter()
+        sms = []
+        while time.perf_counter() - ts0 < 0.4 and len(sms) < 600:
+            sms.append(step())
+        settle = {"launches": len(sms), "seconds": time.perf_counter() - ts0, "first_launches_kernel_ms": float(np.mean(sms[:10])),
+                  "last_launches_kernel_ms": float(np.mean(sms[-10:]))}
     for _ in range(args.warmup):
         step()
     barrier()
@@ -418,6 +431,8 @@ def main() -> int:
                        "batch_per_gpu": B, "global_batch": total_instances, "iters_per_solve": args.iters,
                        "parallelism": "independent instances sharded x%d, no data-path collective" % world},
             "solves_per_s": value / args.iters,
+            "settle": dict(settle, note="untimed repetitions of the step before the W warm-up steps, until 0.4 s have passed: the GPU idles during the "
+                                        "CPU baseline and its first launches run at a lower clock; first / last = mean kernel time of the first / last ten"),
             "roofline": {"bound": "fp64_vector", "achieved": achieved_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname + "<%d lanes/instance>" % info["lanes_per_instance"], "kernel_ms_avg": kernel_ms_avg,
