@@ -464,6 +464,7 @@ int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, 
         return TINYMPC_OK;
     }
     if ((rc = bind_device(s))) return rc;
+    if ((rc = materialize_zero_solution(s))) return rc;
     if (x_out && (rc = download(s, x_out, s->dsolx + (size_t)first * s->X(), sizeof(double) * s->X() * count))) return rc;
     if (u_out && (rc = download(s, u_out, s->dsolu + (size_t)first * s->U(), sizeof(double) * s->U() * count))) return rc;
     return TINYMPC_OK;
@@ -482,6 +483,7 @@ int tinympc_get_first_controls_batch(tinympc_solver *s, double *u0_out, int firs
     if (first < 0 || count < 0 || first + count > s->batch)
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
     if ((rc = bind_device(s))) return rc;
+    if ((rc = materialize_zero_solution(s))) return rc;
     HIP_TRY(hipMemcpy2DAsync(u0_out, sizeof(double) * s->nu, s->dsolu + (size_t)first * s->U(), sizeof(double) * s->U(),
                              sizeof(double) * s->nu, count, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -868,11 +870,8 @@ int tinympc_reset_workspace(tinympc_solver *s) {
         HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
         HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
     }
-    HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
-    HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
-    HIP_TRY(hipMemsetAsync(s->distats, 0, sizeof(int) * s->batch * 2, s->stream));
-    HIP_TRY(hipMemsetAsync(s->ddstats, 0, sizeof(double) * s->batch * 4, s->stream));
-    HIP_TRY(launch_fill(s->drho_inst, (size_t)s->batch, s->rho, s->stream));  // adapted rho back to the setup value
+    s->sol_zero_pending = true;  // (sol_x / sol_u: zero by contract; the next solve overwrites them, a reader before that gets zeros written first)
+    HIP_TRY(launch_reset_stats(s->distats, s->ddstats, s->drho_inst, s->batch, s->rho, s->stream));  // (adapted rho back to the setup value)
     s->host_sol_state = 0;  // the device solution / statistics were just zeroed: read them from there
     return TINYMPC_OK;
 }
@@ -889,6 +888,8 @@ int tinympc_get_rho_batch(tinympc_solver *s, double *rho_out, int first, int cou
 int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if ((rc = materialize_zero_solution(s))) return rc;
     if (d_x) *d_x = s->dsolx;
     if (d_u) *d_u = s->dsolu;
     return TINYMPC_OK;

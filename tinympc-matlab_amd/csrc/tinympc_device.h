@@ -265,6 +265,7 @@ hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream);  // asynchronous constant fill
+hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int batch, double rho, hipStream_t stream);
 size_t lqr_scratch_doubles(int nx, int nu);
 // The same precompute for large systems (nx+nu > 64; tinympc_precompute_large.hip): every matrix product of an iteration its own
 // launch on the FP64 matrix cores; blocks on the stream while it looks at the data-dependent iteration count.

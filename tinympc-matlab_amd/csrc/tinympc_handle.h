@@ -88,6 +88,7 @@ struct tinympc_solver {
     // adaptive rho / session.
     bool layout_m = false;
     double dbg_tick[4] = {0.0, 0.0, 0.0, 0.0};  // tinympc_debug_tick_timing
+    bool sol_zero_pending = false;  // the device solution is zero by contract (reset_workspace), not yet zeroed: every solve of >= 1 iteration overwrites all of it
     bool cold_state = false;  // G, V, D are zero by contract (reset_workspace) but NOT yet zeroed in HBM: see SolveParams::cold
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
     int d_adapt = -1;       // ... and with adaptive rho
@@ -230,6 +231,8 @@ int end_session(tinympc_solver *s);
 void park_sessions_on_device(int device, const tinympc_solver *except);
 // Writes the zeros of a pending cold start into G, V, D (for a kernel that loads its state from HBM whatever its value).
 int materialize_cold_state(tinympc_solver *s);
+// ... and of a pending zero solution into sol_x / sol_u (before anything reads them that no solve has written since the reset).
+int materialize_zero_solution(tinympc_solver *s);
 
 }  // namespace host
 }  // namespace tinympc

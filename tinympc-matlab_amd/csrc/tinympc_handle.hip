@@ -72,6 +72,14 @@ int materialize_cold_state(tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+int materialize_zero_solution(tinympc_solver *s) {
+    if (!s->sol_zero_pending) return TINYMPC_OK;
+    HIP_TRY(hipMemsetAsync(s->dsolx, 0, sizeof(double) * s->X() * s->batch, s->stream));
+    HIP_TRY(hipMemsetAsync(s->dsolu, 0, sizeof(double) * s->U() * s->batch, s->stream));
+    s->sol_zero_pending = false;
+    return TINYMPC_OK;
+}
+
 int run_precompute(tinympc_solver *s) {
     PrecomputeParams p{};
     p.nx = s->nx; p.nu = s->nu; p.rho = s->rho;

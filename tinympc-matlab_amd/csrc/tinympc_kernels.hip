@@ -396,6 +396,25 @@ __global__ void __launch_bounds__(256) k_fill(double *dst, size_t count, double 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = value;
 }
 
+// The small per-instance arrays of a workspace reset in ONE launch: iteration count / status <- 0, the four residual norms <- 0, rho <- the
+// setup value (three separate operations were three launch gaps of a 1.76 ms cold-started step).
+__global__ void __launch_bounds__(256) k_reset_stats(int *istats, double *dstats, double *rho_inst, int batch, double rho) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < batch; i += gridDim.x * 256) {
+        istats[2 * i] = 0;
+        istats[2 * i + 1] = 0;
+        dstats[4 * i] = 0.0;
+        dstats[4 * i + 1] = 0.0;
+        dstats[4 * i + 2] = 0.0;
+        dstats[4 * i + 3] = 0.0;
+        rho_inst[i] = rho;
+    }
+}
+hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int batch, double rho, hipStream_t stream) {
+    const int blocks = (batch + 255) / 256;
+    hipLaunchKernelGGL(k_reset_stats, dim3(blocks < 1024 ? (blocks ? blocks : 1) : 1024), dim3(256), 0, stream, istats, dstats, rho_inst, batch, rho);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream) {
     const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_fill, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, count, value);

@@ -284,6 +284,8 @@ int launch(tinympc_solver *s, bool timed) {
     if (s->cold_state && !kernel_takes_cold && (rc = materialize_cold_state(s))) return rc;
     p.cold = s->cold_state ? 1 : 0;
     s->cold_state = false;  // (the launch below writes the state back)
+    if (s->st.max_iter > 0) s->sol_zero_pending = false;  // (every instance writes its whole solution)
+    else if ((rc = materialize_zero_solution(s))) return rc;
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     switch (pl.kernel) {
         case KernelId::M:

@@ -53,6 +53,7 @@ int launch_session_kernel(tinympc_solver *s) {
     const bool fam = s->families_active();
     if (fam && (rc = refresh_families(s))) return rc;
     if ((rc = materialize_cold_state(s))) return rc;  // (the resident kernel loads its state from HBM)
+    if ((rc = materialize_zero_solution(s))) return rc;
     SolveParams p{};
     p.nx = s->nx; p.nu = s->nu; p.N = s->N; p.batch = 1;
     p.max_iter = s->st.max_iter; p.check_termination = s->st.check_termination;
