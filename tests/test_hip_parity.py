@@ -335,7 +335,7 @@ def test_full_size_batch_properties(pkg):
     (1) every instance equals the single-instance solve of the same x0 (spot-checked against the
     oracle on a seeded sample), (2) permutation equivariance: reversing the instance order reverses
     the solutions bit for bit, (3) feasibility of the projected solution, (4) idempotence of a
-    0-iteration solve."""
+    0-iteration solve, (5) odd symmetry in x0."""
     P = pkg.problems
     prob = P.quadrotor(50)
     settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=40, check_termination=1)
@@ -363,6 +363,15 @@ def test_full_size_batch_properties(pkg):
     s.update_settings(max_iter=0)
     s.solve()
     np.testing.assert_array_equal(s.get_solution_batch()["controls"], sol_r["controls"])
+    # (5) odd symmetry: with bounds symmetric about zero, zero references and no affine term every operation of the solve is odd
+    # in x0 (mat-vecs, the clamp, the dual update; the residual maxima are even) -- the negated batch gives the negated trajectories
+    s.update_settings(max_iter=40)
+    s.reset_workspace()
+    s.set_x0_batch(np.ascontiguousarray(-x0s))
+    s.solve()
+    sol_n = s.get_solution_batch()
+    np.testing.assert_array_equal(sol_n["controls"], -sol["controls"])
+    np.testing.assert_array_equal(sol_n["states"], -sol["states"])
     s.reset()
 
 
