@@ -612,3 +612,48 @@ def test_families_on_wide_systems(pkg, kernel_layout, monkeypatch, nx, nu, N, ba
             assert st["iter"][b] == orc[b].stats()["iter"] and st["status"][b] == orc[b].stats()["status"], (rnd, b)
             assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
     s.reset()
+
+
+def test_rocket_batch_properties_at_bench_size(pkg, kernel_layout, monkeypatch):
+    """BASELINE config 4 in the batch the bench times (4,096 rocket landings, N=100, cones + linear row + fdyn, layout E): properties
+    that need no oracle -- reversing the instance order reverses the results bit for bit; equal initial states give equal results
+    wherever they sit in the batch; the thrust cone and the box hold on every converged instance; a seeded sample against the
+    restatement."""
+    if kernel_layout != "A":
+        pytest.skip("one pass is enough")
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    rk = pkg.problems.rocket(100)
+    settings = dict(max_iter=150, abs_pri_tol=1e-2, abs_dua_tol=1e-2)
+    B = 4096
+    rng = np.random.default_rng(11)
+    x0s = rk.x0[:, None] * rng.uniform(0.6, 1.2, (1, B)) + 0.05 * rng.standard_normal((6, B))
+    x0s[:, 1000] = x0s[:, 7]      # duplicates far apart (different wavefronts, different workgroups)
+    x0s[:, 4095] = x0s[:, 7]
+    s = make(pkg, rk, settings, batch=B)
+    s.set_x0_batch(x0s)
+    s.solve()
+    assert s.launch_info()["layout"] == "E", s.jit_info()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    for b in (1000, 4095):
+        np.testing.assert_array_equal(sol["controls"][:, :, b], sol["controls"][:, :, 7])
+        assert st["iter"][b] == st["iter"][7]
+    conv = st["status"] == 1
+    assert conv.sum() > 500  # (a third of the landings converge within 150 iterations at this tolerance)
+    u = sol["controls"][:, :, conv]
+    assert np.max(np.linalg.norm(u[:2], axis=0) - 0.25 * u[2]) < 5e-2  # the thrust cone, up to the ADMM tolerance
+    assert np.all(sol["controls"] >= rk.u_min[:, None, None] - 1e-12) and np.all(sol["controls"] <= rk.u_max[:, None, None] + 1e-12)
+    sample = sorted(rng.choice(B, size=6, replace=False))
+    for b in sample:
+        o = oracle(rk, settings)
+        o.set_x0(x0s[:, b])
+        o.solve()
+        assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], b
+        assert rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
+    s.reset_workspace()
+    s.set_x0_batch(np.ascontiguousarray(x0s[:, ::-1]))
+    s.solve()
+    sol_r, st_r = s.get_solution_batch(), s.get_stats_batch()
+    np.testing.assert_array_equal(sol_r["controls"][:, :, ::-1], sol["controls"])
+    np.testing.assert_array_equal(sol_r["states"][:, :, ::-1], sol["states"])
+    np.testing.assert_array_equal(st_r["iter"][::-1], st["iter"])
+    s.reset()
