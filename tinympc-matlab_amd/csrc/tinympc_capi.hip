@@ -416,7 +416,9 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
     }
     std::memcpy(s->h_x0, x0s, sizeof(double) * nx0);
     if ((rc = resolve_plan(s))) return rc;
-    if (s->batch <= kZeroCopyTickMax && s->st.max_iter > 0 && current_plan(s).host_exchange) {
+    int zc_max = current_plan(s).layout == 'D' ? kZeroCopyTickMaxD : kZeroCopyTickMax;
+    if (const char *e = getenv("TINYMPC_ZERO_COPY_MAX")) zc_max = atoi(e);  // (experiments)
+    if (s->batch <= zc_max && s->st.max_iter > 0 && current_plan(s).host_exchange) {
         // Small batches: no copy engine at all. The kernel reads x0 from the pinned host buffer (and mirrors it into
         // the device copy the other verbs use) and writes the first controls into the pinned host buffer; both
         // are device-visible host allocations, and the stream synchronisation makes the writes visible here.

@@ -39,6 +39,7 @@ constexpr double kBoundInf = 1e17;  // TinyMPC.m:261-264
 // mailbox, references re-read by a resident kernel) is allocated hipHostMallocCoherent: with the default flags the
 // GPU may keep host lines in its L2 until the kernel ends, and a resident kernel then polls a stale copy forever.
 constexpr int kZeroCopyTickMax = 256;   // mpc_step: up to this many instances exchange x0 / u0 through pinned host memory
+constexpr int kZeroCopyTickMaxD = 1 << 30;  // ... on layout D: any batch (measured: tools/tick_latency.py)
 constexpr int kLayoutEBatchMin = 260;   // families at horizons layout D cannot hold: from here on layout E (4 instances per CU, the whole
                                         // state on chip) passes the latency kernel (1 instance per CU); measured, profiles/r03_rocket_sweep.txt
 constexpr int kLayoutCBatchMax = 768;  // above this the batch-oriented layouts win (profiles/r02_layout_sweep.txt: layout D with four

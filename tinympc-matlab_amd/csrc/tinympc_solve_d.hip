@@ -346,6 +346,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
     double rhom = is_x ? nrho : 0.0;
     const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+    if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * NX + r] = x0v;  // zero-copy tick: x0 came from pinned host memory
     const int dIdx = j * NU + (is_u ? r - NX : 0);
     const double *const sDr = sD + dIdx;
     double *const sDw = sD + dIdx;
@@ -421,6 +422,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                     wG[s * 64] = G[s];
                     wV[s * 64] = vn;
                     wS[s * sst] = vn;
+                    if constexpr (s == 0) {  // zero-copy tick: the first controls also go straight into pinned host memory
+                        if (p.u0_host && !x_o) p.u0_host[inst_o * NU + (r_o - NX)] = vn;
+                    }
                 });
                 if constexpr (FAM) {
                     double *const wGC = p.GC + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;
