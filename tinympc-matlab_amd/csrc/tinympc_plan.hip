@@ -150,13 +150,12 @@ LaunchPlan current_plan(const tinympc_solver *s) {
         case KernelId::D_JIT:
             pl.layout = 'D';
             pl.jit = true;
-            pl.host_exchange = s->W == 16;  // (the 16-lane form reads x0 from / writes the first controls to pinned host memory: batched ticks)
             pl.workgroups = solve_jit_workgroups(s->W, s->nx, s->nu, s->N, ct, s->groups, fam, adaptive);
             pl.lds_bytes = solve_jit_lds_bytes(s->W, s->nx, s->nu, s->N, ct, fam, adaptive);
             break;
         case KernelId::D_COMPILED:
             pl.layout = 'D';
-            pl.host_exchange = s->W == 16;
+            pl.host_exchange = s->W == 16;  // (the compiled-in 16-lane shapes have a variant that reads x0 from / writes the first controls to pinned host memory)
             pl.workgroups = s->W == 64 ? solve_dx_workgroups(s->nu, s->N, s->groups) : s->W == 32 ? solve_dw_workgroups(s->nu, s->N, s->groups)
                                                                                                    : solve_d_workgroups(s->nu, s->N, ct, s->groups);
             pl.lds_bytes = s->W == 64 ? solve_dx_lds_bytes(s->nu, s->N) : s->W == 32 ? solve_dw_lds_bytes(s->nu, s->N) : solve_d_lds_bytes(s->nu, s->N, ct);

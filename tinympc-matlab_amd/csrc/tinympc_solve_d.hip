@@ -148,7 +148,10 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // variable, persistent in p.rho_inst), the lane's operator rows are (base row) + (rho - rho0) * (derivative row) rebuilt from
 // LDS at every sweep, and every fifth iteration the four norms of the reference's dense KKT system ride on the forward sweep
 // (one extra mat-vec per step). Run-time specialised only (-DTINY_JIT_ADAPT=1), not together with the families.
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true>
+// HOSTX: the batched zero-copy tick (x0 read from pinned host memory and mirrored, first controls written to pinned host memory). A variant
+// of its own: as run-time branches in the rare paths of the one kernel the two stores cost the sweeps 3.6 % (1.72 -> 1.78 ms: the
+// pointers' scalar registers, live across the unrolled iteration loop).
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true, bool HOSTX = false>
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     static_assert(!(FAM && ADAPT), "adaptive rho and the constraint families exclude each other (as in the C ABI)");
     // this wavefront's slot on its SIMD (HW_REG_HW_ID bits 3:0): the two wavefronts of a SIMD sit in different slots
@@ -346,7 +349,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
     double rhom = is_x ? nrho : 0.0;
     const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
-    if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * NX + r] = x0v;  // zero-copy tick: x0 came from pinned host memory
+    if constexpr (HOSTX) {  // zero-copy tick: x0 came from pinned host memory
+        if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * NX + r] = x0v;
+    }
     const int dIdx = j * NU + (is_u ? r - NX : 0);
     const double *const sDr = sD + dIdx;
     double *const sDw = sD + dIdx;
@@ -422,7 +427,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                     wG[s * 64] = G[s];
                     wV[s * 64] = vn;
                     wS[s * sst] = vn;
-                    if constexpr (s == 0) {  // zero-copy tick: the first controls also go straight into pinned host memory
+                    if constexpr (HOSTX && s == 0) {  // zero-copy tick: the first controls also go straight into pinned host memory
                         if (p.u0_host && !x_o) p.u0_host[inst_o * NU + (r_o - NX)] = vn;
                     }
                 });
@@ -749,10 +754,10 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 }
 
 #ifndef TINY_JIT
-template <int NX, int NU, int N, bool CT, int WPG, int VL>
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool HOSTX = false>
 __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL>(p, smem);
+    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, HOSTX>(p, smem);
 }
 #endif
 
@@ -804,12 +809,19 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
         return hipErrorInvalidValue;
     } else {
         constexpr size_t lds = d_lds_bytes(NU, N, CT, WPG, VL);
-        static size_t lds_set[16] = {0};
-        auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL>;
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
-        if (e != hipSuccess) return e;
+        static size_t lds_set[16] = {0}, lds_set_x[16] = {0};
         const int wgs = (p.groups + WPG - 1) / WPG;
-        hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * WPG), lds, stream, p);
+        if (p.x0_mirror || p.u0_host) {  // (the batched zero-copy tick)
+            auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL, true>;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_x);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * WPG), lds, stream, p);
+        } else {
+            auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL>;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(fn, dim3(wgs), dim3(64 * WPG), lds, stream, p);
+        }
         return hipGetLastError();
     }
 }
