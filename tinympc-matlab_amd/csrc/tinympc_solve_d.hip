@@ -32,7 +32,8 @@
 // Reference semantics that need care are those of layout B (tinympc_solve_b.hip): per-instance termination,
 // `iter % check_termination` with iter already incremented, the solution is vnew/znew, and a converged solve leaves
 // the PREVIOUS iterate in v/z (admm.cpp:181-197) -- the stale copy goes to p.V2, written only in sweeps that can
-// still end converged (decided every D_GROUP steps, exact because the residual maxima only grow).
+// still end converged (decided on knot 0, after D_FIRST steps and then every D_GROUP steps; exact because the
+// residual maxima only grow).
 #include <type_traits>
 
 #include "tinympc_device.h"
@@ -69,7 +70,17 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 // ---- LDS plan per workgroup, in doubles: operators [2][16 k][16 r] | tables (!CT) | per wave: V[VL][64], D[(N-1)*4*nu]
 constexpr int D_OPS_DOUBLES = 2 * 16 * 16;
-constexpr int D_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
+#ifdef TINY_D_GROUP
+constexpr int D_GROUP = TINY_D_GROUP;  // (experiments)
+constexpr int D_FIRST = TINY_D_FIRST;
+#else
+// Forward steps between two "can this sweep still converge" tests: one test on knot 0 alone, the next after D_FIRST
+// steps (a sweep that cannot converge has then copied D_FIRST slots of stale iterate at most), then every D_GROUP steps.
+// Each test is a scheduling boundary of the unrolled sweep; 4 | 23 measured best of the splits tried on the headline
+// (profiles/r03_dgroup_ab.txt), forced iterations and converging batch alike.
+constexpr int D_GROUP = 23;
+constexpr int D_FIRST = 4;
+#endif
 #ifdef TINY_JIT_VREG
 constexpr int D_VREG_MAX = TINY_JIT_VREG;  // chosen by the host from its register estimate
 #else
@@ -469,12 +480,18 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         // ---------------- knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
         {
             const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
-            if (may && is_x) gV1u[(unsigned)lane] = V0;
             const double s = x0v + G0;
             const double snew = fmin(hi0, fmax(lo0, s));
             G0 = s - snew;
             pri = is_x ? fabs(x0v - snew) : 0.0;
             dua = is_x ? fabs(V0 - snew) : 0.0;
+            // First "can this sweep still converge" test, on knot 0's residuals alone (exact like the later ones: the
+            // maxima only grow). With tolerances nothing can meet -- forced iteration counts -- the sweep writes no stale copy.
+            if (may && !adapt) {
+                const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+            }
+            if (may && is_x) gV1u[(unsigned)lane] = V0;
             V0 = snew;
         }
         if constexpr (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
@@ -548,9 +565,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 hicur = hin;
             }
         };
-        constexpr int NG = (NS + D_GROUP - 1) / D_GROUP;
+        constexpr int DF = D_FIRST < NS ? D_FIRST : NS;
+        constexpr int NG = 1 + (NS - DF + D_GROUP - 1) / D_GROUP;
         static_for<0, NG>([&](auto Gi) {
-            constexpr int s0 = Gi.value * D_GROUP, s1 = (s0 + D_GROUP < NS) ? s0 + D_GROUP : NS;
+            constexpr int s0 = Gi.value == 0 ? 0 : DF + (Gi.value - 1) * D_GROUP;
+            constexpr int s1 = Gi.value == 0 ? DF : ((s0 + D_GROUP < NS) ? s0 + D_GROUP : NS);
             if (may) {
                 // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
                 // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does

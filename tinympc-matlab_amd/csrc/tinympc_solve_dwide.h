@@ -35,7 +35,13 @@ __device__ __forceinline__ void static_for_w(F &&f) {
     }
 }
 
+#ifdef TINY_WIDE_GROUP
+constexpr int WIDE_GROUP = TINY_WIDE_GROUP;  // (experiments)
+constexpr int WIDE_FIRST = TINY_WIDE_FIRST;
+#else
 constexpr int WIDE_GROUP = 8;        // forward steps between two "can this sweep still converge" tests
+constexpr int WIDE_FIRST = 8;        // ... and before the first one inside the sweep (after the one on knot 0)
+#endif
 constexpr int WIDE_LDS_PER_CU = 160 * 1024;
 // ---- LDS plan per workgroup, in doubles: operators [2][W k][W r] | tables (!ct) | per wave: V[VL][64], D[(N-1) * (64 / W) * nu]
 __host__ __device__ constexpr int wide_ops_doubles(int W) { return 2 * W * W; }
@@ -254,12 +260,16 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
         // ---------------- knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
         {
             const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
-            if (may && is_x) gV1u[(unsigned)lane] = V0;
             const double s = x0v + G0;
             const double snew = fmin(hi0, fmax(lo0, s));
             G0 = s - snew;
             pri = is_x ? fabs(x0v - snew) : 0.0;
             dua = is_x ? fabs(V0 - snew) : 0.0;
+            if (may) {  // first test on knot 0 alone (tinympc_solve_d.hip): forced iteration counts write no stale copy
+                const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+                may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_w<W>(__ballot(bad), __ballot(active))) != 0;
+            }
+            if (may && is_x) gV1u[(unsigned)lane] = V0;
             V0 = snew;
         }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
@@ -303,9 +313,11 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
                 hicur = hin;
             }
         };
-        constexpr int NG = (NS + WIDE_GROUP - 1) / WIDE_GROUP;
+        constexpr int WF = WIDE_FIRST < NS ? WIDE_FIRST : NS;
+        constexpr int NG = 1 + (NS - WF + WIDE_GROUP - 1) / WIDE_GROUP;
         static_for_w<0, NG>([&](auto Gi) {
-            constexpr int s0 = Gi.value * WIDE_GROUP, s1 = (s0 + WIDE_GROUP < NS) ? s0 + WIDE_GROUP : NS;
+            constexpr int s0 = Gi.value == 0 ? 0 : WF + (Gi.value - 1) * WIDE_GROUP;
+            constexpr int s1 = Gi.value == 0 ? WF : ((s0 + WIDE_GROUP < NS) ? s0 + WIDE_GROUP : NS);
             if (may) {
                 // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
                 // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does
