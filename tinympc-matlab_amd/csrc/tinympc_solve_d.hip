@@ -138,18 +138,41 @@ __device__ __forceinline__ void lds_write_masked(unsigned addr, double v, unsign
                  : "memory", "scc");
 }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ... and the point where the compiler retires ITS OWN reads of the sweep's operator rows: left alone it waits for them in
+// front of the first block that uses them, i.e. right behind the asynchronous reads issued for the second block -- a full
+// LDS latency in every sweep.
+__device__ __forceinline__ void lds_wait_ops(double (&m)[16]) {
+#ifdef TINY_D_NO_OPS_WAIT
+    lds_wait();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]),
+                   "+v"(m[10]), "+v"(m[11]), "+v"(m[12]), "+v"(m[13]), "+v"(m[14]), "+v"(m[15])
+                 :
+                 : "memory");
+#endif
+}
 
 // `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the lanes that
 // are still iterating. True if some live instance (16-lane row) has no bad lane.
+// (no short-circuit evaluation: four scalar compares instead of a chain of branches in every sweep)
 __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsigned long long live) {
-    bool any = false;
+    int any = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const unsigned long long b = (bad >> (j * 16)) & 0xffffull, l = (live >> (j * 16)) & 0xffffull;
-        any = any || (l != 0ull && b == 0ull);
+        const unsigned b = (unsigned)(bad >> (j * 16)) & 0xffffu, l = (unsigned)(live >> (j * 16)) & 0xffffu;
+        any |= (int)(l != 0u) & (int)(b == 0u);
     }
-    return any;
+    return any != 0;
 }
+// Branches that are almost never taken (write-back, stale copies): the compiler moves their bodies out of the sweep's
+// straight line. A TAKEN branch costs a wavefront ~110 cycles of instruction fetch (tools/microbench_fp64_step.hip, loops
+// against straight-line code), so the common path should be the fall-through.
+#ifdef TINY_D_NO_RARE
+#define TINY_RARE(c) (c)
+#else
+#define TINY_RARE(c) __builtin_expect(!!(c), 0)
+#endif
 
 // FAM: the second-order-cone and linear-inequality slack families of k_admm_solve_fam (PARITY UNPINNED, see there) ride on
 // the forward step exactly as in the latency kernel (tinympc_solve_c.hip): every knot carries two more duals gc|yc, gl|yl
@@ -412,7 +435,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
         // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
         const bool wb = pending || (final_round && active);
-        if (__ballot(wb) != 0ull) {
+        if (TINY_RARE(__ballot(wb) != 0ull)) {
             // Rare path (once per instance and solve), kept small in registers rather than fast: addresses are rebuilt
             // here from the kernel arguments (the opaque copy of `lane` keeps the compiler from hoisting them out of
             // the iteration loop, where they would occupy registers the unrolled sweeps need).
@@ -491,7 +514,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
                 may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
             }
-            if (may && is_x) gV1u[(unsigned)lane] = V0;
+            if (TINY_RARE(may) && is_x) gV1u[(unsigned)lane] = V0;
             V0 = snew;
         }
         if constexpr (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
@@ -514,7 +537,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             locur = lds_read_async<W * 8>(aT);
             hicur = lds_read_async<(TOFF + W) * 8>(aT);
         }
-        lds_wait();
+        lds_wait_ops(m);
         auto fstep = [&](auto S) {
             constexpr int q = decltype(S)::value;
             double dn = 0.0, vn = 0.0, lon = lo_c, hin = hi_c;
@@ -570,7 +593,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         static_for<0, NG>([&](auto Gi) {
             constexpr int s0 = Gi.value == 0 ? 0 : DF + (Gi.value - 1) * D_GROUP;
             constexpr int s1 = Gi.value == 0 ? DF : ((s0 + D_GROUP < NS) ? s0 + D_GROUP : NS);
-            if (may) {
+            if (TINY_RARE(may)) {
                 // Stale copy of the group's slots (still holding the previous iterate) before the blocks overwrite them.
                 // Rare path: the addresses are rebuilt from an opaque copy of the lane offset so that the compiler does
                 // not keep one pointer per slot alive across the iteration loop.
@@ -582,7 +605,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                         may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
                     }
                 }
-                if (may) {
+                if (TINY_RARE(may)) {
                     unsigned vo = voff;
                     double *base = gV1u;
                     asm volatile("" : "+v"(vo), "+s"(base));
@@ -693,7 +716,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 else return lds_read_async<decltype(S)::value * 512>(aV);
             };
             double v2cur = vreq(std::integral_constant<int, (NS >= 3 ? NS - 3 : 0)>{});
-            lds_wait();
+            lds_wait_ops(m);
             static_for<0, NS - 1>([&](auto I) {
                 constexpr int s = NS - 1 - I.value;           // NS-1 .. 1
                 constexpr int s2 = s >= 2 ? s - 2 : 0;        // slot feeding the tail (s = 1: any finite t will do)
