@@ -63,7 +63,13 @@ struct DStep;  // tinympc_solve_d_chain.h
 
 namespace tinympc {
 
-constexpr int E_GROUP = 8;  // forward steps between two "can this sweep still converge" tests
+#ifdef TINY_E_FIRST
+constexpr int E_FIRST = TINY_E_FIRST;  // (experiments)
+#else
+constexpr int E_FIRST = 1;  // forward steps before the first "can this sweep still converge" test (a wavefront's chunk is
+                            // a handful of slots: with one group all of them went to the stale copy in every checked sweep)
+#endif
+constexpr int E_GROUP = 8;  // ... and between two later ones
 
 template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS>
 __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double *smem) {
@@ -376,9 +382,11 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         hicur = hin;
                     }
                 };
-                constexpr int NG = (S + E_GROUP - 1) / E_GROUP;
+                constexpr int EF = E_FIRST < S ? E_FIRST : S;
+                constexpr int NG = 1 + (S - EF + E_GROUP - 1) / E_GROUP;
                 e_static_for<0, NG>([&](auto Gi) {
-                    constexpr int g0 = Gi.value * E_GROUP, g1 = (g0 + E_GROUP < S) ? g0 + E_GROUP : S;
+                    constexpr int g0 = Gi.value == 0 ? 0 : EF + (Gi.value - 1) * E_GROUP;
+                    constexpr int g1 = Gi.value == 0 ? EF : ((g0 + E_GROUP < S) ? g0 + E_GROUP : S);
                     if (may) {
                         // stale copy of the group's slots (still the previous iterate) before the blocks overwrite them -- only
                         // while some instance of this wavefront can still converge in this sweep (exact: the maxima only grow)
