@@ -201,7 +201,7 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
         # k_admm_solve_m<13..15, false>: the per-knot-table variants at sixteen wavefronts per workgroup (128 registers): 14 registers
         **{("tinympc_solve_m.hip", "_ZN7tinympc14k_admm_solve_mILi%dELb0EEEvNS_11SolveParamsE" % r): 64 for r in (13, 14, 15)},
     }
-    seen = 0
+    seen = refill = 0
     for source in ge.HIP_SOURCES:
         built = ge.device_asm_path(source)
         if not os.path.exists(built):
@@ -210,8 +210,19 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
             seen += 1
             size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+            if source == "tinympc_solve_d.hip" and m.group(1).endswith("ELb0ELb1EEEvNS_11SolveParamsE"):
+                # k_admm_solve_d<..., HOSTX = false, REFILL = true>: the slot-refill variants spill in their RARE paths (write-back
+                # and refill of a row: once per instance); their sweeps -- the blocks made of DPP FMAs -- must not touch scratch
+                refill += 1
+                body = re.search(r"^%s:(.*?)^\.Lfunc_end" % re.escape(m.group(1)), text, re.S | re.M).group(1)
+                blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
+                sweeps = [b for b in blocks if b.count("v_fmac_f64_dpp") >= 15]
+                assert len(sweeps) >= 2, m.group(1)
+                for b in sweeps:
+                    assert "scratch_" not in b, f"{m.group(1)}: a sweep block of the slot-refill variant uses scratch"
+                continue
             assert size <= allowed.get((source, m.group(1)), 0), f"{source}: {m.group(1)} uses {size} bytes of scratch per lane"
-    assert seen > 50
+    assert seen > 50 and refill >= 3
 
 
 def _hiprtc_compile(source_text: str, options: list[str]) -> tuple[int, str]:
@@ -245,6 +256,7 @@ def _hiprtc_compile(source_text: str, options: list[str]) -> tuple[int, str]:
 
 @pytest.mark.parametrize("source,defs", [
     ("tinympc_solve_d.hip", "-DTINY_JIT_NX=6 -DTINY_JIT_NU=3 -DTINY_JIT_N=30 -DTINY_JIT_VREG=29 -DTINY_JIT_WPS=2 -DTINY_JIT_WPG=4 -DTINY_JIT_CT=1 -DTINY_JIT_FAM=0 -DTINY_JIT_ADAPT=0"),
+    ("tinympc_solve_d.hip", "-DTINY_JIT_NX=12 -DTINY_JIT_NU=4 -DTINY_JIT_N=20 -DTINY_JIT_VREG=19 -DTINY_JIT_WPS=2 -DTINY_JIT_WPG=4 -DTINY_JIT_CT=1 -DTINY_JIT_FAM=0 -DTINY_JIT_ADAPT=0 -DTINY_JIT_REFILL=1"),
     ("tinympc_solve_dw.hip", "-DTINY_JIT_NX=17 -DTINY_JIT_NU=2 -DTINY_JIT_N=10 -DTINY_JIT_VREG=9 -DTINY_JIT_WPS=2 -DTINY_JIT_WPG=4 -DTINY_JIT_CT=1"),
     ("tinympc_solve_dx.hip", "-DTINY_JIT_NX=40 -DTINY_JIT_NU=12 -DTINY_JIT_N=8 -DTINY_JIT_VREG=7 -DTINY_JIT_WPS=2 -DTINY_JIT_WPG=4 -DTINY_JIT_CT=1"),
 ])

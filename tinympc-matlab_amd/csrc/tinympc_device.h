@@ -165,6 +165,11 @@ struct SolveParams {
     // handle) and has not been materialised in HBM -- the kernel starts from zero registers / LDS instead of loading 14 KB of zeros
     // per instance. Only set for kernels that honour it (layout D and its wide forms); the host zeroes the arrays for every other kernel.
     int cold;
+    // Slot refill (layout D, 16 lanes per instance, batches larger than the chip holds at once, tolerances that can be met): the
+    // launch is as many wavefronts as are resident together; a 16-lane row whose instance has finished writes it back and takes the
+    // next instance index from this counter (instance = 4 x launched wavefronts + old value; zeroed by the host before the launch),
+    // so that a wavefront does not idle three rows while its slowest instance iterates. NULL: one instance per row and launch.
+    int *refill_next;
 };
 
 struct ChunkTableParams {
@@ -287,6 +292,8 @@ bool solve_d_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream);
 int solve_d_workgroups(int nu, int N, bool const_tables, int groups);
 size_t solve_d_lds_bytes(int nu, int N, bool const_tables);  // per workgroup
+int solve_d_resident_workgroups(int wpg);  // workgroups of `wpg` wavefronts the device holds at two wavefronts per SIMD (slot refill)
+int solve_d_wavefronts_per_workgroup(int nu, int N, bool const_tables);
 // ... and its 32-lanes-per-instance form for wide systems (16 < nx+nu <= 32), tinympc_solve_dw.hip
 bool solve_dw_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_dw(const SolveParams &p, hipStream_t stream);
@@ -335,6 +342,8 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).
 bool solve_jit_supported(int W, int nx, int nu, int N, bool const_tables, bool families = false, bool adaptive = false);
 hipError_t launch_solve_jit(const SolveParams &p, int W, hipStream_t stream);
+bool solve_jit_refill_supported(int W, int nx, int nu, int N, bool const_tables);   // (compiles the slot-refill variant on first use)
+int solve_jit_resident_wavefronts(int W, int nx, int nu, int N, bool const_tables);  // wavefronts of the shape's plan the device holds at once
 int solve_jit_workgroups(int W, int nx, int nu, int N, bool const_tables, int groups, bool families = false, bool adaptive = false);
 size_t solve_jit_lds_bytes(int W, int nx, int nu, int N, bool const_tables, bool families = false, bool adaptive = false);  // per workgroup, from the plan  // 8 wavefronts per workgroup, 4 on the long-horizon plan
 #endif  // !__HIPCC_RTC__

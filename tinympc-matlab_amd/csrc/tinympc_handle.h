@@ -73,6 +73,7 @@ struct tinympc_solver {
     // per-instance state
     double *dx0 = nullptr, *dG = nullptr, *dV = nullptr, *dD = nullptr, *dsolx = nullptr, *dsolu = nullptr;
     int *distats = nullptr;
+    int *drefill = nullptr;  // slot refill (layout D): the next-instance counter of a launch (SolveParams::refill_next)
     double *ddstats = nullptr;
     size_t lds_bytes = 0;
     bool tables_in_lds = false;

@@ -3,6 +3,7 @@
 // function, current_plan(), from the handle's capabilities (what setup found possible for the shape) and the variants decided
 // for the CURRENT configuration (resolve_plan(): may specialise a kernel, seconds the first time). launch(), the launch geometry
 // of tinympc_get_launch_info, tinympc_get_layout and tinympc_get_jit_info all read that one LaunchPlan.
+#include <cstring>
 #include "tinympc_handle.h"
 
 using namespace tinympc;
@@ -212,6 +213,30 @@ int resolve_plan(tinympc_solver *s) {
     return decide_layout_f(s);
 }
 
+// Slot refill (tinympc_solve_d.hip, REFILL): the compiled-in 16-lane shapes (box path), when the batch is more than the device
+// holds at once and the tolerances can be met -- i.e. when instances finish at different times and there is something to refill a
+// row with. Forced iteration counts keep the plain kernel (every instance runs max_iter: nothing to balance).
+// TINYMPC_REFILL=0 switches it off, =1 takes it for any batch beyond one resident set whatever the tolerances.
+static bool refill_applies(const tinympc_solver *s, const LaunchPlan &pl) {
+    const bool jit = pl.kernel == KernelId::D_JIT;
+    if ((pl.kernel != KernelId::D_COMPILED && !jit) || s->W != 16 || pl.adaptive || pl.families || s->zero_copy_tick || s->st.max_iter <= 0 ||
+        s->st.check_termination <= 0)
+        return false;
+    const char *env = getenv("TINYMPC_REFILL");
+    const int mode = env ? atoi(env) : -1;
+    if (mode == 0) return false;
+    const bool ct = s->tables_const();
+    long resident;  // wavefronts = groups of four instances
+    if (jit) resident = solve_jit_resident_wavefronts(s->W, s->nx, s->nu, s->N, ct);
+    else {
+        const int wpg = solve_d_wavefronts_per_workgroup(s->nu, s->N, ct);
+        resident = (long)solve_d_resident_workgroups(wpg) * wpg;
+    }
+    const bool reachable = s->st.abs_pri_tol > 0.0 && s->st.abs_dua_tol > 0.0;
+    if ((long)s->groups <= resident || !(reachable || mode == 1)) return false;
+    return !jit || solve_jit_refill_supported(s->W, s->nx, s->nu, s->N, ct);  // (run-time specialised shapes: built on first use)
+}
+
 int launch(tinympc_solver *s, bool timed) {
     int rc;
     s->flag_pending = false;
@@ -287,6 +312,11 @@ int launch(tinympc_solver *s, bool timed) {
     s->cold_state = false;  // (the launch below writes the state back)
     if (s->st.max_iter > 0) s->sol_zero_pending = false;  // (every instance writes its whole solution)
     else if ((rc = materialize_zero_solution(s))) return rc;
+    if (refill_applies(s, pl) && !p.x0_mirror && !p.u0_host && !p.host_sol) {  // slot refill (see refill_applies)
+        if (!s->drefill && (rc = dalloc(s, &s->drefill, 1))) return rc;
+        HIP_TRY(hipMemsetAsync(s->drefill, 0, sizeof(int), s->stream));
+        p.refill_next = s->drefill;
+    }
     if (timed) HIP_TRY(hipEventRecord(s->ev0, s->stream));
     switch (pl.kernel) {
         case KernelId::M:
@@ -377,7 +407,8 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
     else if (pl.kernel == KernelId::D_JIT || (s->d_jit_asked && !s->layout_d && !s->layout_m)) {
         if ((rc = bind_device(s))) return rc;
         solve_jit_describe(s->W, s->nx, s->nu, s->N, ct, pl.families && !pl.adaptive, pl.adaptive && !pl.families, buf, (size_t)len);
-    } else snprintf(buf, (size_t)len, "compiled-in layout=%c", pl.layout);
+        if (pl.kernel == KernelId::D_JIT && refill_applies(s, pl)) strncat(buf, " slot-refill", (size_t)len - strlen(buf) - 1);
+    } else snprintf(buf, (size_t)len, "compiled-in layout=%c%s", pl.layout, refill_applies(s, pl) ? " slot-refill" : "");
     return TINYMPC_OK;
 }
 

@@ -185,9 +185,16 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // HOSTX: the batched zero-copy tick (x0 read from pinned host memory and mirrored, first controls written to pinned host memory). A variant
 // of its own: as run-time branches in the rare paths of the one kernel the two stores cost the sweeps 3.6 % (1.72 -> 1.78 ms: the
 // pointers' scalar registers, live across the unrolled iteration loop).
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true, bool HOSTX = false>
+// REFILL: slot refill (SolveParams::refill_next). The launch is one resident set of wavefronts; every 16-lane row counts its OWN
+// iterations, and a row whose instance has finished (converged, or max_iter) is written back -- state, solution, statistics -- and
+// loaded with the next instance of the batch, cold or warm, while the other three rows of the wavefront keep iterating. The
+// arithmetic of an instance is that of the plain kernel (bit-identical results: tests/test_hip_parity.py); what changes is that
+// a wavefront's time is the sum of what its rows worked, not four times its slowest instance.
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true, bool HOSTX = false,
+          bool REFILL = false>
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     static_assert(!(FAM && ADAPT), "adaptive rho and the constraint families exclude each other (as in the C ABI)");
+    static_assert(!REFILL || (!FAM && !ADAPT && !HOSTX), "slot refill: box-constrained path only");
     // this wavefront's slot on its SIMD (HW_REG_HW_ID bits 3:0): the two wavefronts of a SIMD sit in different slots
     const int simd_slot = TWO_PER_SIMD ? simd_slot_id() : 0;
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
@@ -244,7 +251,12 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
     double *const gD = p.D + g0 * (size_t)(NS * DS);
     double *const gV0 = p.V + (g0 * v_rows(N) + V_PAD) * 64 + lane;    // canonical v|z, knot 0
-    double *const gV1u = p.V2 + (g0 * v_rows(N) + V_PAD) * 64;         // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset)
+    // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset; REFILL: the rows of a wavefront belong to different
+    // groups of four, so the base is the array's and the offset carries the group -- below 2^32 doubles for any batch that fits HBM)
+    double *const gV1u = p.V2 + ((REFILL ? 0 : g0) * v_rows(N) + V_PAD) * 64;
+    int cur = (int)inst;  // REFILL: the instance this row works on
+    auto row_offset = [&](int i) -> unsigned { return (unsigned)(i >> 2) * (unsigned)(v_rows(N) * 64) + (unsigned)((i & 3) * 16 + r); };
+    // (REFILL: rebuilt from `cur` where it is needed -- rare paths -- instead of living in a register across the sweeps)
     const unsigned voff = (unsigned)(lane + koff * 64);
     double *const sVl = sV + lane;
     const bool cold = p.cold != 0;  // (uniform) the state is zero by contract and was never written to HBM: nothing to load
@@ -382,7 +394,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double nrho = -rho;
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
     double rhom = is_x ? nrho : 0.0;
-    const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+    double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
     if constexpr (HOSTX) {  // zero-copy tick: x0 came from pinned host memory
         if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * NX + r] = x0v;
     }
@@ -430,11 +442,12 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         // (readfirstlane: keeps the loop counter and everything derived from it in SGPRs, so that the branches below
         // are scalar branches and not EXEC-masked regions)
         const int it0 = __builtin_amdgcn_readfirstlane(it);
-        const bool final_round = it0 >= max_iter;
+        const bool final_round = REFILL ? false : it0 >= max_iter;  // (REFILL: every row has its own count, `fin` below)
         if constexpr (TWO_PER_SIMD) fair_share_priority<NS>(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
         // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
         // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
-        const bool wb = pending || (final_round && active);
+        const bool fin = REFILL ? it_done >= max_iter : final_round;
+        const bool wb = pending || (fin && active);
         if (TINY_RARE(__ballot(wb) != 0ull)) {
             // Rare path (once per instance and solve), kept small in registers rather than fast: addresses are rebuilt
             // here from the kernel arguments (the opaque copy of `lane` keeps the compiler from hoisting them out of
@@ -443,11 +456,16 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             asm volatile("" : "+v"(lane_o));
             const int r_o = lane_o & 15, j_o = lane_o >> 4;
             const bool x_o = r_o < NX;
+            // (REFILL: this row's instance; its place in the group-of-four layout of the state arrays)
+            int cur_o = cur;
+            if constexpr (REFILL) asm volatile("" : "+v"(cur_o));
+            const size_t grp_w = REFILL ? (size_t)(cur_o >> 2) : (size_t)grp;
+            const int lane_w = REFILL ? (cur_o & 3) * 16 + r_o : lane_o;
             if (wb && r_o < NXU) {
                 const int ko = x_o ? 1 : 0;
-                const size_t inst_o = (size_t)grp * IPW + j_o;
-                double *const wG = p.G + (size_t)grp * (N + 1) * 64 + lane_o + ko * 64;                // slot 0
-                double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;   // slot 0
+                const size_t inst_o = REFILL ? (size_t)cur_o : (size_t)grp * IPW + j_o;
+                double *const wG = p.G + grp_w * (N + 1) * 64 + lane_w + ko * 64;                // slot 0
+                double *const wV = p.V + (grp_w * v_rows(N) + V_PAD) * 64 + lane_w + ko * 64;   // slot 0
                 double *const wS = x_o ? p.sol_x + (inst_o * N + 1) * NX + r_o : p.sol_u + inst_o * NS * NU + (r_o - NX);  // slot 0
                 const int sst = x_o ? NX : NU;
                 if (x_o) {  // knot 0
@@ -478,15 +496,84 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                     }
                 }
                 if (!x_o) {
-                    double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
+                    double *const wD = p.D + grp_w * (NS * DS) + (REFILL ? (cur_o & 3) : j_o) * NU + (r_o - NX);
                     for (int i = 0; i < NS; ++i) wD[i * DS] = sDw[i * DS];
+                }
+            }
+            if constexpr (REFILL) {
+                // ---- what the plain kernel does behind its loop, here for the rows that are being written back
+                // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the stale copy.
+                if (wb && status == 1 && r_o < NXU) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    const int rows = x_o ? N : NS;
+                    double *const cV = p.V + (grp_w * v_rows(N) + V_PAD) * 64 + lane_w;
+                    const double *const cV2 = p.V2 + (grp_w * v_rows(N) + V_PAD) * 64 + lane_w;
+                    for (int kn = 0; kn < rows; ++kn) cV[kn * 64] = cV2[kn * 64];
+                }
+                const double s_px = group_max<W>(is_x ? snap_pri : 0.0), s_pu = group_max<W>(is_u ? snap_pri : 0.0);
+                const double s_dx = group_max<W>(is_x ? snap_dua : 0.0) * rho, s_du = group_max<W>(is_u ? snap_dua : 0.0) * rho;
+                if (wb && r_o == 0) {
+                    p.istats[(size_t)cur_o * 2 + 0] = it_done;
+                    p.istats[(size_t)cur_o * 2 + 1] = status;
+                    if (res_valid) {
+                        p.dstats[(size_t)cur_o * 4 + 0] = s_px;
+                        p.dstats[(size_t)cur_o * 4 + 1] = s_dx;
+                        p.dstats[(size_t)cur_o * 4 + 2] = s_pu;
+                        p.dstats[(size_t)cur_o * 4 + 3] = s_du;
+                    }
+                }
+                // ---- the next instance of the batch for this row (or none: the row idles as a zombie until the wavefront is done)
+                int nxt = 0x7fffffff;
+                if (wb && r_o == 0) nxt = (int)(gridDim.x * WPG * IPW) + atomicAdd(p.refill_next, 1);
+                nxt = __shfl(nxt, lane_o & 48);
+                const bool take = wb && nxt < p.batch;
+                if (wb) {
+                    active = take;
+                    status = 11;
+                    res_valid = false;
+                    snap_pri = 0.0;
+                    snap_dua = 0.0;
+                    it_done = 0;
+                }
+                if (__ballot(take) != 0ull) {
+                    if (take) cur = nxt;
+                    const size_t grp_n = (size_t)(nxt >> 2);
+                    const int lane_n = (nxt & 3) * 16 + r_o;
+                    if (take && x_o) x0v = p.x0[(size_t)nxt * NX + r_o];
+                    if (cold) {
+                        static_for<0, NS>([&](auto S) { G[S.value] = take ? 0.0 : G[S.value]; });
+                        static_for<0, NVR>([&](auto S) { Vr[S.value] = take ? 0.0 : Vr[S.value]; });
+                        G0 = take ? 0.0 : G0;
+                        V0 = take ? 0.0 : V0;
+                        if (take) {
+                            static_for<0, VL>([&](auto S) { sVl[S.value * 64] = 0.0; });
+                            if (!x_o && r_o < NXU)
+                                for (int i = 0; i < NS; ++i) sDw[i * DS] = 0.0;
+                        }
+                    } else if (take) {
+                        const double *const nG = p.G + grp_n * (N + 1) * 64 + lane_n;
+                        const double *const nV = p.V + (grp_n * v_rows(N) + V_PAD) * 64 + lane_n;
+                        static_for<0, NS>([&](auto S) { G[S.value] = nG[(S.value + koff) * 64]; });
+                        static_for<0, NVR>([&](auto S) { Vr[S.value] = nV[(VL + S.value + koff) * 64]; });
+                        static_for<0, VL>([&](auto S) { sVl[S.value * 64] = nV[(S.value + koff) * 64]; });
+                        G0 = nG[0];
+                        V0 = nV[0];
+                        if (!x_o && r_o < NXU) {
+                            const double *const nD = p.D + grp_n * (NS * DS) + (nxt & 3) * NU + (r_o - NX);
+                            for (int i = 0; i < NS; ++i) sDw[i * DS] = nD[i * DS];
+                        }
+                    }
                 }
             }
             pending = false;
         }
         if (final_round || __ballot(active) == 0ull) break;
         const int it1 = it0 + 1;
-        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91 (iter already incremented, :143)
+        // admm.cpp:91 (iter already incremented, :143). REFILL: every row checks by its own count; `check` = some live row does.
+        bool chk = true;
+        if constexpr (REFILL) chk = active && (ct > 0) && (((it_done + 1) % ct) == 0);
+        const bool check = REFILL ? (__ballot(chk) != 0ull)
+                                  : (__builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0);
 
         double pri = 0.0, dua = 0.0;
         bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
@@ -512,9 +599,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             // maxima only grow). With tolerances nothing can meet -- forced iteration counts -- the sweep writes no stale copy.
             if (may && !adapt) {
                 const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
-                may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+                may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(REFILL ? chk : active))) != 0;
             }
-            if (TINY_RARE(may) && is_x) gV1u[(unsigned)lane] = V0;
+            if (TINY_RARE(may) && is_x) gV1u[REFILL ? row_offset(cur) : (unsigned)lane] = V0;
             V0 = snew;
         }
         if constexpr (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
@@ -602,11 +689,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 if constexpr (s0 > 0) {
                     if (!adapt) {
                         const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
-                        may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+                        may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(REFILL ? chk : active))) != 0;
                     }
                 }
                 if (TINY_RARE(may)) {
-                    unsigned vo = voff;
+                    unsigned vo = REFILL ? row_offset(cur) + (unsigned)(koff * 64) : voff;
                     double *base = gV1u;
                     asm volatile("" : "+v"(vo), "+s"(base));
                     static_for<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
@@ -614,7 +701,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             }
             static_for<s0, s1>([&](auto S) { fstep(S); });
         });
-        if (active) it_done = it1;  // admm.cpp:143
+        if constexpr (REFILL) {
+            if (active) it_done += 1;
+        } else {
+            if (active) it_done = it1;  // admm.cpp:143
+        }
 
         // ---------------- adaptive rho (admm.cpp:147-174), as in k_admm_solve_adapt
         const double nrho_lin = nrho, rhom_lin = rhom, pnref_lin = pnref;  // what update_linear_cost used this iteration
@@ -655,7 +746,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         if (check) {
             const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
             const bool conv = ((__ballot(below) >> (j * W)) & 0xffffull) == 0xffffull;
-            if (active) {
+            if (REFILL ? chk : active) {
                 snap_pri = pri;
                 snap_dua = dua;
                 if constexpr (ADAPT) snap_rho = rho;  // cache->rho AFTER the adaptation (admm.cpp:95-96)
@@ -753,6 +844,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
     // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
     // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
+    if constexpr (REFILL) return;  // (every row was finished inside the loop)
     if (inst_ok && status == 1 && r < NXU) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const int rows = is_x ? N : NS;
@@ -796,10 +888,10 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 }
 
 #ifndef TINY_JIT
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool HOSTX = false>
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool HOSTX = false, bool REFILL = false>
 __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, HOSTX>(p, smem);
+    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, HOSTX, REFILL>(p, smem);
 }
 #endif
 
@@ -830,7 +922,10 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ, ADJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
     __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ) / sizeof(double)];
-    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ, TINY_JIT_WPS == 2>(p, smem_jit);
+#ifndef TINY_JIT_REFILL
+#define TINY_JIT_REFILL 0
+#endif
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ, TINY_JIT_WPS == 2, false, TINY_JIT_REFILL != 0>(p, smem_jit);
 }
 namespace tinympc {
 #else
@@ -843,6 +938,18 @@ namespace tinympc {
 // per SIMD (10.1 us, 406 M); full batches gain a few percent from the finer tail (profiles/r02_layout_sweep.txt).
 __host__ __device__ constexpr int d_wpg(int nu, int N, bool ct) { return d_vl(nu, N, ct, 4) >= 0 ? 4 : 8; }
 
+// Slot refill launches one resident set: 2 wavefronts per SIMD x 4 SIMDs x the device's CUs, in workgroups of wpg.
+int solve_d_resident_workgroups(int wpg) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus * 8 / wpg;
+}
+int solve_d_wavefronts_per_workgroup(int nu, int N, bool const_tables) { return d_wpg(nu, N, const_tables); }
+
 template <int NX, int NU, int N, bool CT>
 static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
     constexpr int WPG = d_wpg(NU, N, CT);
@@ -851,9 +958,15 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
         return hipErrorInvalidValue;
     } else {
         constexpr size_t lds = d_lds_bytes(NU, N, CT, WPG, VL);
-        static size_t lds_set[16] = {0}, lds_set_x[16] = {0};
+        static size_t lds_set[16] = {0}, lds_set_x[16] = {0}, lds_set_r[16] = {0};
         const int wgs = (p.groups + WPG - 1) / WPG;
-        if (p.x0_mirror || p.u0_host) {  // (the batched zero-copy tick)
+        if (p.refill_next) {  // (slot refill: one resident set of wavefronts, tinympc_plan.hip)
+            auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL, false, true>;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_r);
+            if (e != hipSuccess) return e;
+            const int resident = solve_d_resident_workgroups(WPG);
+            hipLaunchKernelGGL(fn, dim3(wgs < resident ? wgs : resident), dim3(64 * WPG), lds, stream, p);
+        } else if (p.x0_mirror || p.u0_host) {  // (the batched zero-copy tick)
             auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL, true>;
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_x);
             if (e != hipSuccess) return e;
