@@ -477,8 +477,41 @@ def main() -> int:
                                          "value": 3 * nb * args.iters / dt, "unit": "ADMM iters/s", "ms_per_step": 1e3 * dt / 3,
                                          "kernel_ms_avg": sum(kms) / 3, "layout": big.launch_info()["layout"],
                                          "fp64_frac": nb * args.iters * flops_iter / (sum(kms) / 3 * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                         "prefix_matches_8192_run": (bool(np.array_equal(u_first, sol["controls"])) if parity else None)}
+                                         "prefix_matches_8192_run": (bool(np.array_equal(u_first, sol["controls"])) if parity else None),
+                                         "kernel": big.jit_info()}
             big.reset()
+            # The same 65,536 instances as a CONVERGING batch (tol 1e-3, x0 scaled 0.05 ... 3: 5 to 200 iterations per instance):
+            # the plain kernel holds a wavefront until its slowest instance is done; with slot refill (tinympc_solve_d.hip) a
+            # row takes the next instance as soon as its own has finished. Same results bit for bit (tests/test_slot_refill_gpu.py).
+            rng = np.random.default_rng(0)
+            x0c = np.ascontiguousarray((P.quadrotor_batch_x0(nb) * rng.uniform(0.05, 3.0, nb)[None, :]).T)
+            conv = {}
+            for mode in ("0", None):
+                if mode is None:
+                    os.environ.pop("TINYMPC_REFILL", None)
+                else:
+                    os.environ["TINYMPC_REFILL"] = mode
+                cb = pkg.TinyMPC()
+                cb.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=local_rank, rho=prob.rho,
+                         abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=args.iters, check_termination=1)
+                cb.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+                cb.set_x0_batch(torch.from_numpy(x0c).to(dev))
+                kms = []
+                for _ in range(4):
+                    cb.reset_workspace()
+                    kms.append(cb.solve_timed())
+                its = cb.get_stats_batch()["iter"].astype(np.float64)
+                conv["plain" if mode == "0" else "default"] = {"kernel_ms": float(np.median(kms[1:])), "kernel": cb.jit_info(), "instance_iterations": float(its.sum())}
+                cb.reset()
+            os.environ.pop("TINYMPC_REFILL", None)
+            forced_rate = nb * args.iters / (out["config5_single_gpu"]["kernel_ms_avg"] * 1e-3)  # instance-iterations/s with every row busy
+            d = conv["default"]
+            out["converging_batch"] = {"workload": "65,536 quadrotor N=%d instances, tol 1e-3, max_iter %d, x0 scaled 0.05 ... 3 (mean %.0f iterations per instance)"
+                                                   % (prob.N, args.iters, d["instance_iterations"] / nb),
+                                       "kernel_ms": d["kernel_ms"], "kernel": d["kernel"], "iters_per_s": d["instance_iterations"] / (d["kernel_ms"] * 1e-3),
+                                       "fraction_of_forced_iteration_rate": d["instance_iterations"] / (d["kernel_ms"] * 1e-3) / forced_rate,
+                                       "plain_kernel_ms": conv["plain"]["kernel_ms"],
+                                       "same_iteration_total": conv["plain"]["instance_iterations"] == d["instance_iterations"]}
         if not args.no_single:
             one = pkg.TinyMPC()
             one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho,

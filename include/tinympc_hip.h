@@ -292,7 +292,13 @@ int tinympc_get_layout(tinympc_solver *s);
 /* Where the kernel of the handle's CURRENT configuration comes from, as text: "compiled-in layout=X", or for the run-time
  * specialised kernels (layouts D and E) "compiled ..." / "disk-cache ..." with the code object's register count, scratch and LDS
  * bytes, or "refused(<reason>)" when the specialiser declined (plan overflow, spills, compile error, TINYMPC_JIT=0) and the
- * launch falls back to a generic kernel. Refusals are also printed once to stderr (TINYMPC_JIT_QUIET=1 silences them). */
+ * launch falls back to a generic kernel. Refusals are also printed once to stderr (TINYMPC_JIT_QUIET=1 silences them).
+ * " slot-refill" is appended when the launch uses layout D's slot-refill variant: a batch larger than the device holds at once
+ * (8,192 instances of 16 lanes on MI355X) runs as ONE resident set of wavefronts, and a 16-lane row whose instance has finished
+ * (converged, or max_iter) is written back and given the next instance of the batch while the rest of its wavefront keeps
+ * iterating -- a wavefront then costs the sum of what its rows worked instead of four times its slowest instance. Results are
+ * bit-identical to the plain kernel's. Taken whenever the tolerances can be met, and from two resident sets on with forced
+ * iteration counts; TINYMPC_REFILL=0 switches it off, =1 takes it for any batch beyond one resident set. */
 int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len);
 
 /* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:
