@@ -17,7 +17,7 @@ from tools.isa_lint import lint as _lint
 
 CSRC = os.path.join(ROOT, "tinympc-matlab_amd", "csrc")
 SOURCES = ["tinympc_solve.hip", "tinympc_solve_b.hip", "tinympc_solve_c.hip", "tinympc_solve_fam.hip", "tinympc_solve_adapt.hip",
-           "tinympc_solve_d.hip", "tinympc_solve_dw.hip", "tinympc_solve_dx.hip"]
+           "tinympc_solve_d.hip", "tinympc_solve_dr.hip", "tinympc_solve_dw.hip", "tinympc_solve_dx.hip"]
 
 
 def test_lint_catches_a_planted_hazard():
@@ -210,8 +210,8 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
             seen += 1
             size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
-            if source == "tinympc_solve_d.hip" and m.group(1).endswith("ELb0ELb1EEEvNS_11SolveParamsE"):
-                # k_admm_solve_d<..., HOSTX = false, REFILL = true>: the slot-refill variants spill in their RARE paths (write-back
+            if source == "tinympc_solve_dr.hip" and "k_admm_solve_d_refill" in m.group(1):
+                # k_admm_solve_d_refill<...> (tinympc_solve_dr.hip): the slot-refill variants spill in their RARE paths (write-back
                 # and refill of a row: once per instance); their sweeps -- the blocks made of DPP FMAs -- must not touch scratch
                 refill += 1
                 body = re.search(r"^%s:(.*?)^\.Lfunc_end" % re.escape(m.group(1)), text, re.S | re.M).group(1)

@@ -290,6 +290,7 @@ constexpr int WAVES_PER_GROUP_B = 4;
 // per SIMD. Only for the (nx, nu, N) shapes compiled into the library and time-invariant bounds / references.
 bool solve_d_supported(int nx, int nu, int N, bool const_tables);
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream);
+hipError_t launch_solve_d_refill(const SolveParams &p, hipStream_t stream);  // tinympc_solve_dr.hip (SolveParams::refill_next set)
 int solve_d_workgroups(int nu, int N, bool const_tables, int groups);
 size_t solve_d_lds_bytes(int nu, int N, bool const_tables);  // per workgroup
 int solve_d_resident_workgroups(int wpg);  // workgroups of `wpg` wavefronts the device holds at two wavefronts per SIMD (slot refill)

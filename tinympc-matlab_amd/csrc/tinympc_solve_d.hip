@@ -39,6 +39,19 @@
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
 
+// Slot refill is a TEXTUAL variant of this file (TINY_REFILL: tinympc_solve_dr.hip includes it; -DTINY_JIT_REFILL=1 for the
+// run-time specialisations), not a template parameter of the plain kernels: the headline kernel's code depends on such details
+// as the order in which the compiler meets otherwise dead expressions (2.6 % between two builds whose only difference was
+// `REFILL ? a : b` against `b` in the non-refill instantiation, profiles/r03_dgroup_ab.txt), so the plain translation unit
+// preprocesses to exactly the text it had before the variant existed.
+#ifndef TINY_REFILL
+#if defined(TINY_JIT_REFILL) && TINY_JIT_REFILL
+#define TINY_REFILL 1
+#else
+#define TINY_REFILL 0
+#endif
+#endif
+
 namespace tinympc {
 template <int NX, int NU>
 struct DStep;  // specialised per (nx, nu) by tinympc_solve_d_chain.h
@@ -185,6 +198,7 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // HOSTX: the batched zero-copy tick (x0 read from pinned host memory and mirrored, first controls written to pinned host memory). A variant
 // of its own: as run-time branches in the rare paths of the one kernel the two stores cost the sweeps 3.6 % (1.72 -> 1.78 ms: the
 // pointers' scalar registers, live across the unrolled iteration loop).
+#if TINY_REFILL
 // REFILL: slot refill (SolveParams::refill_next). The launch is one resident set of wavefronts; every 16-lane row counts its OWN
 // iterations, and a row whose instance has finished (converged, or max_iter) is written back -- state, solution, statistics -- and
 // loaded with the next instance of the batch, cold or warm, while the other three rows of the wavefront keep iterating. The
@@ -192,9 +206,14 @@ __device__ __forceinline__ bool wave_may_converge_d(unsigned long long bad, unsi
 // a wavefront's time is the sum of what its rows worked, not four times its slowest instance.
 template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true, bool HOSTX = false,
           bool REFILL = false>
+#else
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false, bool ADAPT = false, bool TWO_PER_SIMD = true, bool HOSTX = false>
+#endif
 __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double *smem) {
     static_assert(!(FAM && ADAPT), "adaptive rho and the constraint families exclude each other (as in the C ABI)");
+#if TINY_REFILL
     static_assert(!REFILL || (!FAM && !ADAPT && !HOSTX), "slot refill: box-constrained path only");
+#endif
     // this wavefront's slot on its SIMD (HW_REG_HW_ID bits 3:0): the two wavefronts of a SIMD sit in different slots
     const int simd_slot = TWO_PER_SIMD ? simd_slot_id() : 0;
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
@@ -251,12 +270,16 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double *const gG = p.G + g0 * (N + 1) * 64 + lane;                 // row kn = knot kn
     double *const gD = p.D + g0 * (size_t)(NS * DS);
     double *const gV0 = p.V + (g0 * v_rows(N) + V_PAD) * 64 + lane;    // canonical v|z, knot 0
+#if TINY_REFILL
     // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset; REFILL: the rows of a wavefront belong to different
     // groups of four, so the base is the array's and the offset carries the group -- below 2^32 doubles for any batch that fits HBM)
     double *const gV1u = p.V2 + ((REFILL ? 0 : g0) * v_rows(N) + V_PAD) * 64;
     int cur = (int)inst;  // REFILL: the instance this row works on
     auto row_offset = [&](int i) -> unsigned { return (unsigned)(i >> 2) * (unsigned)(v_rows(N) * 64) + (unsigned)((i & 3) * 16 + r); };
     // (REFILL: rebuilt from `cur` where it is needed -- rare paths -- instead of living in a register across the sweeps)
+#else
+    double *const gV1u = p.V2 + (g0 * v_rows(N) + V_PAD) * 64;         // stale copy, knot 0 (wave-uniform: scalar base + 32-bit lane offset)
+#endif
     const unsigned voff = (unsigned)(lane + koff * 64);
     double *const sVl = sV + lane;
     const bool cold = p.cold != 0;  // (uniform) the state is zero by contract and was never written to HBM: nothing to load
@@ -394,7 +417,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
     double nrho = -rho;
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
     double rhom = is_x ? nrho : 0.0;
+#if TINY_REFILL
     double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+#else
+    const double x0v = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;
+#endif
     if constexpr (HOSTX) {  // zero-copy tick: x0 came from pinned host memory
         if (p.x0_mirror && inst_ok && is_x) p.x0_mirror[inst * NX + r] = x0v;
     }
@@ -442,12 +469,20 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         // (readfirstlane: keeps the loop counter and everything derived from it in SGPRs, so that the branches below
         // are scalar branches and not EXEC-masked regions)
         const int it0 = __builtin_amdgcn_readfirstlane(it);
+#if TINY_REFILL
         const bool final_round = REFILL ? false : it0 >= max_iter;  // (REFILL: every row has its own count, `fin` below)
+#else
+        const bool final_round = it0 >= max_iter;
+#endif
         if constexpr (TWO_PER_SIMD) fair_share_priority<NS>(it0, simd_slot);  // (tinympc_sweep.h: the two wavefronts of a SIMD finish together)
         // ---- write-back: G, D and the canonical v|z (not converged: v = vnew, admm.cpp:196-197; converged: the solve
         // returned before v <- vnew, so the canonical copy is the stale one in V2); solution = vnew / znew (:187-188, 204-205)
+#if TINY_REFILL
         const bool fin = REFILL ? it_done >= max_iter : final_round;
         const bool wb = pending || (fin && active);
+#else
+        const bool wb = pending || (final_round && active);
+#endif
         if (TINY_RARE(__ballot(wb) != 0ull)) {
             // Rare path (once per instance and solve), kept small in registers rather than fast: addresses are rebuilt
             // here from the kernel arguments (the opaque copy of `lane` keeps the compiler from hoisting them out of
@@ -456,16 +491,24 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             asm volatile("" : "+v"(lane_o));
             const int r_o = lane_o & 15, j_o = lane_o >> 4;
             const bool x_o = r_o < NX;
+#if TINY_REFILL
             // (REFILL: this row's instance; its place in the group-of-four layout of the state arrays)
             int cur_o = cur;
             if constexpr (REFILL) asm volatile("" : "+v"(cur_o));
             const size_t grp_w = REFILL ? (size_t)(cur_o >> 2) : (size_t)grp;
             const int lane_w = REFILL ? (cur_o & 3) * 16 + r_o : lane_o;
+#endif
             if (wb && r_o < NXU) {
                 const int ko = x_o ? 1 : 0;
+#if TINY_REFILL
                 const size_t inst_o = REFILL ? (size_t)cur_o : (size_t)grp * IPW + j_o;
                 double *const wG = p.G + grp_w * (N + 1) * 64 + lane_w + ko * 64;                // slot 0
                 double *const wV = p.V + (grp_w * v_rows(N) + V_PAD) * 64 + lane_w + ko * 64;   // slot 0
+#else
+                const size_t inst_o = (size_t)grp * IPW + j_o;
+                double *const wG = p.G + (size_t)grp * (N + 1) * 64 + lane_o + ko * 64;                // slot 0
+                double *const wV = p.V + ((size_t)grp * v_rows(N) + V_PAD) * 64 + lane_o + ko * 64;   // slot 0
+#endif
                 double *const wS = x_o ? p.sol_x + (inst_o * N + 1) * NX + r_o : p.sol_u + inst_o * NS * NU + (r_o - NX);  // slot 0
                 const int sst = x_o ? NX : NU;
                 if (x_o) {  // knot 0
@@ -496,8 +539,13 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                     }
                 }
                 if (!x_o) {
+#if TINY_REFILL
                     double *const wD = p.D + grp_w * (NS * DS) + (REFILL ? (cur_o & 3) : j_o) * NU + (r_o - NX);
+#else
+                    double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
+#endif
                     for (int i = 0; i < NS; ++i) wD[i * DS] = sDw[i * DS];
+#if TINY_REFILL
                 }
             }
             if constexpr (REFILL) {
@@ -563,17 +611,26 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                             for (int i = 0; i < NS; ++i) sDw[i * DS] = nD[i * DS];
                         }
                     }
+#endif
                 }
             }
             pending = false;
         }
         if (final_round || __ballot(active) == 0ull) break;
         const int it1 = it0 + 1;
+#if TINY_REFILL
         // admm.cpp:91 (iter already incremented, :143). REFILL: every row checks by its own count; `check` = some live row does.
-        bool chk = true;
-        if constexpr (REFILL) chk = active && (ct > 0) && (((it_done + 1) % ct) == 0);
-        const bool check = REFILL ? (__ballot(chk) != 0ull)
-                                  : (__builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0);
+        bool chk = true, check_r = false;
+        if constexpr (REFILL) {
+            chk = active && (ct > 0) && (((it_done + 1) % ct) == 0);
+            check_r = __ballot(chk) != 0ull;
+        }
+#define TINY_CHECK_PLAIN (__builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0)
+        const bool check = REFILL ? check_r : TINY_CHECK_PLAIN;
+#undef TINY_CHECK_PLAIN
+#else
+        const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91 (iter already incremented, :143)
+#endif
 
         double pri = 0.0, dua = 0.0;
         bool may = check;  // wave-uniform: can this sweep still end converged for some instance of the wave?
@@ -599,9 +656,17 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             // maxima only grow). With tolerances nothing can meet -- forced iteration counts -- the sweep writes no stale copy.
             if (may && !adapt) {
                 const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+#if TINY_REFILL
                 may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(REFILL ? chk : active))) != 0;
+#else
+                may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+#endif
             }
+#if TINY_REFILL
             if (TINY_RARE(may) && is_x) gV1u[REFILL ? row_offset(cur) : (unsigned)lane] = V0;
+#else
+            if (TINY_RARE(may) && is_x) gV1u[(unsigned)lane] = V0;
+#endif
             V0 = snew;
         }
         if constexpr (FAM) {  // knot 0 of the state rows (its lx only reaches p_0, which nothing reads; the duals persist)
@@ -689,11 +754,19 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
                 if constexpr (s0 > 0) {
                     if (!adapt) {
                         const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
+#if TINY_REFILL
                         may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(REFILL ? chk : active))) != 0;
+#else
+                        may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_d(__ballot(bad), __ballot(active))) != 0;
+#endif
                     }
                 }
                 if (TINY_RARE(may)) {
+#if TINY_REFILL
                     unsigned vo = REFILL ? row_offset(cur) + (unsigned)(koff * 64) : voff;
+#else
+                    unsigned vo = voff;
+#endif
                     double *base = gV1u;
                     asm volatile("" : "+v"(vo), "+s"(base));
                     static_for<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
@@ -701,11 +774,15 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
             }
             static_for<s0, s1>([&](auto S) { fstep(S); });
         });
+#if TINY_REFILL
         if constexpr (REFILL) {
             if (active) it_done += 1;
         } else {
             if (active) it_done = it1;  // admm.cpp:143
         }
+#else
+        if (active) it_done = it1;  // admm.cpp:143
+#endif
 
         // ---------------- adaptive rho (admm.cpp:147-174), as in k_admm_solve_adapt
         const double nrho_lin = nrho, rhom_lin = rhom, pnref_lin = pnref;  // what update_linear_cost used this iteration
@@ -746,7 +823,11 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         if (check) {
             const bool below = (pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol);
             const bool conv = ((__ballot(below) >> (j * W)) & 0xffffull) == 0xffffull;
+#if TINY_REFILL
             if (REFILL ? chk : active) {
+#else
+            if (active) {
+#endif
                 snap_pri = pri;
                 snap_dua = dua;
                 if constexpr (ADAPT) snap_rho = rho;  // cache->rho AFTER the adaptation (admm.cpp:95-96)
@@ -844,7 +925,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
     // A converged solve returned before v <- vnew (admm.cpp:181-197): its canonical v|z is the previous iterate, i.e. the
     // stale copy. (The write-back above stored vnew there; this wave wrote both, in program order.)
+#if TINY_REFILL
     if constexpr (REFILL) return;  // (every row was finished inside the loop)
+#endif
     if (inst_ok && status == 1 && r < NXU) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const int rows = is_x ? N : NS;
@@ -888,10 +971,19 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 }
 
 #ifndef TINY_JIT
-template <int NX, int NU, int N, bool CT, int WPG, int VL, bool HOSTX = false, bool REFILL = false>
+#if TINY_REFILL
+template <int NX, int NU, int N, bool CT, int WPG, int VL>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d_refill(const SolveParams p) {
+#else
+template <int NX, int NU, int N, bool CT, int WPG, int VL, bool HOSTX = false>
 __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_admm_solve_d(const SolveParams p) {
+#endif
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, HOSTX, REFILL>(p, smem);
+#if TINY_REFILL
+    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, false, true>(p, smem);
+#else
+    k_admm_solve_d_body<NX, NU, N, CT, WPG, VL, false, false, true, HOSTX>(p, smem);
+#endif
 }
 #endif
 
@@ -922,10 +1014,14 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr int VLJ = tinympc::d_vl(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS, FAMJ, ADJ);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
     __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::d_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ) / sizeof(double)];
+#if TINY_REFILL
 #ifndef TINY_JIT_REFILL
 #define TINY_JIT_REFILL 0
 #endif
     tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ, TINY_JIT_WPS == 2, false, TINY_JIT_REFILL != 0>(p, smem_jit);
+#else
+    tinympc::k_admm_solve_d_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, FAMJ, ADJ, TINY_JIT_WPS == 2>(p, smem_jit);
+#endif
 }
 namespace tinympc {
 #else
@@ -938,6 +1034,7 @@ namespace tinympc {
 // per SIMD (10.1 us, 406 M); full batches gain a few percent from the finer tail (profiles/r02_layout_sweep.txt).
 __host__ __device__ constexpr int d_wpg(int nu, int N, bool ct) { return d_vl(nu, N, ct, 4) >= 0 ? 4 : 8; }
 
+#if !TINY_REFILL
 // Slot refill launches one resident set: 2 wavefronts per SIMD x 4 SIMDs x the device's CUs, in workgroups of wpg.
 int solve_d_resident_workgroups(int wpg) {
     static int cus = 0;
@@ -950,6 +1047,9 @@ int solve_d_resident_workgroups(int wpg) {
 }
 int solve_d_wavefronts_per_workgroup(int nu, int N, bool const_tables) { return d_wpg(nu, N, const_tables); }
 
+#endif
+#if TINY_REFILL
+// (the slot-refill translation unit, tinympc_solve_dr.hip: one resident set of wavefronts, tinympc_plan.hip decides when)
 template <int NX, int NU, int N, bool CT>
 static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
     constexpr int WPG = d_wpg(NU, N, CT);
@@ -958,15 +1058,28 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
         return hipErrorInvalidValue;
     } else {
         constexpr size_t lds = d_lds_bytes(NU, N, CT, WPG, VL);
-        static size_t lds_set[16] = {0}, lds_set_x[16] = {0}, lds_set_r[16] = {0};
+        static size_t lds_set_r[16] = {0};
         const int wgs = (p.groups + WPG - 1) / WPG;
-        if (p.refill_next) {  // (slot refill: one resident set of wavefronts, tinympc_plan.hip)
-            auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL, false, true>;
-            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_r);
-            if (e != hipSuccess) return e;
-            const int resident = solve_d_resident_workgroups(WPG);
-            hipLaunchKernelGGL(fn, dim3(wgs < resident ? wgs : resident), dim3(64 * WPG), lds, stream, p);
-        } else if (p.x0_mirror || p.u0_host) {  // (the batched zero-copy tick)
+        auto fn = &k_admm_solve_d_refill<NX, NU, N, CT, WPG, VL>;
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_r);
+        if (e != hipSuccess) return e;
+        const int resident = solve_d_resident_workgroups(WPG);
+        hipLaunchKernelGGL(fn, dim3(wgs < resident ? wgs : resident), dim3(64 * WPG), lds, stream, p);
+        return hipGetLastError();
+    }
+}
+#else
+template <int NX, int NU, int N, bool CT>
+static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
+    constexpr int WPG = d_wpg(NU, N, CT);
+    constexpr int VL = d_vl(NU, N, CT, WPG);
+    if constexpr (VL < 0) {
+        return hipErrorInvalidValue;
+    } else {
+        constexpr size_t lds = d_lds_bytes(NU, N, CT, WPG, VL);
+        static size_t lds_set[16] = {0}, lds_set_x[16] = {0};
+        const int wgs = (p.groups + WPG - 1) / WPG;
+        if (p.x0_mirror || p.u0_host) {  // (the batched zero-copy tick)
             auto fn = &k_admm_solve_d<NX, NU, N, CT, WPG, VL, true>;
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), lds, lds_set_x);
             if (e != hipSuccess) return e;
@@ -981,11 +1094,23 @@ static hipError_t launch_d_one(const SolveParams &p, hipStream_t stream) {
     }
 }
 
+#endif
+
 #define TINY_D_SHAPES(X) \
     X(12, 4, 50)         \
     X(4, 1, 20)          \
     X(4, 1, 10)
 
+#if TINY_REFILL
+hipError_t launch_solve_d_refill(const SolveParams &p, hipStream_t stream) {
+#define X(NX_, NU_, N_)                                       \
+    if (p.nx == NX_ && p.nu == NU_ && p.N == N_)              \
+        return p.const_tables ? launch_d_one<NX_, NU_, N_, true>(p, stream) : launch_d_one<NX_, NU_, N_, false>(p, stream);
+    TINY_D_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+#else
 bool solve_d_supported(int nx, int nu, int N, bool const_tables) {
 #define X(NX_, NU_, N_) \
     if (nx == NX_ && nu == NU_ && N == N_) return d_vl(NU_, N_, const_tables, d_wpg(NU_, N_, const_tables)) >= 0;
@@ -995,6 +1120,7 @@ bool solve_d_supported(int nx, int nu, int N, bool const_tables) {
 }
 
 hipError_t launch_solve_d(const SolveParams &p, hipStream_t stream) {
+    if (p.refill_next) return launch_solve_d_refill(p, stream);  // (tinympc_solve_dr.hip)
 #define X(NX_, NU_, N_)                                       \
     if (p.nx == NX_ && p.nu == NU_ && p.N == N_)              \
         return p.const_tables ? launch_d_one<NX_, NU_, N_, true>(p, stream) : launch_d_one<NX_, NU_, N_, false>(p, stream);
@@ -1012,6 +1138,8 @@ int solve_d_workgroups(int nu, int N, bool const_tables, int groups) {
     const int wpg = d_wpg(nu, N, const_tables);
     return (groups + wpg - 1) / wpg;
 }
+
+#endif  // TINY_REFILL
 
 #endif  // TINY_JIT
 
