@@ -99,3 +99,31 @@ def test_slot_refill_is_only_taken_where_it_can_pay(pkg, monkeypatch):
         np.testing.assert_array_equal(a, b)
     assert np.all(plain[2] == 12) and np.all(plain[3] == 11)
     s.reset()
+
+
+@pytest.mark.parametrize("B,ct,max_iter,tol", [(8193, 1, 30, 1e-3), (9100, 1, 1, 1e-3), (9100, 5, 3, 1e-3), (10240, 4, 9, 1e-2), (8200, 1, 25, 1e3)])
+def test_slot_refill_edges(pkg, monkeypatch, B, ct, max_iter, tol):
+    """One instance more than a resident set; max_iter 1; a check_termination that never comes up before max_iter (nobody is
+    ever tested: every instance runs max_iter and reports no residuals); a check every fourth iteration with max_iter not a
+    multiple of it; tolerances everything meets at the first check. Always: what the plain kernel returns, bit for bit."""
+    P = pkg.problems
+    prob = P.quadrotor(50)
+    rng = np.random.default_rng(B)
+    x0s = np.asfortranarray(P.quadrotor_batch_x0(B) * rng.uniform(0.05, 3.0, B)[None, :])
+    settings = dict(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=max_iter, check_termination=ct)
+    got = {}
+    for refill in (False, True):
+        s = _batch(pkg, prob, B, settings, x0s, refill, monkeypatch)
+        assert ("slot-refill" in s.jit_info()) == refill
+        s.solve()
+        first = _everything(s)
+        s.solve()  # warm, same x0
+        got[refill] = (first, _everything(s))
+        s.reset()
+    for k in range(2):
+        for a, b, what in zip(got[False][k], got[True][k], ("states", "controls", "iterations", "status", "residuals")):
+            np.testing.assert_array_equal(a, b, err_msg=f"solve {k}: {what}")
+    if ct > max_iter:
+        assert np.all(got[True][0][2] == max_iter) and np.all(got[True][0][3] != 1)
+    if tol >= 1e3:
+        assert np.all(got[True][0][2] == ct) and np.all(got[True][0][3] == 1)

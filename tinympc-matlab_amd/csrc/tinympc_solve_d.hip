@@ -663,9 +663,9 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 #endif
             }
 #if TINY_REFILL
-            if (TINY_RARE(may) && is_x) gV1u[REFILL ? row_offset(cur) : (unsigned)lane] = V0;
+            if (TINY_RARE(may) && is_x && active) gV1u[REFILL ? row_offset(cur) : (unsigned)lane] = V0;
 #else
-            if (TINY_RARE(may) && is_x) gV1u[(unsigned)lane] = V0;
+            if (TINY_RARE(may) && is_x && active) gV1u[(unsigned)lane] = V0;  // (active: see the stale copy of the slots below)
 #endif
             V0 = snew;
         }
@@ -769,7 +769,10 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 #endif
                     double *base = gV1u;
                     asm volatile("" : "+v"(vo), "+s"(base));
-                    static_for<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
+                    // Only for instances that are still iterating: a zombie's slots hold iterates it computed AFTER it converged,
+                    // and its own stale copy -- the previous iterate of the sweep in which it converged, its canonical v|z
+                    // (admm.cpp:181-197) -- must survive the later sweeps of its wavefront's other instances.
+                    if (active) static_for<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
                 }
             }
             static_for<s0, s1>([&](auto S) { fstep(S); });

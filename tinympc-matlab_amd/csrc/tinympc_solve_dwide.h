@@ -269,7 +269,7 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
                 const bool bad = !((pri < p.abs_pri_tol) && (dua * rho < p.abs_dua_tol));
                 may = __builtin_amdgcn_readfirstlane((int)wave_may_converge_w<W>(__ballot(bad), __ballot(active))) != 0;
             }
-            if (may && is_x) gV1u[(unsigned)lane] = V0;
+            if (may && is_x && active) gV1u[(unsigned)lane] = V0;  // (active: as for the slots below)
             V0 = snew;
         }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
@@ -330,7 +330,9 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
                     unsigned vo = voff;
                     double *base = gV1u;
                     asm volatile("" : "+v"(vo), "+s"(base));
-                    static_for_w<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
+                    // (only for instances that are still iterating: a converged instance's stale copy -- its canonical v|z,
+                    // admm.cpp:181-197 -- must survive the later sweeps of the wavefront's other instance; tinympc_solve_d.hip)
+                    if (active) static_for_w<s0, s1>([&](auto S) { (base + S.value * 64)[vo] = vget(S); });
                 }
             }
             static_for_w<s0, s1>([&](auto S) { fstep(S); });

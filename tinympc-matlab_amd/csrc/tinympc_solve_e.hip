@@ -320,7 +320,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             if (bottom) {      // knot 0, state lanes: x_0 is given (tiny_set_x0), no mat-vec
                 const double lo0 = CT ? lo_c : sT[W + r], hi0 = CT ? hi_c : sT[TOFF + W + r];
                 const double x0v = sK0[4 * 64 + lane], G0 = sK0[lane], V0 = sK0[64 + lane];
-                if (may && is_x) gV1u[(unsigned)lane] = V0;
+                if (may && is_x && active) gV1u[(unsigned)lane] = V0;  // (active: as for the slots below)
                 const double s = x0v + G0;
                 const double snew = fmin(hi0, fmax(lo0, s));
                 sK0[lane] = s - snew;
@@ -399,7 +399,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                             double *base = gV1u;
                             asm volatile("" : "+v"(vo), "+s"(base));
                             e_static_for<g0, g1>([&](auto Q) {
-                                if (real(Q.value)) (base + Q.value * 64)[vo] = V[Q.value];
+                                // (active: a converged instance's stale copy must survive its neighbours' later sweeps, tinympc_solve_d.hip)
+                                if (real(Q.value) && active) (base + Q.value * 64)[vo] = V[Q.value];
                             });
                         }
                     }
