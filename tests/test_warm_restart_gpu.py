@@ -28,7 +28,8 @@ def _wide_system(P, nx, nu, N, seed=0):
     return prob
 
 
-CASES = [("A", "quadrotor", 50, 64), ("B", "quadrotor", 50, 64), ("C", "quadrotor", 50, 64), ("D", "quadrotor", 50, 64), ("D", "quadrotor", 20, 200),
+CASES = [("A", "rocket", 10, 64), ("D", "rocket", 10, 64), ("E", "rocket", 100, 32), ("F", "rocket", 100, 8),
+         ("A", "quadrotor", 50, 64), ("B", "quadrotor", 50, 64), ("C", "quadrotor", 50, 64), ("D", "quadrotor", 50, 64), ("D", "quadrotor", 20, 200),
          ("D", "wide32", 30, 64), ("D", "wide64", 20, 32), ("E", "quadrotor", 125, 64), ("D", "quadrotor", 100, 64)]
 
 
@@ -40,14 +41,26 @@ def test_second_solve_of_a_mixed_batch_matches_the_oracle(pkg, monkeypatch, layo
     if system == "quadrotor":
         prob = P.quadrotor(N)
         x0s = np.asfortranarray(P.quadrotor_batch_x0(B) * rng.uniform(0.05, 3.0, B)[None, :])
+    elif system == "rocket":  # cones + a linear row + fdyn + references (BASELINE config 4; the oracle is the builder's restatement there)
+        prob = P.rocket(N)
+        x0s = np.asfortranarray(prob.x0[:, None] * rng.uniform(0.2, 1.3, B)[None, :])
     else:
         prob = _wide_system(P, 24, 8, N) if system == "wide32" else _wide_system(P, 40, 8, N)
         x0s = np.asfortranarray(rng.standard_normal((prob.A.shape[0], B)) * rng.uniform(0.02, 1.0, B)[None, :])
-    tol = 3e-2 if system == "wide64" else 1e-3  # (the 48-row synthetic system converges slowly)
-    settings = dict(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=80, check_termination=1)
+    # (the 48-row synthetic system and the 100-knot rocket landing converge slowly: looser tolerances, so that instances DO converge)
+    tol = 3e-2 if system == "wide64" else 2e-2 if (system == "rocket" and N == 100) else 1e-3
+    settings = dict(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=200 if system == "rocket" else 80, check_termination=1)
     s = pkg.TinyMPC()
-    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, **settings)
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, fdyn=prob.fdyn, **settings)
     s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if prob.cones:
+        s.set_cone_constraints(**prob.cones)
+    if prob.linear:
+        s.set_linear_constraints(**prob.linear)
+    if prob.x_ref is not None:
+        s.set_x_ref(prob.x_ref)
+    if prob.u_ref is not None:
+        s.set_u_ref(prob.u_ref)
     s.set_x0_batch(x0s)
     s.solve()
     it0 = s.get_stats_batch()["iter"].copy()
