@@ -18,10 +18,10 @@ import pyoracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _wide_system(P, nx, nu, N, seed=0):
+def _wide_system(P, nx, nu, N, seed=0, a_scale=0.03, b_scale=0.1, diag=1.0):
     rng = np.random.default_rng(seed)
-    A = np.eye(nx) + 0.03 * rng.standard_normal((nx, nx))
-    B = 0.1 * rng.standard_normal((nx, nu))
+    A = np.eye(nx) * diag + a_scale * rng.standard_normal((nx, nx))
+    B = b_scale * rng.standard_normal((nx, nu))
     prob = P.Problem("wide", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 2.0, rng.standard_normal(nx))
     prob.u_min, prob.u_max = np.full(nu, -0.3), np.full(nu, 0.3)
     prob.x_min, prob.x_max = np.full(nx, -2.0), np.full(nx, 2.0)
@@ -30,7 +30,7 @@ def _wide_system(P, nx, nu, N, seed=0):
 
 CASES = [("A", "rocket", 10, 64), ("D", "rocket", 10, 64), ("E", "rocket", 100, 32), ("F", "rocket", 100, 8),
          ("A", "quadrotor", 50, 64), ("B", "quadrotor", 50, 64), ("C", "quadrotor", 50, 64), ("D", "quadrotor", 50, 64), ("D", "quadrotor", 20, 200),
-         ("D", "wide32", 30, 64), ("D", "wide64", 20, 32), ("E", "quadrotor", 125, 64), ("D", "quadrotor", 100, 64)]
+         ("D", "wide32", 30, 64), ("D", "wide64", 20, 32), ("M", "large", 10, 48), ("E", "quadrotor", 125, 64), ("D", "quadrotor", 100, 64)]
 
 
 @pytest.mark.parametrize("layout,system,N,B", CASES)
@@ -44,11 +44,14 @@ def test_second_solve_of_a_mixed_batch_matches_the_oracle(pkg, monkeypatch, layo
     elif system == "rocket":  # cones + a linear row + fdyn + references (BASELINE config 4; the oracle is the builder's restatement there)
         prob = P.rocket(N)
         x0s = np.asfortranarray(prob.x0[:, None] * rng.uniform(0.2, 1.3, B)[None, :])
+    elif system == "large":  # 84 rows: layout M, sixteen instances per matrix-core tile
+        prob = _wide_system(P, 70, 14, N, a_scale=0.015, b_scale=0.08, diag=0.98)
+        x0s = np.asfortranarray(rng.standard_normal((70, B)) * rng.uniform(0.02, 1.0, B)[None, :])
     else:
         prob = _wide_system(P, 24, 8, N) if system == "wide32" else _wide_system(P, 40, 8, N)
         x0s = np.asfortranarray(rng.standard_normal((prob.A.shape[0], B)) * rng.uniform(0.02, 1.0, B)[None, :])
-    # (the 48-row synthetic system and the 100-knot rocket landing converge slowly: looser tolerances, so that instances DO converge)
-    tol = 3e-2 if system == "wide64" else 2e-2 if (system == "rocket" and N == 100) else 1e-3
+    # (the 48- and 84-row synthetic systems and the 100-knot rocket landing converge slowly: looser tolerances, so that instances DO converge)
+    tol = 3e-2 if system in ("wide64", "large") else 2e-2 if (system == "rocket" and N == 100) else 1e-3
     settings = dict(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=200 if system == "rocket" else 80, check_termination=1)
     s = pkg.TinyMPC()
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, fdyn=prob.fdyn, **settings)
@@ -64,6 +67,8 @@ def test_second_solve_of_a_mixed_batch_matches_the_oracle(pkg, monkeypatch, layo
     s.set_x0_batch(x0s)
     s.solve()
     it0 = s.get_stats_batch()["iter"].copy()
+    if system == "large":
+        assert s.launch_info()["layout"] == "M"
     if system != "wide64":  # (64 lanes: one instance per wavefront, nothing to overwrite; the warm semantics are checked all the same)
         assert len(np.unique(it0)) >= 4, "the batch must converge at different iterations for this test to mean anything"
     s.solve()                      # warm, same x0: most instances now converge at the first check
