@@ -297,8 +297,8 @@ int tinympc_get_layout(tinympc_solver *s);
  * (8,192 instances of 16 lanes on MI355X) runs as ONE resident set of wavefronts, and a 16-lane row whose instance has finished
  * (converged, or max_iter) is written back and given the next instance of the batch while the rest of its wavefront keeps
  * iterating -- a wavefront then costs the sum of what its rows worked instead of four times its slowest instance. Results are
- * bit-identical to the plain kernel's. Taken whenever the tolerances can be met, and from two resident sets on with forced
- * iteration counts; TINYMPC_REFILL=0 switches it off, =1 takes it for any batch beyond one resident set. */
+ * bit-identical to the plain kernel's. Taken whenever the tolerances can be met (with forced iteration counts there is nothing to
+ * balance); TINYMPC_REFILL=0 switches it off, =1 takes it for any batch beyond one resident set. */
 int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len);
 
 /* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:

@@ -91,8 +91,15 @@ constexpr int D_FIRST = TINY_D_FIRST;
 // steps (a sweep that cannot converge has then copied D_FIRST slots of stale iterate at most), then every D_GROUP steps.
 // Each test is a scheduling boundary of the unrolled sweep; 4 | 23 measured best of the splits tried on the headline
 // (profiles/r03_dgroup_ab.txt), forced iterations and converging batch alike.
+#if TINY_REFILL
+// (the slot-refill variant runs converging batches: finer groups cut a sweep's stale copies sooner -- 4 | 12 measured best of
+// eight splits on the 65,536-instance converging batch, 10.7 against 10.85 ms with 4 | 23; profiles/r03_refill_probe.txt)
+constexpr int D_GROUP = 12;
+constexpr int D_FIRST = 4;
+#else
 constexpr int D_GROUP = 23;
 constexpr int D_FIRST = 4;
+#endif
 #endif
 #ifdef TINY_JIT_VREG
 constexpr int D_VREG_MAX = TINY_JIT_VREG;  // chosen by the host from its register estimate

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package(); P = pkg.problems
 prob = P.quadrotor(50)
-for B in (9000, 12288, 16384, 24576, 32768):
+for B in (16384, 32768, 65536):
   x0s = P.quadrotor_batch_x0(B)
   for mode in ("0", "1"):
       os.environ["TINYMPC_REFILL"] = mode
