@@ -263,6 +263,14 @@ int tinympc_synchronize(tinympc_solver *s);
  * the handle's stream immediately around the launch. */
 int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
 
+/* Throughput form of the timed solve: queue the launch on the handle's stream and return at once; every queued launch records its
+ * own HIP event pair around the solve kernel. tinympc_collect_kernel_ms waits for the stream and returns the kernel durations of
+ * the launches queued since the last collect, in order (*count; an error if they exceed `capacity`, at most 4,096). Between two
+ * queued solves the caller may queue tinympc_reset_workspace / tinympc_set_x0_batch_device as usual -- they run on the same stream,
+ * in order; host readers (get_solution ...) synchronise as always. Batched handles outside a session only. */
+int tinympc_solve_queued(tinympc_solver *s);
+int tinympc_collect_kernel_ms(tinympc_solver *s, float *kernel_ms, int capacity, int *count);
+
 /* One closed-loop control tick for every instance of the handle (the loop of
  * examples/cartpole_example_mpc.m:36-44 / rocket_landing_constraints.m:86-121 as ONE call): upload the
  * measured states x0s (nx x batch), run the warm-started solve, download the first control of each

@@ -85,6 +85,8 @@ SIGNATURES = {
     "tinympc_solve_async": (C.c_int, [Handle]),
     "tinympc_synchronize": (C.c_int, [Handle]),
     "tinympc_solve_timed": (C.c_int, [Handle, C.POINTER(C.c_float)]),
+    "tinympc_solve_queued": (C.c_int, [Handle]),
+    "tinympc_collect_kernel_ms": (C.c_int, [Handle, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "tinympc_mpc_step_batch": (C.c_int, [Handle, c_double_p, c_double_p]),
     "tinympc_session_begin": (C.c_int, [Handle]),
     "tinympc_session_step": (C.c_int, [Handle, c_double_p, c_double_p]),

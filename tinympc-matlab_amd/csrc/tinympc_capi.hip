@@ -399,6 +399,43 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms) {
     return TINYMPC_OK;
 }
 
+int tinympc_solve_queued(tinympc_solver *s) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    if (s->session_active || s->host_path()) return fail(TINYMPC_ERR_UNSUPPORTED, "solve_queued: batched handles outside a session only");
+    if (s->ring_count >= 4096) return fail(TINYMPC_ERR_INVALID_INPUT, "solve_queued: 4096 launches queued, collect their times first");
+    if ((rc = refresh_derived(s))) return rc;  // keep table rebuilds out of the timed region
+    while ((int)s->ring_ev.size() < 2 * (s->ring_count + 1)) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        s->ring_ev.push_back(e);
+    }
+    // the launch records the handle's event pair: lend it this launch's slot of the ring
+    hipEvent_t keep0 = s->ev0, keep1 = s->ev1;
+    s->ev0 = s->ring_ev[2 * (size_t)s->ring_count];
+    s->ev1 = s->ring_ev[2 * (size_t)s->ring_count + 1];
+    rc = launch(s, true);
+    s->ev0 = keep0;
+    s->ev1 = keep1;
+    if (rc) return rc;
+    s->ring_count++;
+    return TINYMPC_OK;
+}
+
+int tinympc_collect_kernel_ms(tinympc_solver *s, float *kernel_ms, int capacity, int *count) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if ((rc = bind_device(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int n = s->ring_count;
+    if (count) *count = n;
+    if (n > capacity || (n > 0 && !kernel_ms)) return fail(TINYMPC_ERR_INVALID_INPUT, "collect_kernel_ms: %d launches queued, room for %d", n, capacity);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&kernel_ms[i], s->ring_ev[2 * (size_t)i], s->ring_ev[2 * (size_t)i + 1]));
+    s->ring_count = 0;
+    return TINYMPC_OK;
+}
+
 int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out) {
     int rc = check_handle(s);
     if (rc) return rc;

@@ -55,6 +55,8 @@ struct tinympc_solver {
     tinympc::Settings st{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ring_ev;  // tinympc_solve_queued: one event pair per queued launch (2 i, 2 i + 1)
+    int ring_count = 0;               // pairs recorded since the last tinympc_collect_kernel_ms
     // problem + cache
     double *dA = nullptr, *dB = nullptr, *dfdyn = nullptr, *dQd = nullptr, *dRd = nullptr;
     double *dKinf = nullptr, *dPinf = nullptr, *dQuu = nullptr, *dAmBKt = nullptr, *dAPf = nullptr, *dBPf = nullptr;

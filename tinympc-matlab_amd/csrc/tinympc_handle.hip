@@ -273,6 +273,8 @@ void destroy(tinympc_solver *s) {
     if (s->h_u0) (void)hipHostFree(s->h_u0);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ring_ev) (void)hipEventDestroy(e);
+    s->ring_ev.clear();
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

@@ -354,6 +354,19 @@ class TinyMPC:
         _lib.check(self._L.tinympc_solve_timed(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def solve_queued(self):
+        """Queue a timed solve on the handle's stream and return at once (tinympc_solve_queued); collect_kernel_ms() waits and
+        returns the kernel durations of everything queued since the last collect."""
+        self._check_setup()
+        _lib.check(self._L.tinympc_solve_queued(self._h))
+
+    def collect_kernel_ms(self) -> list[float]:
+        self._check_setup()
+        buf = (C.c_float * 4096)()
+        n = C.c_int()
+        _lib.check(self._L.tinympc_collect_kernel_ms(self._h, buf, 4096, C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
     def solve_async(self):
         self._check_setup()
         _lib.check(self._L.tinympc_solve_async(self._h))
