@@ -145,14 +145,17 @@ def test_device_adaptive_rho_batch_with_computed_sensitivities(pkg, which):
         o.set_sensitivity(dK, dP)
         o.set_x_ref(Xref)
         oracles.append(o)
-    for solve in range(2):
-        s.set_x0_batch(x0s * (1.0 - 0.4 * solve))
+    for solve in range(3):  # (the third: warm from a state in which the instances had converged at different iterations)
+        s.set_x0_batch(x0s * (1.0 - 0.4 * min(solve, 1)))
         s.solve()
         sol, st, rho = s.get_solution_batch(), s.get_stats_batch(), s.get_rho_batch()
         for b, o in enumerate(oracles):
-            o.set_x0(x0s[:, b] * (1.0 - 0.4 * solve))
+            o.set_x0(x0s[:, b] * (1.0 - 0.4 * min(solve, 1)))
             o.solve()
             assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], (solve, b)
+            if st["iter"][b] > 0:  # the residuals of the last check: they depend on the canonical v|z the PREVIOUS solve left
+                want = np.array([o.stats()[k] for k in ("pri_x", "dua_x", "pri_u", "dua_u")])
+                np.testing.assert_allclose(st["residuals"][:, b], want, rtol=1e-6, atol=1e-12, err_msg=f"solve {solve}, instance {b}")
             assert abs(rho[b] - o.stats()["rho"]) < 1e-9 * rho[b], (solve, b)
             assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL, (solve, b)
             assert rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, (solve, b)
