@@ -91,3 +91,36 @@ def test_second_solve_of_a_mixed_batch_matches_the_oracle(pkg, monkeypatch, layo
             np.testing.assert_allclose(st["residuals"][:, i], ref, rtol=1e-6, atol=1e-12, err_msg=f"instance {i} (first solve: {it0[i]} iterations)")
             ox, ou = orc.solution()
             assert rel_err(sol["states"][:, :, i], ox) < 1e-9 and rel_err(sol["controls"][:, :, i], ou) < 1e-9
+
+
+@pytest.mark.parametrize("layout,B", [("D", 64), ("C", 24), ("A", 40)])
+def test_closed_loop_of_a_mixed_batch_matches_the_oracle_tick_by_tick(pkg, monkeypatch, layout, B):
+    """The callers' real pattern (cartpole_example_mpc.m:36-44) on a batch: every tick x0 in, warm-started solve, first controls
+    out, plant step. Instances start at different distances from the origin, so in every tick they converge at different
+    iterations -- each must follow its own oracle closed loop exactly (iteration counts) and to 1e-9 (controls)."""
+    P = pkg.problems
+    monkeypatch.setenv("TINYMPC_LAYOUT", layout)
+    prob = P.quadrotor(50 if layout == "D" else 20)
+    rng = np.random.default_rng(3)
+    x = np.asfortranarray(P.quadrotor_batch_x0(B) * rng.uniform(0.05, 2.5, B)[None, :])
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=40, check_termination=1)
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    oracles = [O.OraclePort(prob).load_problem(prob, settings) for _ in range(B)]
+    xo = x.copy()
+    spread = 0
+    for tick in range(6):
+        u0 = s.mpc_step(x)
+        its = s.get_stats_batch()["iter"]
+        spread = max(spread, len(np.unique(its)))
+        for b, o in enumerate(oracles):
+            o.set_x0(xo[:, b])
+            o.solve()
+            assert its[b] == o.stats()["iter"], (tick, b, its[b], o.stats()["iter"])
+            uo = o.solution()[1][:, 0]
+            assert np.max(np.abs(u0[:, b] - uo)) <= 1e-9 * max(np.max(np.abs(uo)), 1e-3), (tick, b)
+            xo[:, b] = prob.A @ xo[:, b] + prob.B @ uo
+        x = np.asfortranarray(prob.A @ x + prob.B @ u0)
+    assert spread >= 3
+    s.reset()
