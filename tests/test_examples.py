@@ -10,7 +10,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script", ["one_solve.py", "mpc_loop.py", "rocket_landing.py", "batched_throughput.py", "large_system.py"])
+@pytest.mark.parametrize("script", ["one_solve.py", "mpc_loop.py", "rocket_landing.py", "batched_throughput.py", "large_system.py", "converging_batch.py"])
 def test_example_runs(script):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], capture_output=True, text=True, timeout=600,
                          cwd=os.path.join(ROOT, "examples"))
