@@ -3,7 +3,8 @@
 extra legs, a few launches each, nothing else in the process (no torch import: numpy + the C ABI only).
 
     python tools/leg_workload.py <leg> [launches]
-legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance
+legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance,
+      converging_batch, converging_batch_plain
 Prints one JSON line: leg, kernel layout, launches, iterations per launch, instances, median kernel ms (HIP events)."""
 import json
 import os
@@ -80,6 +81,18 @@ def build(leg):
         return s, 8192, 100
     if leg == "single_instance":
         return quadrotor(50, 1, 200), 1, 200
+    if leg in ("converging_batch", "converging_batch_plain"):
+        # 65,536 quadrotors solved to a tolerance, 5 ... 200 iterations each: the slot-refill variant (tinympc_solve_dr.hip) against
+        # the plain kernel (TINYMPC_REFILL=0). "iterations per launch" is the mean over the batch (127.6).
+        os.environ["TINYMPC_REFILL"] = "0" if leg.endswith("_plain") else "1"
+        prob = P.quadrotor(50)
+        nb = 65536
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=200, check_termination=1)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        rng = np.random.default_rng(0)
+        s.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(nb) * rng.uniform(0.05, 3.0, nb)[None, :]))
+        return s, nb, 127.574
     raise SystemExit("unknown leg " + leg)
 
 
