@@ -310,8 +310,8 @@ int tinympc_get_layout(tinympc_solver *s);
 int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len);
 
 /* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:
- * bounds / references that vary over the horizon, cone / linear families and adaptive rho select variants that are otherwise
- * built at the first launch that needs them. Call it once after the constraints and settings are in place to keep that
+ * bounds / references that vary over the horizon, cone / linear families, adaptive rho and slot refill select variants that are
+ * otherwise built at the first launch that needs them. Call it once after the constraints and settings are in place to keep that
  * one-off cost out of the first real-time tick. No reference counterpart (the reference has one code path). */
 int tinympc_prepare(tinympc_solver *s);
 

@@ -389,7 +389,9 @@ int tinympc_prepare(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
-    return resolve_plan(s);
+    if ((rc = resolve_plan(s))) return rc;
+    (void)refill_applies(s, current_plan(s));  // (a run-time specialised shape builds its slot-refill variant here, not in the first solve)
+    return TINYMPC_OK;
 }
 
 int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len) {
