@@ -40,10 +40,11 @@
 #include "tinympc_sweep.h"
 
 // Slot refill is a TEXTUAL variant of this file (TINY_REFILL: tinympc_solve_dr.hip includes it; -DTINY_JIT_REFILL=1 for the
-// run-time specialisations), not a template parameter of the plain kernels: the headline kernel's code depends on such details
-// as the order in which the compiler meets otherwise dead expressions (2.6 % between two builds whose only difference was
-// `REFILL ? a : b` against `b` in the non-refill instantiation, profiles/r03_dgroup_ab.txt), so the plain translation unit
-// preprocesses to exactly the text it had before the variant existed.
+// run-time specialisations), not a template parameter of the plain kernels: as one, the non-refill instantiation kept its
+// semantics but not its code, and lost 2.6 % (profiles/r03_dgroup_ab.txt). What it had lost was found afterwards -- its sweep
+// chains had moved off the 8-byte grid by one 4-byte instruction, see D_AL in tinympc_solve_d_chain.h, which now puts every
+// chain on the grid by construction; the variant stays textual all the same: the plain translation unit preprocesses to
+// exactly the text it had before the variant existed.
 #ifndef TINY_REFILL
 #if defined(TINY_JIT_REFILL) && TINY_JIT_REFILL
 #define TINY_REFILL 1
@@ -52,6 +53,8 @@
 #endif
 #endif
 
+#define TINY_STR2(x) #x
+#define TINY_STR(x) TINY_STR2(x)
 namespace tinympc {
 template <int NX, int NU>
 struct DStep;  // specialised per (nx, nu) by tinympc_solve_d_chain.h
@@ -470,6 +473,12 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
 
 #ifdef TINY_CLOCK_STAMP  // diagnostic build only (tools/clock_check.py): the shader clock held under this kernel
     const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef TINY_D_PAD  // (experiment: TINY_D_PAD s_nop in front of the iteration loop -- shifts the loop's code by 4 bytes each)
+    asm volatile(".rept " TINY_STR(TINY_D_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory");
+#endif
+#ifdef TINY_D_LOOP_ALIGN  // (experiment: the iteration loop's code starts on a 2^TINY_D_LOOP_ALIGN byte boundary)
+    asm volatile(".p2align " TINY_STR(TINY_D_LOOP_ALIGN) ::: "memory");
 #endif
     const int max_iter = p.max_iter;
     for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129

@@ -28,10 +28,19 @@
 // generated code: there every chain block opens with its own `s_nop 1`, whatever the compiler may have placed in front of it
 // (a register copy or v_accvgpr_read of `x` / `d` on the 512-register plan). The compiled-in instantiations keep the bare
 // blocks and are linted by the build (tools/isa_lint.py; the nop costs 1-2 % there).
-#if defined(TINY_JIT) || defined(TINY_CHAIN_NOP)
-#define D_HAZ "s_nop 1\n\t"
+// Every chain starts on an 8-byte boundary. Its instructions are 8 bytes each, and whether they sit on the 8-byte grid or
+// straddle it decided, alone, between the two speeds every build of these kernels had shown (+-2.5 %, profiles/r03_dgroup_ab.txt):
+// four bytes of s_nop in front of the iteration loop switch a fast build to the slow one and back; with the alignment both are
+// fast (1.669 / 1.669 against 1.670 / 1.712 ms on the headline). At most one 4-byte s_nop per block.
+#ifdef TINY_CHAIN_NOALIGN  // (experiments)
+#define D_AL ""
 #else
-#define D_HAZ ""
+#define D_AL ".p2align 3\n\t"
+#endif
+#if defined(TINY_JIT) || defined(TINY_CHAIN_NOP)
+#define D_HAZ "s_nop 1\n\t" D_AL
+#else
+#define D_HAZ D_AL
 #endif
 #define D_FM_(src, i) "v_fmac_f64_dpp %[a], " src ", %[m" #i "] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
 // column i of the chain: state operand, input operand, or nothing.
@@ -194,7 +203,7 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_plain(double x, double d, const double (&m)[16], double c) {
         double a;
         asm volatile("v_mov_b64 %[a], %[c]\n\t"
-                     "s_nop 1\n\t" D_CHAIN D_WAIT
+                     "s_nop 1\n\t" D_AL D_CHAIN D_WAIT
                      : [a] "=&v"(a)
                      : [x] "v"(x), [d] "v"(d), [c] "v"(c), D_MOPS);
         return a;
@@ -235,6 +244,7 @@ struct DStep<D_NX, D_NU> {
 
 #undef D_FM_
 #undef D_HAZ
+#undef D_AL
 #undef D_C0
 #undef D_C1
 #undef D_C2

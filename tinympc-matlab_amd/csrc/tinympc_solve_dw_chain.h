@@ -22,9 +22,15 @@
 #else
 #define DW_HAZ ""
 #endif
+// (every 16-column block of the chain starts on an 8-byte boundary: tinympc_solve_d_chain.h)
+#ifdef TINY_CHAIN_NOALIGN
+#define TINY_CHAIN_AL ""
+#else
+#define TINY_CHAIN_AL ".p2align 3\n\t"
+#endif
 #define DW_FE_(i) "v_fmac_f64_dpp %[a], %[e], %[m" #i "] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n\t"
 #define DW_FO_(i, b) "v_fmac_f64_dpp %[a], %[o], %[m" #i "] row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
-#define DW_LO DW_FE_(0) DW_FE_(1) DW_FE_(2) DW_FE_(3) DW_FE_(4) DW_FE_(5) DW_FE_(6) DW_FE_(7) DW_FE_(8) DW_FE_(9) DW_FE_(10) DW_FE_(11) DW_FE_(12) DW_FE_(13) DW_FE_(14) DW_FE_(15)
+#define DW_LO TINY_CHAIN_AL DW_FE_(0) DW_FE_(1) DW_FE_(2) DW_FE_(3) DW_FE_(4) DW_FE_(5) DW_FE_(6) DW_FE_(7) DW_FE_(8) DW_FE_(9) DW_FE_(10) DW_FE_(11) DW_FE_(12) DW_FE_(13) DW_FE_(14) DW_FE_(15)
 #if DW_NXU > 16
 #define DW_H16 DW_FO_(16, 0)
 #else
@@ -105,7 +111,7 @@
 #else
 #define DW_H31 ""
 #endif
-#define DW_HI DW_H16 DW_H17 DW_H18 DW_H19 DW_H20 DW_H21 DW_H22 DW_H23 DW_H24 DW_H25 DW_H26 DW_H27 DW_H28 DW_H29 DW_H30 DW_H31
+#define DW_HI TINY_CHAIN_AL DW_H16 DW_H17 DW_H18 DW_H19 DW_H20 DW_H21 DW_H22 DW_H23 DW_H24 DW_H25 DW_H26 DW_H27 DW_H28 DW_H29 DW_H30 DW_H31
 #define DW_MLO [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]), [m6] "v"(m[6]), [m7] "v"(m[7]), [m8] "v"(m[8]), [m9] "v"(m[9]), [m10] "v"(m[10]), [m11] "v"(m[11]), [m12] "v"(m[12]), [m13] "v"(m[13]), [m14] "v"(m[14]), [m15] "v"(m[15])
 #define DW_MHI [m16] "v"(m[16]), [m17] "v"(m[17]), [m18] "v"(m[18]), [m19] "v"(m[19]), [m20] "v"(m[20]), [m21] "v"(m[21]), [m22] "v"(m[22]), [m23] "v"(m[23]), [m24] "v"(m[24]), [m25] "v"(m[25]), [m26] "v"(m[26]), [m27] "v"(m[27]), [m28] "v"(m[28]), [m29] "v"(m[29]), [m30] "v"(m[30]), [m31] "v"(m[31])
 // S1 + D1 + R1 for the element the chain just produced (admm.cpp:45-58, 67-68, 93-96); g is updated in place.
@@ -170,6 +176,7 @@ struct DWStep<DW_NX, DW_NU> {
 
 #undef DW_FE_
 #undef DW_FO_
+#undef TINY_CHAIN_AL
 #undef DW_LO
 #undef DW_HI
 #undef DW_MLO

@@ -12,6 +12,12 @@
 #error "64-lane layout D: 32 < nx + nu <= 64"
 #endif
 #define DX_NXU (DX_NX + DX_NU)
+// (every 16-column block of the chain starts on an 8-byte boundary: tinympc_solve_d_chain.h)
+#ifdef TINY_CHAIN_NOALIGN
+#define TINY_CHAIN_AL ""
+#else
+#define TINY_CHAIN_AL ".p2align 3\n\t"
+#endif
 #define DX_F_(i, b) "v_fmac_f64_dpp %[a], %[w], %[m" #i "] row_newbcast:" #b " row_mask:0xf bank_mask:0xf\n\t"
 #define DX_C0 DX_F_(0, 0)
 #define DX_C1 DX_F_(1, 1)
@@ -205,13 +211,13 @@
 #else
 #define DX_C63 ""
 #endif
-#define DX_Q0 DX_C0 DX_C1 DX_C2 DX_C3 DX_C4 DX_C5 DX_C6 DX_C7 DX_C8 DX_C9 DX_C10 DX_C11 DX_C12 DX_C13 DX_C14 DX_C15
+#define DX_Q0 TINY_CHAIN_AL DX_C0 DX_C1 DX_C2 DX_C3 DX_C4 DX_C5 DX_C6 DX_C7 DX_C8 DX_C9 DX_C10 DX_C11 DX_C12 DX_C13 DX_C14 DX_C15
 #define DX_M0 [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]), [m6] "v"(m[6]), [m7] "v"(m[7]), [m8] "v"(m[8]), [m9] "v"(m[9]), [m10] "v"(m[10]), [m11] "v"(m[11]), [m12] "v"(m[12]), [m13] "v"(m[13]), [m14] "v"(m[14]), [m15] "v"(m[15])
-#define DX_Q1 DX_C16 DX_C17 DX_C18 DX_C19 DX_C20 DX_C21 DX_C22 DX_C23 DX_C24 DX_C25 DX_C26 DX_C27 DX_C28 DX_C29 DX_C30 DX_C31
+#define DX_Q1 TINY_CHAIN_AL DX_C16 DX_C17 DX_C18 DX_C19 DX_C20 DX_C21 DX_C22 DX_C23 DX_C24 DX_C25 DX_C26 DX_C27 DX_C28 DX_C29 DX_C30 DX_C31
 #define DX_M1 [m16] "v"(m[16]), [m17] "v"(m[17]), [m18] "v"(m[18]), [m19] "v"(m[19]), [m20] "v"(m[20]), [m21] "v"(m[21]), [m22] "v"(m[22]), [m23] "v"(m[23]), [m24] "v"(m[24]), [m25] "v"(m[25]), [m26] "v"(m[26]), [m27] "v"(m[27]), [m28] "v"(m[28]), [m29] "v"(m[29]), [m30] "v"(m[30]), [m31] "v"(m[31])
-#define DX_Q2 DX_C32 DX_C33 DX_C34 DX_C35 DX_C36 DX_C37 DX_C38 DX_C39 DX_C40 DX_C41 DX_C42 DX_C43 DX_C44 DX_C45 DX_C46 DX_C47
+#define DX_Q2 TINY_CHAIN_AL DX_C32 DX_C33 DX_C34 DX_C35 DX_C36 DX_C37 DX_C38 DX_C39 DX_C40 DX_C41 DX_C42 DX_C43 DX_C44 DX_C45 DX_C46 DX_C47
 #define DX_M2 [m32] "v"(m[32]), [m33] "v"(m[33]), [m34] "v"(m[34]), [m35] "v"(m[35]), [m36] "v"(m[36]), [m37] "v"(m[37]), [m38] "v"(m[38]), [m39] "v"(m[39]), [m40] "v"(m[40]), [m41] "v"(m[41]), [m42] "v"(m[42]), [m43] "v"(m[43]), [m44] "v"(m[44]), [m45] "v"(m[45]), [m46] "v"(m[46]), [m47] "v"(m[47])
-#define DX_Q3 DX_C48 DX_C49 DX_C50 DX_C51 DX_C52 DX_C53 DX_C54 DX_C55 DX_C56 DX_C57 DX_C58 DX_C59 DX_C60 DX_C61 DX_C62 DX_C63
+#define DX_Q3 TINY_CHAIN_AL DX_C48 DX_C49 DX_C50 DX_C51 DX_C52 DX_C53 DX_C54 DX_C55 DX_C56 DX_C57 DX_C58 DX_C59 DX_C60 DX_C61 DX_C62 DX_C63
 #define DX_M3 [m48] "v"(m[48]), [m49] "v"(m[49]), [m50] "v"(m[50]), [m51] "v"(m[51]), [m52] "v"(m[52]), [m53] "v"(m[53]), [m54] "v"(m[54]), [m55] "v"(m[55]), [m56] "v"(m[56]), [m57] "v"(m[57]), [m58] "v"(m[58]), [m59] "v"(m[59]), [m60] "v"(m[60]), [m61] "v"(m[61]), [m62] "v"(m[62]), [m63] "v"(m[63])
 #define DX_PROJECT                                 \
     "v_add_f64 %[s], %[a], %[g]\n\t"               \
@@ -341,6 +347,7 @@ struct DXStep<DX_NX, DX_NU> {
 #undef DX_C61
 #undef DX_C62
 #undef DX_C63
+#undef TINY_CHAIN_AL
 #undef DX_Q0
 #undef DX_M0
 #undef DX_Q1
