@@ -34,8 +34,14 @@
 // fast (1.669 / 1.669 against 1.670 / 1.712 ms on the headline). At most one 4-byte s_nop per block.
 #ifdef TINY_CHAIN_NOALIGN  // (experiments)
 #define D_AL ""
+#define D_MOV64 "v_mov_b64"
 #else
 #define D_AL ".p2align 3\n\t"
+#ifdef TINY_CHAIN_MOV32  // (experiments)
+#define D_MOV64 "v_mov_b64"
+#else
+#define D_MOV64 "v_mov_b64_e64"
+#endif
 #endif
 #if defined(TINY_JIT) || defined(TINY_CHAIN_NOP)
 #define D_HAZ "s_nop 1\n\t" D_AL
@@ -192,7 +198,10 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_lds(double x, double d, const double (&m)[16], double cf, double lo, double hi,
                                                      double &g, double v, double &vnew, double &pri, double &dua) {
         double a, s, t;
-        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT D_WAIT
+        // (v_mov_b64 in its 8-byte encoding: with the 4-byte one this block and what the caller puts around it -- s_waitcnt, a
+        // hazard s_nop, the slot's LDS write and the next step's two reads -- come to 4 bytes more than a multiple of 8, every
+        // second LDS step's chain would straddle the 8-byte grid and D_AL would pad each of them with an s_nop)
+        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT D_WAIT
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), D_MOPS);
         return a;
@@ -245,6 +254,7 @@ struct DStep<D_NX, D_NU> {
 #undef D_FM_
 #undef D_HAZ
 #undef D_AL
+#undef D_MOV64
 #undef D_C0
 #undef D_C1
 #undef D_C2
