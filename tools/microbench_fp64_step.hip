@@ -64,6 +64,30 @@ KERNEL(k_02, CHAIN(A0, A2) TAIL(A0) CHAIN(A2, A0) TAIL(A2))  // banks 0 / 2
 KERNEL(k_22, CHAIN(A2, B2) TAIL(A2) CHAIN(B2, A2) TAIL(B2))  // banks 2 / 2
 KERNEL(k_chain, CHAIN(A0, A2) "s_nop 1\n\t" CHAIN(A2, A0) "s_nop 1\n\t")  // chains alone (the s_nop: DPP hazard)
 KERNEL(k_mixed, MIXED(A0, A2) MIXED(A2, A0))                // row-local block of step q inside the chain of step q+1
+// the same stream 4 bytes off the 8-byte grid (every instruction of the body is 8 bytes long: one 4-byte s_nop in front of the
+// loop decides for all of them) -- what the two speeds of the layout-D kernels' builds came from (tinympc_solve_d_chain.h, D_AL)
+#define KERNEL_OFF(NAME, BODY)                                                                                   \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long *out, int iters) {                            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();       \
+        for (int i = 0; i < iters; ++i) asm volatile(".p2align 3\n\ts_nop 0\n\t" R16(BODY)::: CLOB);            \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();       \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                                               \
+            out[0] = t1 - t0;                                                                                    \
+            out[1] = r1 - r0;                                                                                    \
+        }                                                                                                        \
+    }
+#define KERNEL_ON(NAME, BODY)                                                                                    \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long *out, int iters) {                            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();       \
+        for (int i = 0; i < iters; ++i) asm volatile(".p2align 3\n\t" R16(BODY)::: CLOB);                        \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();       \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                                               \
+            out[0] = t1 - t0;                                                                                    \
+            out[1] = r1 - r0;                                                                                    \
+        }                                                                                                        \
+    }
+KERNEL_ON(k_on_grid, CHAIN(A0, A2) TAIL(A0) CHAIN(A2, A0) TAIL(A2))
+KERNEL_OFF(k_off_grid, CHAIN(A0, A2) TAIL(A0) CHAIN(A2, A0) TAIL(A2))
 
 typedef void (*kern_t)(unsigned long long *, int);
 int main() {
@@ -72,7 +96,8 @@ int main() {
     const int iters = 2000;
     struct { const char *name; kern_t f; int valu; } ks[] = {
         {"chain + block, acc bank 0, x bank 0", k_00, 48}, {"chain + block, acc bank 0, x bank 2", k_02, 48}, {"chain + block, acc bank 2, x bank 2", k_22, 48},
-        {"chains alone", k_chain, 32}, {"block of step q inside chain q+1", k_mixed, 48}};
+        {"chains alone", k_chain, 32}, {"block of step q inside chain q+1", k_mixed, 48},
+        {"chain + block, on the 8-byte grid", k_on_grid, 48}, {"chain + block, 4 bytes off the grid", k_off_grid, 48}};
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
