@@ -55,9 +55,17 @@ def parse_args():
     ap.add_argument("--sync-steps", action="store_true", help="wait for every timed step before launching the next (default: the K steps are queued and waited for once)")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the 65,536-instance single-GPU leg")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default=os.environ.get("TINYMPC_BENCH_DIST_BACKEND", "nccl"),
+                    help="process-group backend of the N > 1 run: nccl (= RCCL over xGMI, one GPU per rank; the default and what the driver "
+                         "runs) or gloo (host-side collectives: the only backend that lets several ranks share one device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank solves on device 0 (rehearsal of the N > 1 path on a one-GPU box; needs --dist-backend gloo: "
+                         "RCCL refuses two ranks on one device)")
+    ap.add_argument("--devices", default="", help="comma-separated device index per rank (default: LOCAL_RANK; --share-device = all 0)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--worker-index", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-rocket", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-latency", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -121,6 +129,40 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
         solver.solve()
         total += solver.stats()["iter"]
     print(total, time.perf_counter() - t0, flush=True)
+    return 0
+
+
+def cpu_worker_latency(seconds: float) -> int:
+    """The reference's own core (oracle/_ref) on ONE host core in the reference's own usage, beside the GPU's latency legs:
+    (a) BASELINE configs 1/2, cartpole N=20 with input bounds, 200 forced iterations (examples/cartpole_example_one_solve.m:13-31);
+    (b) the closed loop of bench.py's `closed_loop_tick` leg -- quadrotor N=50, tol 1e-3, max_iter 100, warm start, 20 untimed + 200
+        timed ticks of set_x0 -> solve -> first control (examples/cartpole_example_mpc.m:36-44), the loop itself in compiled code
+        (oracle/ref_shim.cpp: ref_bench_closed_loop) so that no Python call sits inside a tick.
+    Prints one JSON object. Never touches the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, ROOT)
+    import pyoracle as O  # checker / baseline only
+    import __graft_entry__ as ge
+
+    if not O.ref_available():
+        print(json.dumps({}), flush=True)
+        return 0
+    P = ge.load_package().problems
+    cp = P.cartpole(20, True)
+    s = O.OracleRef(cp).load_problem(cp, dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200, check_termination=1))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        n += s.bench_solves(cp.x0.reshape(-1, 1), 20)
+    cart_us = 1e6 * (time.perf_counter() - t0) / n
+    prob = P.quadrotor(50)
+    s = O.OracleRef(prob).load_problem(prob, dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1))
+    runs = []
+    for _ in range(5):  # (each run starts from the state the last one left: warm, like the GPU leg's handle)
+        s.reset_workspace()
+        its, sec, _x = s.bench_closed_loop(prob.x0, 220, 20)
+        runs.append((sec, its))
+    sec, its = sorted(runs)[len(runs) // 2]
+    print(json.dumps({"cartpole_us_per_iter": cart_us, "closed_loop_us_per_tick": 1e6 * sec / 200, "closed_loop_iterations_per_tick": its / 200}), flush=True)
     return 0
 
 
@@ -265,7 +307,17 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.split()
     rocket_us = 1e6 * float(rocket[-1]) / int(rocket[-2]) if len(rocket) >= 2 and int(rocket[-2]) > 0 else None
-    return {"value": value, "rocket_us_per_iter_single_process": rocket_us, "unit": "ADMM iters/s", "cores": len(rates),
+    lat = {}
+    try:
+        lat = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-latency", "--cpu-seconds", "1"],
+                                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        pass
+    return {"value": value, "rocket_us_per_iter_single_process": rocket_us,
+            "cartpole_us_per_iter_single_process": lat.get("cartpole_us_per_iter"),
+            "closed_loop_us_per_tick_single_process": lat.get("closed_loop_us_per_tick"),
+            "closed_loop_iterations_per_tick": lat.get("closed_loop_iterations_per_tick"),
+            "unit": "ADMM iters/s", "cores": len(rates),
             "effective_parallelism": eff, "affinity_cpus": len(cpus), "cgroup_quota": quota, "cgroup_quota_source": quota_src,
             "cores_logical": os.cpu_count(), "cores_physical": physical, "kind": kind,
             "sample": f"{total // iters} cold-started {iters}-iteration quadrotor N={horizon} solves, {len(rates)} single-threaded "
@@ -282,6 +334,8 @@ def main() -> int:
         return cpu_worker(args.cpu_seconds, args.iters, args.horizon, args.worker_index)
     if args.cpu_worker_rocket:
         return cpu_worker_rocket(args.cpu_seconds, args.iters)
+    if args.cpu_worker_latency:
+        return cpu_worker_latency(args.cpu_seconds)
     rccl_environment()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
@@ -306,13 +360,35 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the HIP path has no CPU fallback", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # Under torchrun (RANK / MASTER_ADDR set) the RCCL group is created even for a single rank, so that the
+    # Which device this rank solves on: its LOCAL_RANK (one GPU per rank, what the driver launches), or what --devices /
+    # --share-device say (several ranks on one GPU: the N > 1 path rehearsed on a one-GPU box, collectives over gloo).
+    if args.devices:
+        dev_of_rank = [int(d) for d in args.devices.split(",")]
+        if len(dev_of_rank) != world:
+            print("bench.py: --devices names %d devices for %d ranks" % (len(dev_of_rank), world), file=sys.stderr)
+            return 2
+        dev_index = dev_of_rank[rank]
+    else:
+        dev_index = 0 if args.share_device else local_rank
+    shared = world > 1 and (args.share_device or (args.devices and len(set(dev_of_rank)) < world))
+    if shared and args.dist_backend == "nccl":
+        print("bench.py: several ranks on one device need --dist-backend gloo (RCCL refuses duplicate devices)", file=sys.stderr)
+        return 2
+    if dev_index < 0 or dev_index >= torch.cuda.device_count():
+        print("bench.py: rank %d: device %d does not exist (%d visible)" % (rank, dev_index, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # Under torchrun (RANK / MASTER_ADDR set) the process group is created even for a single rank, so that the
     # collective path can be exercised on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 1 bench.py`.
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    # the collectives' tensors live where the backend works: HBM for RCCL, host memory for gloo
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     prob = P.quadrotor(args.horizon)
     total_instances, first, count, scaling = pkg.batch.job_shard(rank, world, args.batch_per_gpu, args.global_batch)
@@ -322,7 +398,7 @@ def main() -> int:
     x0_dev = torch.from_numpy(np.ascontiguousarray(x0_host.T)).to(dev)  # [count][nx] == nx x count column-major
 
     solver = pkg.TinyMPC()
-    solver.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=count, device=local_rank, rho=prob.rho,
+    solver.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=count, device=dev_index, rho=prob.rho,
                  abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
     solver.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     solver.set_x0_batch(x0_dev)  # device-to-device: inputs are HBM-resident before the timed region
@@ -338,53 +414,79 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Settle: this process has just spent ~30 s on the CPU baseline with the GPU idle, and the first launches after that run at a
-    # lower shader clock -- 1.81 ms per launch in the first 25, 1.72 from about the 50th on (in-kernel stamps: tools/clock_check.py).
-    # W = 5 warm-up steps end inside that ramp, so the step is repeated, untimed, until 0.4 s have passed; what the ramp looked
-    # like is reported (`settle`: kernel time of the first and of the last ten launches).
+    def timed_steps():
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides. The K steps are QUEUED
+        (tinympc_solve_queued: each records its own event pair around the solve kernel) and waited for once, behind the last one --
+        the way a throughput job runs them; a host round trip per step left the GPU idle for ~15 us between a step's end and the
+        next step's launch (1.694 against 1.67 ms per step). `--sync-steps` times them one by one. Returns (seconds, kernel ms)."""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        if args.sync_steps:
+            kms = [step() for _ in range(args.steps)]
+        else:
+            for _ in range(args.steps):
+                solver.reset_workspace()  # cold start: every step does identical work (stream-ordered in front of the launch)
+                solver.solve_queued()
+            kms = solver.collect_kernel_ms()  # (waits for the stream)
+            assert len(kms) == args.steps
+        barrier()
+        return time.perf_counter() - t0, kms
+
+    # (1) AS ASKED: exactly the driver's W warm-up steps, then the K timed steps. This process has just spent ~30 s on the CPU
+    # baseline with the GPU idle, and the first launches after that run at a lower shader clock (2.0 ms per launch in the first
+    # ten, 1.67 from about the 50th on; in-kernel stamps: tools/clock_check.py), so W = 5 ends inside that ramp.
+    # (2) SETTLED: the step is repeated, untimed, until 0.4 s have passed, then W warm-up + K timed steps again -- the
+    # steady state a throughput job lives in. `value` is (2); (1) is printed beside it as `value_as_asked`; `--no-settle` runs (1)
+    # only and makes it `value`. What the ramp looked like is reported (`settle`: kernel time of the first and last ten launches).
+    elapsed_asked, kernel_ms_asked = timed_steps()
     settle = {"launches": 0, "seconds": 0.0}
-    if not args.no_settle:
+    if args.no_settle:
+        elapsed, kernel_ms = elapsed_asked, kernel_ms_asked
+    else:
         ts0 = time.perf_counter()
         sms = []
         while time.perf_counter() - ts0 < 0.4 and len(sms) < 600:
             sms.append(step())
         settle = {"launches": len(sms), "seconds": time.perf_counter() - ts0, "first_launches_kernel_ms": float(np.mean(sms[:10])),
                   "last_launches_kernel_ms": float(np.mean(sms[-10:]))}
-    for _ in range(args.warmup):
-        step()
-    # The K timed steps are QUEUED (tinympc_solve_queued: each records its own event pair around the solve kernel) and waited
-    # for once, behind the last one -- the way a throughput job runs them; a host round trip per step left the GPU idle for
-    # ~15 us between a step's end and the next step's launch (1.694 against 1.67 ms per step). `--sync-steps` times them one by one.
-    barrier()
-    t0 = time.perf_counter()
-    if args.sync_steps:
-        kernel_ms = [step() for _ in range(args.steps)]
-    else:
-        for _ in range(args.steps):
-            solver.reset_workspace()  # cold start: every step does identical work (stream-ordered in front of the launch)
-            solver.solve_queued()
-        kernel_ms = solver.collect_kernel_ms()  # (waits for the stream)
-        assert len(kernel_ms) == args.steps
-    barrier()
-    elapsed = time.perf_counter() - t0
+        elapsed, kernel_ms = timed_steps()
 
-    t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
+    # MAX over ranks of the elapsed times (the contract), every rank's own numbers beside it so that a straggler shows, and a
+    # fingerprint of what each rank computed: its first controls u[:, 0] (the first four instances verbatim + a SHA-256 over the
+    # whole shard) -- sharding must change nothing, bit for bit, and tests/test_multirank_gpu.py checks exactly that.
+    import hashlib
+    u0_mine = np.ascontiguousarray(solver.get_first_controls_batch().T)  # [count][nu]
+    st = solver.get_stats_batch()
+    t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1), elapsed_asked, sum(kernel_ms_asked) / max(len(kernel_ms_asked), 1)],
+                     dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    # every rank's own numbers, so that a straggler shows (the headline uses the MAX, as the contract asks)
-    mine = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1), float(count), float(first)], dtype=torch.float64, device=dev)
+    digest = np.frombuffer(hashlib.sha256(u0_mine.tobytes()).digest(), dtype=np.uint8).astype(np.float64)  # 32 bytes as doubles
+    npre = min(4, count)
+    prefix = np.zeros(4 * prob.nu)
+    prefix[:npre * prob.nu] = u0_mine[:npre].ravel()
+    mine = torch.tensor(np.concatenate([[elapsed, sum(kernel_ms) / max(len(kernel_ms), 1), float(count), float(first), float(dev_index),
+                                         float(np.sum(st["iter"])), float(npre)], prefix, digest]), dtype=torch.float64, device=cdev)
     if use_dist:
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
     else:
         gathered = [mine]
-    per_rank = [{"rank": i, "elapsed_s": float(g[0]), "kernel_ms_avg": float(g[1]), "instances": int(g[2]), "first_instance": int(g[3]),
-                 "iters_per_s": float(g[2]) * args.iters * args.steps / float(g[0])} for i, g in enumerate(gathered)]
-    elapsed, kernel_ms_avg = float(t[0]), float(t[1])
+    per_rank = []
+    for i, g in enumerate(gathered):
+        g = g.cpu().numpy()
+        k = int(g[6])
+        per_rank.append({"rank": i, "device": int(g[4]), "elapsed_s": float(g[0]), "kernel_ms_avg": float(g[1]), "instances": int(g[2]),
+                         "first_instance": int(g[3]), "iters_per_s": float(g[2]) * args.iters * args.steps / float(g[0]),
+                         "total_iterations": int(g[5]),
+                         "first_controls_prefix": g[7:7 + k * prob.nu].reshape(k, prob.nu).tolist(),
+                         "first_controls_sha256": bytes(g[7 + 4 * prob.nu:7 + 4 * prob.nu + 32].astype(np.uint8)).hex()})
+    elapsed, kernel_ms_avg, elapsed_asked, kernel_ms_asked_avg = (float(v) for v in t.cpu())
 
     # after the timed region: the one collective of the batched mode (summary statistics)
-    st = solver.get_stats_batch()
-    summary = pkg.batch.allreduce_summary(pkg.batch.local_summary(st["iter"], st["status"], st["residuals"]), device=dev)
+    summary = pkg.batch.allreduce_summary(pkg.batch.local_summary(st["iter"], st["status"], st["residuals"]), device=cdev)
 
     inst_iters_per_step = total_instances * args.iters
     value = inst_iters_per_step * args.steps / elapsed
@@ -423,7 +525,8 @@ def main() -> int:
                     tj = json.load(f)
                 if tj.get("batch_per_gpu") == B and tj.get("iters") == args.iters and tj.get("horizon") == args.horizon:
                     if tj.get("library_hash") == library_hash():
-                        traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "PMC, " + str(tj.get("source"))
+                        traffic, traffic_note = tj.get("hbm_bytes_per_launch"), ("builder-side PMC on matching sources (library hash %s), not this run: %s"
+                                                                                 % (library_hash(), tj.get("source")))
                     else:
                         traffic_note = "dropped: %s was collected on other kernel sources (%s, now %s)" % (
                             tj.get("source"), tj.get("library_hash"), library_hash())
@@ -433,6 +536,10 @@ def main() -> int:
         out = {
             "metric": "ADMM iterations/s, batched quadrotor nx=12 nu=4 N=%d (instance-iterations/s, whole job)" % prob.N,
             "value": value, "unit": "ADMM iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value_as_asked": inst_iters_per_step * args.steps / elapsed_asked, "ms_per_step_as_asked": 1e3 * elapsed_asked / args.steps,
+            "value_note": ("value = value_as_asked: --no-settle" if args.no_settle else
+                           "value: W warm-up + K timed steps after 0.4 s of untimed repetitions (steady-state clock); value_as_asked: the W warm-up + "
+                           "K timed steps run first, right behind the CPU baseline's ~30 s of GPU idling (clock still ramping up)"),
             "ms_per_step": 1e3 * elapsed / args.steps, "steps_queued": not args.sync_steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "vs_baseline_note": "BASELINE.md section 1: the reference publishes no number for this metric",
             "dtype": "f64", "data": "synthetic",
@@ -446,6 +553,8 @@ def main() -> int:
                                         "CPU baseline and its first launches run at a lower clock; first / last = mean kernel time of the first / last ten"),
             "roofline": {"bound": "fp64_vector", "achieved": achieved_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac_as_asked": alg_flops_per_launch / (kernel_ms_asked_avg * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                         "kernel_ms_avg_as_asked": kernel_ms_asked_avg, "value_as_asked": inst_iters_per_step * args.steps / elapsed_asked,
                          "kernel": kname + "<%d lanes/instance>" % info["lanes_per_instance"], "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_flops_per_instance_iteration": flops_iter,
                          "algorithmic_flops_per_launch": alg_flops_per_launch,
@@ -459,7 +568,12 @@ def main() -> int:
                                                      "from HBM (on-chip), so this roof does not bind"},
                          "hbm_measured_frac_of_peak": (traffic / kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None},
             "parity_check": parity,
-            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if use_dist else None),
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "ranks_per_device": ("%d ranks share device(s) %s (rehearsal of the N > 1 path on fewer GPUs than ranks: the rates are "
+                                                    "not a scaling measurement)" % (world, sorted({p_["device"] for p_ in per_rank}))
+                                                    if len({p_["device"] for p_ in per_rank}) < world else 1)} if use_dist else None),
+            "legs_run_on": ("rank 0 of a single-rank job only: with n_gpus > 1 the line carries the headline, per_rank, summary and parity_check; "
+                            "cpu_baseline, config5_single_gpu, converging_batch and every latency / shape leg are skipped on every rank"),
             "per_rank": per_rank,
             "launch": info,
             "summary": summary,
@@ -468,7 +582,7 @@ def main() -> int:
             # BASELINE config 5 on ONE GPU: all 65,536 instances in one launch (8 waves per CU x 8 rounds)
             nb = 65536
             big = pkg.TinyMPC()
-            big.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=local_rank, rho=prob.rho,
+            big.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=dev_index, rho=prob.rho,
                       abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
             big.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
             big.set_x0_batch(torch.from_numpy(np.ascontiguousarray(P.quadrotor_batch_x0(nb).T)).to(dev))
@@ -503,7 +617,7 @@ def main() -> int:
                 else:
                     os.environ["TINYMPC_REFILL"] = mode
                 cb = pkg.TinyMPC()
-                cb.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=local_rank, rho=prob.rho,
+                cb.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=dev_index, rho=prob.rho,
                          abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=args.iters, check_termination=1)
                 cb.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
                 cb.set_x0_batch(torch.from_numpy(x0c).to(dev))
@@ -523,9 +637,9 @@ def main() -> int:
                                        "fraction_of_forced_iteration_rate": d["instance_iterations"] / (d["kernel_ms"] * 1e-3) / forced_rate,
                                        "plain_kernel_ms": conv["plain"]["kernel_ms"],
                                        "same_iteration_total": conv["plain"]["instance_iterations"] == d["instance_iterations"]}
-        if not args.no_single:
+        if world == 1 and not args.no_single:
             one = pkg.TinyMPC()
-            one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho,
+            one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho,
                       abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
             one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
             one.set_x0(prob.x0)
@@ -542,7 +656,7 @@ def main() -> int:
             # BASELINE config 4: one rocket-landing instance, N=100, second-order cones + a linear row + fdyn
             rk = P.rocket(100)
             one = pkg.TinyMPC()
-            one.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=local_rank, rho=rk.rho, fdyn=rk.fdyn,
+            one.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=dev_index, rho=rk.rho, fdyn=rk.fdyn,
                       abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
             one.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
             if rk.x_ref is not None:
@@ -570,7 +684,7 @@ def main() -> int:
                 rkb = P.rocket(rN)
                 rB, rit = 4096, 100
                 many = pkg.TinyMPC()
-                many.setup(rkb.A, rkb.B, rkb.Q, rkb.R, rkb.N, batch=rB, device=local_rank, rho=rkb.rho, fdyn=rkb.fdyn,
+                many.setup(rkb.A, rkb.B, rkb.Q, rkb.R, rkb.N, batch=rB, device=dev_index, rho=rkb.rho, fdyn=rkb.fdyn,
                            abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=rit, check_termination=1)
                 many.set_bound_constraints(rkb.x_min, rkb.x_max, rkb.u_min, rkb.u_max)
                 many.set_x_ref(rkb.x_ref)
@@ -591,7 +705,7 @@ def main() -> int:
             # Adaptive rho (admm.cpp:117-174) on a batch: rho, its operator rows and pNref per instance, layout D's ADAPT variant
             ad = pkg.TinyMPC()
             aB, ait = 8192, 100
-            ad.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=aB, device=local_rank, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0,
+            ad.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=aB, device=dev_index, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0,
                      max_iter=ait, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0)
             ad.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
             ad.set_sensitivity_matrices(*ad.compute_sensitivity_autograd())
@@ -607,7 +721,7 @@ def main() -> int:
                                          "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))],
                                          **leg_counters("adaptive_rho_batch", aB * ait / (med * 1e-3))}
             ad.reset()
-        if not args.no_single:
+        if world == 1 and not args.no_single:
             # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
             # cross-row swaps + fused DPP chain. Synthetic stable system, box constraints, 100 forced iterations.
             rng = np.random.default_rng(0)
@@ -616,7 +730,7 @@ def main() -> int:
             wBm = 0.1 * rng.standard_normal((wnx, wnu))
             wp = P.Problem("wide", wA, wBm, np.diag(rng.uniform(1, 10, wnx)), np.diag(rng.uniform(0.5, 2, wnu)), wN, 2.0, rng.standard_normal(wnx))
             wide = pkg.TinyMPC()
-            wide.setup(wp.A, wp.B, wp.Q, wp.R, wp.N, batch=wB, device=local_rank, rho=wp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=wit)
+            wide.setup(wp.A, wp.B, wp.Q, wp.R, wp.N, batch=wB, device=dev_index, rho=wp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=wit)
             wide.set_bound_constraints(np.full(wnx, -2.0), np.full(wnx, 2.0), np.full(wnu, -0.3), np.full(wnu, 0.3))
             wide.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((wnx, wB))))
             ms = []
@@ -635,7 +749,7 @@ def main() -> int:
             hp = P.quadrotor(100)
             hB, hit = 8192, 100
             longh = pkg.TinyMPC()
-            longh.setup(hp.A, hp.B, hp.Q, hp.R, hp.N, batch=hB, device=local_rank, rho=hp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=hit)
+            longh.setup(hp.A, hp.B, hp.Q, hp.R, hp.N, batch=hB, device=dev_index, rho=hp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=hit)
             longh.set_bound_constraints(hp.x_min, hp.x_max, hp.u_min, hp.u_max)
             longh.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(hB)))
             ms = []
@@ -657,7 +771,7 @@ def main() -> int:
             lBm = 0.08 * rng.standard_normal((lnx, lnu))
             lp = P.Problem("large", lA, lBm, np.diag(rng.uniform(1, 10, lnx)), np.diag(rng.uniform(0.5, 2, lnu)), lN, 2.0, rng.standard_normal(lnx))
             big = pkg.TinyMPC()
-            big.setup(lp.A, lp.B, lp.Q, lp.R, lp.N, batch=lB, device=local_rank, rho=lp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=lit)
+            big.setup(lp.A, lp.B, lp.Q, lp.R, lp.N, batch=lB, device=dev_index, rho=lp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=lit)
             big.set_bound_constraints(np.full(lnx, -2.0), np.full(lnx, 2.0), np.full(lnu, -0.3), np.full(lnu, 0.3))
             big.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((lnx, lB))))
             ms = []
@@ -686,7 +800,7 @@ def main() -> int:
             vp = P.Problem("very_large", vA, 0.08 * rng.standard_normal((vnx, vnu)), np.diag(rng.uniform(1, 10, vnx)), np.diag(rng.uniform(0.5, 2, vnu)), vN, 2.0,
                            rng.standard_normal(vnx))
             vbig = pkg.TinyMPC()
-            vbig.setup(vp.A, vp.B, vp.Q, vp.R, vp.N, batch=vB, device=local_rank, rho=vp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=vit)
+            vbig.setup(vp.A, vp.B, vp.Q, vp.R, vp.N, batch=vB, device=dev_index, rho=vp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=vit)
             vbig.set_bound_constraints(np.full(vnx, -2.0), np.full(vnx, 2.0), np.full(vnu, -0.3), np.full(vnu, 0.3))
             vbig.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((vnx, vB))))
             ms = []
@@ -706,7 +820,7 @@ def main() -> int:
             cart = {}
             for cB in (1, 8192):
                 cs = pkg.TinyMPC()
-                cs.setup(cp.A, cp.B, cp.Q, cp.R, cp.N, batch=cB, device=local_rank, rho=cp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200)
+                cs.setup(cp.A, cp.B, cp.Q, cp.R, cp.N, batch=cB, device=dev_index, rho=cp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200)
                 cs.set_bound_constraints(cp.x_min, cp.x_max, cp.u_min, cp.u_max)
                 if cB == 1:
                     cs.set_x0(cp.x0)
@@ -719,6 +833,7 @@ def main() -> int:
                 med = sorted(ms[1:])[2]
                 key = "one_instance" if cB == 1 else "batch_8192"
                 cart[key] = {"kernel_ms": med, "iters_per_s": cB * 200 / (med * 1e-3), "us_per_iter": 1e3 * med / 200 if cB == 1 else None,
+                             **({"cpu_reference_us_per_iter": cpu.get("cartpole_us_per_iter_single_process") if cpu else None} if cB == 1 else {}),
                              "layout": cs.launch_info()["layout"], "fp64_frac": cB * 200 * cp.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
                 cs.reset()
             out["cartpole"] = dict(workload="BASELINE config 1: cartpole nx=4 nu=1 N=20, box input constraints, 200 forced iterations", **cart)
@@ -731,7 +846,7 @@ def main() -> int:
             tick = {}
             for mode in ("launch", "session"):
                 tk = pkg.TinyMPC()
-                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=local_rank, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
                 tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
                 if mode == "session":
                     tk.session_begin()
@@ -762,10 +877,44 @@ def main() -> int:
                 if slow:
                     tick[mode]["ticks_above_1ms"] = slow
                 tk.reset()
+            tick["cpu_reference_us_per_tick"] = cpu.get("closed_loop_us_per_tick_single_process") if cpu else None
+            tick["cpu_reference_iterations_per_tick"] = cpu.get("closed_loop_iterations_per_tick") if cpu else None
+            tick["cpu_reference_note"] = ("the reference's own core (oracle/_ref) on one host core: set_x0 + solve + first control per tick, the loop in "
+                                          "compiled code; no MATLAB / MEX overhead on its side, the Python mirror's ctypes calls on the GPU's side")
             out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
+        # One headline number per leg, flat: copied into `roofline` as scalars (the driver's record keeps the scalars of the
+        # objects it knows and only the NAMES of other keys) and printed as the LAST key of the line (its record keeps the tail).
+        def leg(path, scale=1.0):
+            d = out
+            for k in path.split("/"):
+                d = d.get(k) if isinstance(d, dict) else None
+                if d is None:
+                    return None
+            return d * scale if isinstance(d, (int, float)) else None
+        legs = {"value_as_asked": out["value_as_asked"],
+                "config5_single_gpu_iters_per_s": leg("config5_single_gpu/value"), "config5_single_gpu_fp64_frac": leg("config5_single_gpu/fp64_frac"),
+                "converging_batch_kernel_ms": leg("converging_batch/kernel_ms"), "converging_batch_plain_kernel_ms": leg("converging_batch/plain_kernel_ms"),
+                "converging_batch_fraction_of_forced_rate": leg("converging_batch/fraction_of_forced_iteration_rate"),
+                "single_instance_us_per_iter": leg("single_instance/us_per_iter"), "single_instance_cpu_reference_us_per_iter": leg("cpu_baseline/us_per_iter_single_process"),
+                "rocket_instance_us_per_iter": leg("rocket_instance/us_per_iter"), "rocket_instance_cpu_port_us_per_iter": leg("cpu_baseline/rocket_us_per_iter_single_process"),
+                "rocket_batch_N100_iters_per_s": leg("rocket_batch/N=100/iters_per_s"), "rocket_batch_N100_fp64_frac": leg("rocket_batch/N=100/fp64_frac"),
+                "rocket_batch_N10_iters_per_s": leg("rocket_batch/N=10/iters_per_s"),
+                "adaptive_rho_batch_iters_per_s": leg("adaptive_rho_batch/iters_per_s"), "adaptive_rho_batch_fp64_frac_box_part": leg("adaptive_rho_batch/fp64_frac_box_part"),
+                "wide_system_fp64_frac": leg("wide_system/fp64_frac"), "long_horizon_fp64_frac": leg("long_horizon/fp64_frac"),
+                "large_system_fp64_frac": leg("large_system/fp64_frac"), "large_system_hbm_measured_frac": leg("large_system/hbm_measured_frac"),
+                "very_large_system_fp64_frac": leg("very_large_system/fp64_frac"),
+                "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),
+                "cartpole_batch_8192_iters_per_s": leg("cartpole/batch_8192/iters_per_s"), "cartpole_batch_8192_fp64_frac": leg("cartpole/batch_8192/fp64_frac"),
+                "closed_loop_tick_launch_us": leg("closed_loop_tick/launch/us_per_tick_median"), "closed_loop_tick_session_us": leg("closed_loop_tick/session/us_per_tick_median"),
+                "closed_loop_tick_cpu_reference_us": leg("cpu_baseline/closed_loop_us_per_tick_single_process")}
+        legs = {k: v for k, v in legs.items() if v is not None}
+        for k, v in legs.items():
+            if k != "value_as_asked":
+                out["roofline"]["leg_" + k] = v
+        out["legs"] = legs
         print(json.dumps(out), flush=True)
     solver.reset()
     if parity is not None and not parity["ok"]:

@@ -15,8 +15,15 @@
  *    outputs are written into caller-allocated buffers.
  *  - Every function returns TINYMPC_OK (0) or a negative TINYMPC_ERR_* code; the message is
  *    available from tinympc_last_error() (thread-local). Nothing throws or long-jumps.
- *  - A handle is externally synchronised (one caller at a time), owns one HIP stream and all its
- *    device buffers, and is bound to one GPU. tinympc_solve is synchronous.
+ *  - Threading: a handle is externally synchronised -- one caller at a time per handle; DIFFERENT handles may be driven
+ *    from different threads concurrently (one handle per thread, or one per GPU, is the intended use). The library keeps
+ *    no other shared mutable state than (a) the run-time specialiser's kernel cache and (b) the registry of open closed-loop
+ *    sessions, both behind their own mutexes. The one place where a call reaches into a handle it was not given --
+ *    tinympc_setup / tinympc_setup_batch / tinympc_reset sending the resident session kernels of OTHER handles on the same
+ *    device home before they allocate or free device memory -- takes that handle's session mutex, which
+ *    tinympc_session_step holds for the duration of a tick: a tick in flight on another thread completes undisturbed, and
+ *    its handle cannot be destroyed under the walk (it leaves the registry first).
+ *  - A handle owns one HIP stream and all its device buffers, and is bound to one GPU. tinympc_solve is synchronous.
  *  - There is NO CPU fallback: without a GPU / without the gfx950 code object every compute verb
  *    fails with TINYMPC_ERR_NO_DEVICE or TINYMPC_ERR_HIP.
  */
@@ -226,7 +233,10 @@ int tinympc_get_first_controls_batch(tinympc_solver *s, double *u0_out, int firs
 int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *residuals, int first,
                             int count);
 /* Device pointers of the solution buffers (nx*N*batch and nu*(N-1)*batch doubles), valid until
- * tinympc_reset; lets a caller consume results without a D2H copy. */
+ * tinympc_reset; lets a caller consume results without a D2H copy. The pointers are stable for the handle's lifetime and
+ * need not be queried again after tinympc_reset_workspace: once they have been handed out, a reset zeroes the buffers on
+ * the handle's stream itself (before, it only marks them zero and lets the next solve overwrite them). Reads must be
+ * ordered behind the handle's stream (tinympc_get_stream) or a synchronous verb. */
 int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, const double **d_u);
 
 /* Closed-loop SESSION (single-instance handles): the reference's control loops call set_x0 -> solve -> get_solution
@@ -266,8 +276,11 @@ int tinympc_solve_timed(tinympc_solver *s, float *kernel_ms);
 /* Throughput form of the timed solve: queue the launch on the handle's stream and return at once; every queued launch records its
  * own HIP event pair around the solve kernel. tinympc_collect_kernel_ms waits for the stream and returns the kernel durations of
  * the launches queued since the last collect, in order (*count; an error if they exceed `capacity`, at most 4,096). Between two
- * queued solves the caller may queue tinympc_reset_workspace / tinympc_set_x0_batch_device as usual -- they run on the same stream,
- * in order; host readers (get_solution ...) synchronise as always. Batched handles outside a session only. */
+ * queued solves the caller may queue tinympc_reset_workspace (stream-ordered, returns at once). tinympc_set_x0_batch_device is
+ * correct there too but NOT asynchronous: it waits for the handle's stream -- i.e. for every launch queued so far -- before it
+ * returns, because the caller may free or reuse d_x0s as soon as it does; a pipeline that wants new x0 per queued solve
+ * without draining the queue keeps them in one device array and switches by offset before queueing. Host readers
+ * (get_solution ...) synchronise as always. Batched handles outside a session only. */
 int tinympc_solve_queued(tinympc_solver *s);
 int tinympc_collect_kernel_ms(tinympc_solver *s, float *kernel_ms, int capacity, int *count);
 

@@ -311,6 +311,9 @@ class OracleRef(_Base):
         L.ref_get_stats.argtypes = [C.c_void_p, _ip, _dp]
         L.ref_bench_solves.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int]
         L.ref_bench_solves.restype = C.c_long
+        if hasattr(L, "ref_bench_closed_loop"):
+            L.ref_bench_closed_loop.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
+            L.ref_bench_closed_loop.restype = C.c_long
         if hasattr(L, "ref_codegen"):
             L.ref_codegen.argtypes = [C.c_void_p, C.c_char_p]
             L.ref_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -407,3 +410,10 @@ class OracleRef(_Base):
     def bench_solves(self, x0s, reps: int) -> int:
         a = _f(x0s)
         return int(self.L.ref_bench_solves(self.h, _p(a), a.shape[1], reps))
+
+    def bench_closed_loop(self, x0, ticks: int, skip: int = 0):
+        """`ticks` warm-started ticks x+ = A x + B u0 inside the compiled shim; returns (iterations, seconds) of the timed ones."""
+        a = _f(np.asarray(x0, dtype=np.float64).reshape(-1, 1).copy())
+        sec = C.c_double(0.0)
+        its = int(self.L.ref_bench_closed_loop(self.h, _p(a), int(ticks), int(skip), C.byref(sec)))
+        return its, float(sec.value), a.ravel()

@@ -16,6 +16,7 @@
 // The output (oracle/_ref/libtinympc_ref.so) is git-ignored and travels to the GPU box as a
 // prebuilt binary only.
 #include <cstring>
+#include <ctime>
 #include <iostream>
 #include <mutex>
 #include <sstream>
@@ -276,6 +277,36 @@ long ref_bench_solves(void *h, const double *x0s, int count, int reps) {
     }
     (void)nu;
     (void)N;
+    return iters;
+}
+
+// CPU-baseline helper for bench.py's closed-loop leg (the reference's own usage, examples/cartpole_example_mpc.m:36-44:
+// set_x0 -> solve -> first control -> simulate one step): `ticks` warm-started ticks of x+ = A x + B u0 on one thread,
+// the first `skip` of them untimed. Only the three core calls of a tick are inside the timed region (what the MEX verbs
+// set_x0 / solve / get_solution reach, bindings.cpp:107-131, 212-261); the plant step is outside it. Returns the total
+// ADMM iterations of the timed ticks; *seconds receives the timed seconds, x0 is overwritten with the final state.
+long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *seconds) {
+    TinySolver *s = static_cast<TinySolver *>(h);
+    CoutSilencer quiet(true);
+    int nx = s->work->nx;
+    tinyVector x = Eigen::Map<const Eigen::VectorXd>(x0, nx);
+    long iters = 0;
+    double acc = 0.0;
+    for (int k = 0; k < ticks; ++k) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        tiny_set_x0(s, x);
+        tiny_solve(s);
+        tinyVector u0 = s->solution->u.col(0);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (k >= skip) {
+            acc += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            iters += s->work->iter;
+        }
+        x = s->work->Adyn * x + s->work->Bdyn * u0;
+    }
+    Eigen::Map<Eigen::VectorXd>(x0, nx) = x;
+    if (seconds) *seconds = acc;
     return iters;
 }
 

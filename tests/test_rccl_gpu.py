@@ -38,7 +38,7 @@ def test_bench_under_torchrun_uses_rccl_and_reduces_the_summary(pkg):
     assert out["n_gpus"] == 1 and out["config"]["global_batch"] == batch
     s = out["summary"]  # produced by batch.allreduce_summary over the RCCL group
     assert s["instances"] == batch and s["total_iterations"] == batch * iters and s["converged"] == 0
-    assert out["process_group"] == {"backend": "nccl", "world_size": 1}
+    assert out["process_group"] == {"backend": "nccl", "world_size": 1, "ranks_per_device": 1}
     assert len(out["per_rank"]) == 1 and out["per_rank"][0]["instances"] == batch and out["per_rank"][0]["kernel_ms_avg"] > 0
     # the numbers in the summary are those of the solve: residual maxima against the golden prefix
     g = golden("quadrotor_batch64")
@@ -64,7 +64,7 @@ def test_bench_two_ranks_over_rccl(pkg):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * batch and out["scaling"] == "weak"
     assert out["summary"]["instances"] == 2 * batch and out["summary"]["total_iterations"] == 2 * batch * iters
     assert [p["first_instance"] for p in out["per_rank"]] == [0, batch] and all(p["instances"] == batch for p in out["per_rank"])
-    assert out["process_group"] == {"backend": "nccl", "world_size": 2}
+    assert out["process_group"] == {"backend": "nccl", "world_size": 2, "ranks_per_device": 1}
 
 
 def test_two_handles_on_two_devices(pkg):

@@ -910,6 +910,7 @@ int tinympc_reset_workspace(tinympc_solver *s) {
         HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
     }
     s->sol_zero_pending = true;  // (sol_x / sol_u: zero by contract; the next solve overwrites them, a reader before that gets zeros written first)
+    if (s->sol_ptrs_exported && (rc = materialize_zero_solution(s))) return rc;  // ... a reader that holds the device pointers comes through no verb
     HIP_TRY(launch_reset_stats(s->distats, s->ddstats, s->drho_inst, s->batch, s->rho, s->stream));  // (adapted rho back to the setup value)
     s->host_sol_state = 0;  // the device solution / statistics were just zeroed: read them from there
     return TINYMPC_OK;
@@ -929,6 +930,7 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
     if ((rc = materialize_zero_solution(s))) return rc;
+    s->sol_ptrs_exported = true;  // from here on tinympc_reset_workspace zeroes the buffers itself instead of deferring it
     if (d_x) *d_x = s->dsolx;
     if (d_u) *d_u = s->dsolu;
     return TINYMPC_OK;

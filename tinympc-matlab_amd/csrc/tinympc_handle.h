@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,7 @@ struct tinympc_solver {
     bool layout_m = false;
     double dbg_tick[4] = {0.0, 0.0, 0.0, 0.0};  // tinympc_debug_tick_timing
     bool sol_zero_pending = false;  // the device solution is zero by contract (reset_workspace), not yet zeroed: every solve of >= 1 iteration overwrites all of it
+    bool sol_ptrs_exported = false;  // tinympc_get_solution_device_ptrs has handed the buffers out: a reset zeroes them eagerly (the caller reads them without a verb)
     bool cold_state = false;  // G, V, D are zero by contract (reset_workspace) but NOT yet zeroed in HBM: see SolveParams::cold
     bool d_varying_jit = false;  // ... and that kernel is a run-time specialisation even if the constant-table one is compiled in
     int d_adapt = -1;       // ... and with adaptive rho
@@ -143,6 +145,10 @@ struct tinympc_solver {
     // from this mailbox in pinned memory (layout: SolveParams::mail).
     double *h_mail = nullptr;          // [64]
     bool session_active = false;
+    // Taken by everything that writes the mailbox or (re)starts the resident kernel: session_step (for the whole tick), end_session
+    // and park_sessions_on_device -- the one place where a thread reaches into a handle it does not own. Lock order: the session
+    // registry (tinympc_session.hip) first, then this.
+    std::mutex session_mu;
     // references re-sent inside a session that turned out to be the previous ones moved up by one knot (receding horizon):
     // only the new last column travels, with the command (flags 4 / 8); two shifts without a step in between, or any other
     // change, fall back to the full re-read (refs_on_host)

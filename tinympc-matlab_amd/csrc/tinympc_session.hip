@@ -91,13 +91,15 @@ void session_registry(tinympc_solver *s, bool open) {
 }  // namespace
 
 void tinympc::host::park_sessions_on_device(int device, const tinympc_solver *except) {
-    std::vector<tinympc_solver *> open;
-    {
-        std::lock_guard<std::mutex> lock(g_sessions_mu);
-        open = g_sessions;
-    }
-    for (tinympc_solver *o : open) {
-        if (o == except || o->device != device || !o->session_active) continue;
+    // The registry lock is held for the whole walk: a handle leaves the registry (end_session, first thing; destroy() passes through
+    // it) before anything of it is torn down, so none of the pointers can die under this loop. Each handle's own session mutex keeps
+    // the stop command out of a tick its owner thread is in the middle of (the stamp and the mailbox lines of that tick would
+    // be overwritten and the owner would spin on a stamp nobody answers, until the restart path or the idle time-out).
+    std::lock_guard<std::mutex> lock(g_sessions_mu);
+    for (tinympc_solver *o : g_sessions) {
+        if (o == except || o->device != device) continue;
+        std::lock_guard<std::mutex> tick(o->session_mu);
+        if (!o->session_active) continue;
         write_command(o, 1, nullptr);                 // stop: the kernel writes its state back and leaves
         (void)hipStreamSynchronize(o->stream);        // (session_active stays set: session_step restarts the kernel)
     }
@@ -105,7 +107,9 @@ void tinympc::host::park_sessions_on_device(int device, const tinympc_solver *ex
 
 int tinympc::host::end_session(tinympc_solver *s) {
     if (!s->session_active) return TINYMPC_OK;
-    session_registry(s, false);
+    session_registry(s, false);  // (registry first, then the handle's mutex: the lock order of park_sessions_on_device)
+    std::lock_guard<std::mutex> tick(s->session_mu);
+    if (!s->session_active) return TINYMPC_OK;
     write_command(s, 1, nullptr);  // stop
     s->session_active = false;     // (before anything that could come back here)
     if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
@@ -133,17 +137,20 @@ int tinympc_session_begin(tinympc_solver *s) {
         std::memset(s->h_mail, 0, sizeof(double) * 64);
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if ((rc = launch_session_kernel(s))) return rc;
-    s->session_active = true;
+    {
+        std::lock_guard<std::mutex> tick(s->session_mu);
+        if ((rc = launch_session_kernel(s))) return rc;
+        s->session_active = true;
+        s->flag_pending = false;
+    }
     session_registry(s, true);
-    s->flag_pending = false;
     return TINYMPC_OK;
 }
 
-int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
-    int rc = check_handle(s);
-    if (rc) return rc;
-    if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
+// One tick under the handle's session mutex. `*dead` is set when the session ended with an error: the caller then takes the
+// handle out of the registry AFTER the mutex is released (lock order: registry before handle).
+static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_out, bool *dead) {
+    int rc;
     if (!s->session_active) return fail(TINYMPC_ERR_NOT_INITIALIZED, "session_step: no session is open (tinympc_session_begin)");
     HIP_TRY(hipSetDevice(s->device));  // (the restart path below launches; a multi-GPU caller may have another device current)
     int flags = 0;
@@ -166,16 +173,20 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
                 // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
                 // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
                 rc = launch_session_kernel(s);  // waits for session_seq + 1
-                if (rc) { s->session_active = false; session_registry(s, false); return rc; }
+                if (rc) { s->session_active = false; *dead = true; return rc; }
                 write_command(s, 0, x0);
                 want = (double)s->session_seq;
             } else if (q != hipErrorNotReady) {
                 s->session_active = false;
-                session_registry(s, false);
+                *dead = true;
                 return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
             }
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
-                (void)end_session(s);
+                write_command(s, 1, nullptr);  // stop (should the kernel still be there); the caller waits for the stream
+                s->session_active = false;
+                if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;
+                s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
+                *dead = true;
                 return fail(TINYMPC_ERR_HIP, "session_step: no answer from the resident kernel within 30 s");
             }
         }
@@ -184,6 +195,22 @@ int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
     s->host_sol_state = 2;
     std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
     return TINYMPC_OK;
+}
+
+int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!x0 || !u0_out) return fail(TINYMPC_ERR_INVALID_INPUT, "session_step: x0 and u0_out are required");
+    bool dead = false;
+    {
+        std::lock_guard<std::mutex> tick(s->session_mu);
+        rc = session_tick_locked(s, x0, u0_out, &dead);
+    }
+    if (dead) {
+        session_registry(s, false);
+        (void)hipStreamSynchronize(s->stream);
+    }
+    return rc;
 }
 
 int tinympc_session_end(tinympc_solver *s) {

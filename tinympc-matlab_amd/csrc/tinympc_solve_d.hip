@@ -34,6 +34,9 @@
 // the PREVIOUS iterate in v/z (admm.cpp:181-197) -- the stale copy goes to p.V2, written only in sweeps that can
 // still end converged (decided on knot 0, after D_FIRST steps and then every D_GROUP steps; exact because the
 // residual maxima only grow).
+#ifndef TINY_JIT
+#include <atomic>  // (host side only: the run-time compiler has no use for it)
+#endif
 #include <type_traits>
 
 #include "tinympc_device.h"
@@ -1056,11 +1059,16 @@ __host__ __device__ constexpr int d_wpg(int nu, int N, bool ct) { return d_vl(nu
 #if !TINY_REFILL
 // Slot refill launches one resident set: 2 wavefronts per SIMD x 4 SIMDs x the device's CUs, in workgroups of wpg.
 int solve_d_resident_workgroups(int wpg) {
-    static int cus = 0;
+    // compute units of the CURRENT device, cached per device id (devices of one node may differ in partition mode); the slots
+    // are written at most once each with the same value, so a relaxed atomic is all the synchronisation they need
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cus_of[dev].load(std::memory_order_relaxed);
     if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus_of[dev].store(cus = n, std::memory_order_relaxed);
     }
     return cus * 8 / wpg;
 }
