@@ -674,6 +674,10 @@ def main() -> int:
             med = sorted(ms[2:])[len(ms[2:]) // 2]
             out["rocket_instance"] = {"workload": "rocket landing nx=6 nu=3 N=100, state + input cones, 1 linear row, fdyn, %d forced iterations" % args.iters,
                                       "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
+                                      "flops_per_instance_iteration": rk.flops_per_iteration_families()["with_box"],
+                                      "flops_model": "problems.flops_per_iteration_families(): SURVEY section 8a's box-path formula + the cone / half-space projections, "
+                                                     "their slack / dual / linear-cost terms and fdyn, counted on oracle/tinympc_oracle.c:348-470",
+                                      "fp64_frac": args.iters * rk.flops_per_iteration_families()["with_box"] / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                                       "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None,
                                       **leg_counters("rocket_instance", args.iters / (med * 1e-3))}
             one.reset()
@@ -699,6 +703,8 @@ def main() -> int:
                 med = sorted(ms[1:])[len(ms[1:]) // 2]
                 rb["N=%d" % rN] = {"iters_per_s": rB * rit / (med * 1e-3), "kernel_ms": med, "layout": many.launch_info()["layout"], "jit": many.jit_info(),
                                    "box_part_fp64_frac": rB * rit * rkb.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                   "flops_per_instance_iteration": rkb.flops_per_iteration_families()["with_box"],
+                                   "fp64_frac": rB * rit * rkb.flops_per_iteration_families()["with_box"] / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                                    **(leg_counters("rocket_batch", rB * rit / (med * 1e-3)) if rN == 100 else {})}
                 many.reset()
             out["rocket_batch"] = dict(workload="4096 rocket-landing instances (cones + linear row + fdyn) x 100 forced iterations", **rb)

@@ -18,6 +18,17 @@ if os.path.join(ROOT, "oracle") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "layouts(*names): the solve-kernel layouts (TINYMPC_LAYOUT) a test of a `kernel_layout` module runs against")
+
+
+def pytest_generate_tests(metafunc):
+    """Modules with a `kernel_layout` fixture run every test once per solve-kernel layout: the module's LAYOUTS, or what the test's
+    own `@pytest.mark.layouts(...)` names. Only combinations that apply are generated -- a skip in the GPU run is then a real
+    condition (one GPU visible ...), not a parametrisation that does not apply."""
+    if "kernel_layout" in metafunc.fixturenames:
+        marker = metafunc.definition.get_closest_marker("layouts")
+        layouts = marker.args if marker else getattr(metafunc.module, "LAYOUTS")
+        metafunc.parametrize("kernel_layout", list(layouts), indirect=True)
 
 
 def load_pkg():

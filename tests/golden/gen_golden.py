@@ -17,6 +17,10 @@ Fixtures:
   quadrotor_box_tol        config 3 with tol 1e-3 (in-kernel termination on a 12-state problem)
   quadrotor_batch64        config 5 prefix: 64 instances, seeded x0, cold start, 200 iterations
   cartpole_mpc_loop        warm-start semantics: 12 closed-loop ticks, tol 1e-4 (iters and u0 per tick)
+  quadrotor_warm_batch16   warm restarts of a MIXED batch: 16 quadrotor instances scaled to converge at different iterations,
+                           three consecutive solves each (cold; warm with the same x0; warm with 1.05 x0): iterations, status, all
+                           four residuals and the solution of every solve -- what a kernel that keeps several instances in one
+                           wavefront must reproduce per instance (the stale v/z a converged solve leaves behind, admm.cpp:181-197)
 """
 from __future__ import annotations
 
@@ -154,6 +158,40 @@ def mpc_loop():
     print(f"cartpole_mpc_loop: iters={iters} -> {os.path.getsize(path)} B")
 
 
+def warm_batch16():
+    """Three consecutive solves per instance on the reference core; every instance has its own workspace (a fresh cold start),
+    exactly what a batched handle promises per instance."""
+    prob = P.quadrotor(50)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=150, check_termination=1)
+    B = 16
+    scales = np.random.default_rng(11).uniform(0.05, 2.2, B)
+    x0s = np.asfortranarray(P.quadrotor_batch_x0(B) * scales[None, :])
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    its = np.zeros((3, B), dtype=np.int32)
+    status = np.zeros((3, B), dtype=np.int32)
+    res = np.zeros((3, 4, B))
+    u0 = np.zeros((3, nu, B))
+    sx = np.zeros((nx, N, B))       # (full trajectories of the THIRD solve only: the fixture stays small)
+    su = np.zeros((nu, N - 1, B))
+    ref = O.OracleRef(prob).load_problem(prob, settings)
+    for b in range(B):
+        ref.reset_workspace()
+        for k, x0 in enumerate((x0s[:, b], x0s[:, b], 1.05 * x0s[:, b])):
+            ref.set_x0(x0)
+            ref.solve()
+            st = ref.stats()
+            its[k, b], status[k, b] = st["iter"], st["status"]
+            res[k, :, b] = [st["pri_x"], st["dua_x"], st["pri_u"], st["dua_u"]]
+            sx[:, :, b], su[:, :, b] = ref.solution()
+            u0[k, :, b] = su[:, 0, b]
+    assert len(np.unique(its[0])) >= 6, its[0]
+    data = base_inputs(prob, settings)
+    data.update(x0s=x0s, iters=its, status=status, residuals=res, u0=u0, sol_x=sx, sol_u=su, third_x0_scale=1.05)
+    path = os.path.join(HERE, "quadrotor_warm_batch16.npz")
+    np.savez_compressed(path, **data)
+    print(f"quadrotor_warm_batch16: iters={its.tolist()} -> {os.path.getsize(path)} B")
+
+
 def main():
     if not O.ref_available():
         sys.exit("oracle/_ref/libtinympc_ref.so missing: run `make -C oracle ref` first")
@@ -167,6 +205,7 @@ def main():
                                                       check_termination=1))
     batch64()
     mpc_loop()
+    warm_batch16()
 
 
 if __name__ == "__main__":

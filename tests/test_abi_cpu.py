@@ -145,3 +145,18 @@ def test_shard_range_partitions_exactly(pkg):
     assert B.shard_range(65536, 3, 8) == (3 * 8192, 8192)
     with pytest.raises(ValueError):
         B.shard_range(4, 4, 4)
+
+
+def test_families_flop_model(pkg):
+    """problems.flops_per_iteration_families(): the roof bench.py prices the rocket-landing legs against. Hand count for BASELINE
+    config 4 (nx=6, nu=3, N=100, one 3-cone per side, one state half-space, fdyn): per side 6 E for slack + dual + linear cost,
+    15 per cone and knot, 6 dim + 3 per linear row and knot, 3 nx for the terminal p of each state family, 2 nx + nu per fdyn step."""
+    P = pkg.problems
+    r = P.rocket(100)
+    X, U = 600, 297
+    f = r.flops_per_iteration_families()
+    assert f["state_cones"] == 6 * X + 18 + 100 * 15 and f["input_cones"] == 6 * U + 99 * 15
+    assert f["state_linear"] == 6 * X + 18 + 100 * 39 and f["input_linear"] == 0 and f["fdyn"] == 99 * 15
+    assert f["total"] == 17388 and f["with_box"] == 17388 + r.flops_per_iteration() == 61215
+    q = P.quadrotor(50).flops_per_iteration_families()
+    assert q["total"] == 0 and q["with_box"] == 60848  # the box path alone: SURVEY.md section 8(a)

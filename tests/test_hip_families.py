@@ -16,10 +16,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
-@pytest.fixture(autouse=True, params=["A", "C"])
+LAYOUTS = ("A", "C")  # (conftest.pytest_generate_tests: the default of this module; @pytest.mark.layouts(...) narrows it per test)
+
+
+@pytest.fixture(autouse=True)
 def kernel_layout(request, monkeypatch):
     """The families run in two kernels: k_admm_solve_fam (layout A: batches, wide systems, long horizons) and the
-    FAM variant of the latency kernel k_admm_solve_c (one instance per workgroup); every test runs against both."""
+    FAM variant of the latency kernel k_admm_solve_c (one instance per workgroup); every test runs against both unless its
+    `layouts` marker names the one pass it needs (tests that choose their kernels themselves)."""
     monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
     return request.param
 
@@ -181,14 +185,13 @@ def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
     s.reset()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("variant", ["cones", "linear", "both", "both_constant_references"])
 @pytest.mark.parametrize("N", [10, 20, 28])
 def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
     """Short horizons, large batches: the families ride on the run-time specialised layout D (gc, gl, lx in registers next to
     g and v; tinympc_jit.hip with -DTINY_JIT_FAM=1). The library's own choice; cold start and a warm start against the
     restatement for every instance, then the same two solves on k_admm_solve_fam (TINYMPC_JIT=0)."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
     rk = P.rocket(N, with_linear=variant != "cones")
@@ -234,6 +237,7 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
     assert (results["1"][0][1]["status"] == 1).any() and (results["1"][1][1]["iter"] < results["1"][0][1]["iter"]).any()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("variant", ["cones", "linear", "both", "both_constant_references", "input_cone_only"])
 @pytest.mark.parametrize("N", [100, 44, 10])
 def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
@@ -243,8 +247,6 @@ def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
     (the two share the persistent HBM state). N=100: eight chunks of 13, the last one 8; N=44: eight chunks would leave the last
     wavefront one slot, so the plan is four wavefronts (one per SIMD, 512 registers) with chunks of 11 and 10; N=10: no plan at all
     (chunks of at least three slots) -- the refusal path: the handle says so and runs on another kernel."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", "E")
     P = pkg.problems
     rk = P.rocket(N, with_linear=variant in ("linear", "both", "both_constant_references"))
@@ -316,11 +318,10 @@ def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
     s.reset()
 
 
+@pytest.mark.layouts("A")
 def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypatch):
     """tinympc_prepare: the variant decision (here: families on layout D) is taken -- and the kernel built -- before the first
     solve, so that launch_info already names it and the first tick does not pay for it."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     rk = pkg.problems.rocket(10)
     s = make(pkg, rk, dict(max_iter=30, abs_pri_tol=1e-3, abs_dua_tol=1e-3), batch=1500)
@@ -333,13 +334,12 @@ def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypa
     s.reset()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("what", ["box", "families", "adaptive_rho"])
 def test_layout_d_variants_share_the_persistent_state_with_the_other_kernels(pkg, kernel_layout, monkeypatch, what):
     """One handle, four warm-started solves, the kernel switched between them (TINYMPC_JIT on / off / on / off): layout D and its
     FAM / ADAPT variants keep g, v, d, gc, gl and the per-instance rho in the same HBM arrays as layouts A / B,
     k_admm_solve_fam and k_admm_solve_adapt, so the sequence must equal the restatement's four consecutive solves."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
     batch = 1100
@@ -394,14 +394,13 @@ def _many_rows(rng, n, dim, point, margin):
     return A, b
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("layout,N,batch", [("A", 12, 3), ("C", 20, 1), ("D", 16, 1301), ("E", 100, 203)])
 def test_twelve_linear_rows_per_side(pkg, kernel_layout, monkeypatch, layout, N, batch):
     """More linear rows than any kernel keeps in registers (bindings.cpp:408-431 forwards any number): 12 state rows and 5 input
     rows, walked one after another as upstream does, on every kernel that carries the families -- k_admm_solve_fam (rows beyond
     the eighth from L2), the latency kernel and layout D (LDS, run-time loop), layout E (LDS; more than four rows: one copy of the
     row's code behind a loop)."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", layout)
     rk = pkg.problems.rocket(N)
     rng = np.random.default_rng(12)
@@ -432,13 +431,12 @@ def test_twelve_linear_rows_per_side(pkg, kernel_layout, monkeypatch, layout, N,
     s2.reset()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("layout,N,batch", [("C", 20, 1), ("E", 100, 203)])
 def test_equality_constraints_through_the_class_surface(pkg, kernel_layout, monkeypatch, layout, N, batch):
     """set_equality_constraints (TinyMPC.m:296-317): Aeq s == beq becomes the two inequalities [A; -A] s <= [b; -b] -- five
     equality rows are ten linear rows, more than the kernels' register budget of round 2 allowed. The solution must satisfy the
     equalities within the primal tolerance and equal the restatement's."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", layout)
     rk = pkg.problems.rocket(N, with_linear=False)
     rk.cones = dict(Acx=[], qcx=[], cx=[], Acu=[0], qcu=[3], cu=[0.25])
@@ -468,14 +466,13 @@ def test_equality_constraints_through_the_class_surface(pkg, kernel_layout, monk
     s.reset()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("layout,N,batch", [("A", 12, 1), ("A", 30, 37), ("E", 100, 203)])
 def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, monkeypatch, layout, N, batch):
     """Two state cones that share rows (rows 0-2 and rows 1-4) plus the input cone: upstream projects the cones of a knot in list
     order (each sees its predecessor's result), which differs from projecting them at once. The kernels group the list into
     rounds of pairwise-disjoint cones: k_admm_solve_fam walks the rounds with mask rows from L2 (any batch, any horizon, also
     where the latency kernel would otherwise run), layout E has them compiled in. Against the restatement (sequential loops)."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", layout)
     rk = pkg.problems.rocket(N)
     rk.cones = dict(Acx=[0, 1], qcx=[3, 4], cx=[0.2, 0.3], Acu=[0], qcu=[3], cu=[0.25])
@@ -510,6 +507,7 @@ def test_overlapping_cones_are_projected_one_after_another(pkg, kernel_layout, m
 
 @pytest.mark.parametrize("case", ["rocket100_both", "rocket100_cones", "rocket100_linear", "rocket100_const_refs", "rocket100_overlap", "rocket44_both",
                                   "rocket10_both", "quadrotor50_box", "quadrotor23_box", "cartpole20_box"])
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("batch", [1, 5])
 def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch, case, batch):
     """Layout F (tinympc_solve_f.hip): one instance per workgroup, up to 32 chunks on the DPP rows of up to eight wavefronts, shape /
@@ -519,8 +517,6 @@ def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch
     handle continues on the latency kernel of round 1 (layout C) from the state layout F left behind.
     Chunk plans: N=100 -> 25 chunks of 4 (last: 3) on 7 wavefronts; N=44 -> 22 chunks of 2 (last: 1); N=10 -> 5 chunks of 2 (last: 1) on
     2 wavefronts; quadrotor N=50 -> 25 chunks of 2 (last: 1); N=23 -> 11 chunks of 2."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.setenv("TINYMPC_LAYOUT", "F")
     P = pkg.problems
     name, variant = case.split("_", 1)
@@ -576,14 +572,13 @@ def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch
     s.reset()
 
 
+@pytest.mark.layouts("A")
 @pytest.mark.parametrize("nx,nu,N,batch", [(20, 4, 12, 37), (24, 8, 10, 5), (40, 10, 8, 9), (48, 16, 6, 3)])
 def test_families_on_wide_systems(pkg, kernel_layout, monkeypatch, nx, nu, N, batch):
     """32 and 64 lanes per instance (k_admm_solve_fam's reduction form: a cone's ||w||^2 is a group sum over its tail rows, t one
     lane read, a linear row two group sums -- no mask rows in registers): a cone inside one DPP row, one that straddles the
     boundary between two rows of 16 lanes, two cones that share a row (a second round), an input cone, linear rows on both
     sides and fdyn. Against the restatement: identical iteration counts, 1e-9 on the trajectories, over a cold and a warm start."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
     P = pkg.problems
     rng = np.random.default_rng(nx * 100 + nu)
@@ -614,13 +609,12 @@ def test_families_on_wide_systems(pkg, kernel_layout, monkeypatch, nx, nu, N, ba
     s.reset()
 
 
+@pytest.mark.layouts("A")
 def test_rocket_batch_properties_at_bench_size(pkg, kernel_layout, monkeypatch):
     """BASELINE config 4 in the batch the bench times (4,096 rocket landings, N=100, cones + linear row + fdyn, layout E): properties
     that need no oracle -- reversing the instance order reverses the results bit for bit; equal initial states give equal results
     wherever they sit in the batch; the thrust cone and the box hold on every converged instance; a seeded sample against the
     restatement."""
-    if kernel_layout != "A":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
     rk = pkg.problems.rocket(100)
     settings = dict(max_iter=150, abs_pri_tol=1e-2, abs_dua_tol=1e-2)

@@ -21,14 +21,18 @@ assert TOL < TOL_BAR
 SINGLE = ["cartpole_unconstrained", "cartpole_box_tol", "cartpole_box_200", "quadrotor_box_200", "quadrotor_box_tol"]
 
 
-@pytest.fixture(autouse=True, params=["A", "B", "C", "D"])
+LAYOUTS = ("A", "B", "C", "D")  # (conftest.pytest_generate_tests: the default of this module; @pytest.mark.layouts(...) narrows it per test)
+
+
+@pytest.fixture(autouse=True)
 def kernel_layout(request, monkeypatch):
     """Every test runs against all four solve kernels: layout A (all ADMM state in LDS, tinympc_solve.hip),
     layout B (V L2-resident in HBM, 4-wave workgroups, tinympc_solve_b.hip), layout C (one instance per
     workgroup, horizon swept in 16 concurrent chunks, tinympc_solve_c.hip) and layout D (horizon unrolled at compile
     time, state in registers, two waves per SIMD, tinympc_solve_d.hip). The layout is chosen at setup time;
     where B does not apply (W > 16 or N < 8), C does not (W > 16 or N > 129) or D does not (shape not compiled in,
-    time-varying bounds / references) the library falls back."""
+    time-varying bounds / references) the library falls back. Tests that apply to some of the kernels only say so with
+    `@pytest.mark.layouts(...)`: the other combinations are never generated (no skips to wade through)."""
     monkeypatch.setenv("TINYMPC_LAYOUT", request.param)
     return request.param
 
@@ -408,13 +412,12 @@ def test_bench_size_solve_matches_golden_and_oracle(pkg, kernel_layout):
     s.reset()
 
 
+@pytest.mark.layouts("D")
 def test_config5_on_one_gpu_properties(pkg, kernel_layout):
     """BASELINE config 5 in one launch: all 65,536 quadrotor instances on ONE GPU (8 rounds of 8 waves per CU).
     The first 8,192 instances must equal, bit for bit, what the 8,192-instance shard produces (an instance's
     result does not depend on the batch it is solved in or on the wave slot it lands in); the last 64 are checked against
     the oracle; feasibility everywhere."""
-    if kernel_layout != "D":
-        pytest.skip("one throughput layout is enough for the 65,536-instance case")
     P = pkg.problems
     prob = P.quadrotor(50)
     settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
@@ -485,13 +488,12 @@ def test_per_tick_references_stay_one_launch_and_match_the_device_path(pkg):
     two.reset()
 
 
+@pytest.mark.layouts("A", "D")
 @pytest.mark.parametrize("nx,nu,N", [(24, 8, 30), (20, 4, 30), (48, 16, 20), (40, 8, 20)])
 def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
     """The shapes compiled into the wide forms of layout D (32 / 64 lanes per instance, duals in registers, two wavefronts
     per SIMD, tinympc_solve_dw.hip / tinympc_solve_dx.hip) against the oracle: per-instance termination inside a wavefront, ragged batch, warm start after
     converged and unconverged solves, forced iteration counts; and layout A on the same handle state in between."""
-    if kernel_layout not in ("A", "D"):
-        pytest.skip("wide systems run on layouts A and D")
     P = pkg.problems
     rng = np.random.default_rng(nx * 100 + nu)
     A = np.eye(nx) + 0.03 * rng.standard_normal((nx, nx))
@@ -525,12 +527,11 @@ def test_wide_systems_on_layout_d(pkg, kernel_layout, nx, nu, N):
 
 @pytest.mark.parametrize("nx,nu,N", [(12, 4, 20), (12, 4, 30), (6, 3, 25), (20, 6, 15), (30, 10, 9),
                                      (12, 4, 75), (12, 4, 100), (6, 3, 100), (24, 8, 60), (48, 16, 40)])
+@pytest.mark.layouts("D")
 def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, N):
     """Shapes that are NOT compiled into the library get layout D through hiprtc (tinympc_jit.hip): default for large
     batches, same results as the oracle, TINYMPC_JIT=0 falls back to layout B / A. The second row are horizons whose duals
     do not fit 256 registers: the plan with one wavefront per SIMD (512 registers, four wavefronts per workgroup)."""
-    if kernel_layout != "D":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")  # the library's own choice
     P = pkg.problems
     rng = np.random.default_rng(nx * 1000 + N)
@@ -567,13 +568,12 @@ def test_run_time_specialised_layout_d(pkg, kernel_layout, monkeypatch, nx, nu, 
     s.reset()
 
 
+@pytest.mark.layouts("D")
 @pytest.mark.parametrize("shape", ["cartpole20", "quadrotor25", "quadrotor80", "wide24x8x30", "wide20x6x15", "wide48x16x20", "wide24x8x60"])
 def test_layout_d_with_bounds_and_references_that_vary_over_the_horizon(pkg, kernel_layout, monkeypatch, shape):
     """Layout D reads per-knot bounds / references from the workgroup's LDS copy of the tables (the compiled-in cartpole
     shape, run-time specialised ones, the 32- and 64-lane forms -- there this variant is always specialised at run time,
     also for shapes whose constant-table kernel is compiled in): large batch, library's own layout choice."""
-    if kernel_layout != "D":
-        pytest.skip("one pass is enough")
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
     rng = np.random.default_rng(5)
@@ -643,13 +643,12 @@ def test_mpc_step_equals_the_three_verb_tick(pkg, batch):
     b.reset()
 
 
+@pytest.mark.layouts("D")
 @pytest.mark.parametrize("case", ["varying_tables", "families"])
 def test_first_tick_on_a_layout_d_variant_that_is_decided_late(pkg, kernel_layout, monkeypatch, case):
     """Layout D's per-knot-table and family variants are specialised when first needed. The batched tick asks "layout D?" before
     it launches (small batches exchange x0 / u0 through pinned memory on the other layouts only): the answer must not change
     between that question and the launch, also on the very first tick (TINYMPC_LAYOUT=D forces layout D on a small batch)."""
-    if kernel_layout != "D":
-        pytest.skip("layout D only")
     P = pkg.problems
     batch = 64
     if case == "families":
@@ -761,13 +760,12 @@ def test_long_horizon_state_in_global_memory(pkg, N):
     s.reset()
 
 
+@pytest.mark.layouts("C")
 @pytest.mark.parametrize("N", [2, 3, 16, 17, 18, 33, 34, 49, 65, 66, 100, 129, 130])
 def test_chunked_layout_horizon_boundaries(pkg, kernel_layout, N):
     """Layout C cuts the N-1 steps into <= 16 chunks of S = ceil((N-1)/16) steps: horizons on either side of every
     change of S and of the chunk count, the 8-slot variant (N > 65), a partial last chunk, and N = 130 where layout
     C no longer applies. Cold solve, warm-started second solve and a converging solve, against the oracle."""
-    if kernel_layout != "C":
-        pytest.skip("layout C only")
     P = pkg.problems
     for prob in (P.cartpole(N, True), P.quadrotor(N)):
         settings = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=23, check_termination=2)

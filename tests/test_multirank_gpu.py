@@ -9,8 +9,9 @@ with ONE unsharded solve of the whole batch in this process. (SURVEY.md section 
 /root/reference/src/codegen_src/tinympc/admm.cpp:109-207.)
 
 Rank counts: the GPU pool allows six processes on a card at once and this pytest process is one of them, so the suite runs 2 and 4
-ranks (`python bench.py --gpus 6 --share-device --dist-backend gloo` runs six from a parent that never opens the device:
-profiles/r04_multirank_6.json); the split arithmetic for 8 ranks is covered
+ranks -- the torchrun launcher holds the device open as well, so five ranks is the most a clean parent can start (`python bench.py --gpus 5
+--share-device --dist-backend gloo`:
+profiles/r04_multirank_5.json; six ranks were killed by the pool's process guard); the split arithmetic for 8 ranks is covered
 on the CPU (tests/test_distributed_cpu.py::test_job_shard_weak_and_strong)."""
 from __future__ import annotations
 

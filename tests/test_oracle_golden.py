@@ -107,6 +107,26 @@ def test_mpc_loop_warm_start(pkg):
     assert rel_err(x, g["xs"][:, -1]) < 1e-9
 
 
+def test_warm_restarts_of_a_mixed_batch_match_reference(pkg):
+    """Three consecutive solves per instance (cold; warm, same x0; warm, 1.05 x0) of 16 instances that converge at different
+    iterations: the restatement against the reference core's own numbers (tests/golden/gen_golden.py::warm_batch16)."""
+    g = golden("quadrotor_warm_batch16")
+    prob = problem_from_golden(pkg, g)
+    settings = settings_from_golden(g)
+    B = g["x0s"].shape[1]
+    for b in range(B):
+        orc = O.OraclePort(prob).load_problem(prob, settings)
+        for k, x0 in enumerate((g["x0s"][:, b], g["x0s"][:, b], float(g["third_x0_scale"]) * g["x0s"][:, b])):
+            orc.set_x0(x0)
+            orc.solve()
+            st = orc.stats()
+            assert st["iter"] == g["iters"][k, b] and st["status"] == g["status"][k, b], (b, k)
+            np.testing.assert_allclose([st["pri_x"], st["dua_x"], st["pri_u"], st["dua_u"]], g["residuals"][k, :, b], rtol=1e-8, atol=1e-14)
+            sx, su = orc.solution()
+            assert rel_err(su[:, 0], g["u0"][k, :, b]) < 1e-10
+        assert rel_err(sx, g["sol_x"][:, :, b]) < 1e-10 and rel_err(su, g["sol_u"][:, :, b]) < 1e-10
+
+
 def test_known_answers_from_survey(pkg):
     """values measured on the reference core during the survey."""
     P = pkg.problems

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import golden, problem_from_golden, rel_err, settings_from_golden
 
 import pyoracle as O
 
@@ -123,4 +123,34 @@ def test_closed_loop_of_a_mixed_batch_matches_the_oracle_tick_by_tick(pkg, monke
             xo[:, b] = prob.A @ xo[:, b] + prob.B @ uo
         x = np.asfortranarray(prob.A @ x + prob.B @ u0)
     assert spread >= 3
+    s.reset()
+
+
+@pytest.mark.parametrize("layout", ["A", "B", "C", "D", "E", "F"])
+def test_warm_restarts_of_a_mixed_batch_match_the_reference_core(pkg, monkeypatch, layout):
+    """The same property pinned to the REFERENCE's own core rather than to the restatement: tests/golden/quadrotor_warm_batch16.npz
+    holds, for 16 quadrotor instances that converge at different iterations (6 ... 54, six of them never), three consecutive solves
+    each -- cold, warm with the same x0, warm with 1.05 x0 -- as oracle/_ref computed them one instance at a time. One batched
+    handle must reproduce every instance's iteration counts and statuses exactly, its residuals to 1e-6 and its solutions to 1e-9
+    in every solve, whatever else shares its wavefront."""
+    g = golden("quadrotor_warm_batch16")
+    prob = problem_from_golden(pkg, g)
+    settings = settings_from_golden(g)
+    monkeypatch.setenv("TINYMPC_LAYOUT", layout)
+    x0s = np.asfortranarray(g["x0s"])
+    B = x0s.shape[1]
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=B, rho=prob.rho, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    for k, scale in enumerate((1.0, 1.0, float(g["third_x0_scale"]))):
+        s.set_x0_batch(np.asfortranarray(scale * x0s))
+        s.solve()
+        if k == 0:
+            assert s.launch_info()["layout"] == layout
+        st, sol = s.get_stats_batch(), s.get_solution_batch()
+        np.testing.assert_array_equal(st["iter"], g["iters"][k], err_msg="solve %d" % k)
+        np.testing.assert_array_equal(st["status"], g["status"][k], err_msg="solve %d" % k)
+        np.testing.assert_allclose(st["residuals"], g["residuals"][k], rtol=1e-6, atol=1e-12, err_msg="solve %d" % k)
+        assert rel_err(sol["controls"][:, 0, :], g["u0"][k]) < 1e-9, k
+    assert rel_err(sol["states"], g["sol_x"]) < 1e-9 and rel_err(sol["controls"], g["sol_u"]) < 1e-9
     s.reset()

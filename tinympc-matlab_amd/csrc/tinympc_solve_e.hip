@@ -61,6 +61,13 @@ struct DStep;  // tinympc_solve_d_chain.h
 #include "tinympc_solve_d_chain.h"
 #include "tinympc_solve_e_common.h"
 
+// Timing experiments (tools/e_breakdown.py, through TINYMPC_JIT_DEFS="-DTINY_E_EXP=k"; results are WRONG, only the clock counts):
+//   1 the families' row-local evaluation returns at once (its LDS traffic stays)   2 no families' work in the forward step at all
+//   3 no pass 1 (forward and backward)   4 no workgroup barriers   5 = 2 + 3 + 4
+#ifndef TINY_E_EXP
+#define TINY_E_EXP 0
+#endif
+
 namespace tinympc {
 
 #ifdef TINY_E_FIRST
@@ -181,7 +188,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     EFamilies<NX, NU> fam_eval;
     if constexpr (FAM) fam_eval.init(p.fam, KT, sLin, r, p.rho);
     auto families = [&](double val, double gc_old, double gl_old, double &gc_new, double &gl_new) -> double {
+#if TINY_E_EXP == 1
+        gc_new = gc_old;
+        gl_new = gl_old;
+        return val;
+#else
         return fam_eval.eval(val, gc_old, gl_old, gc_new, gl_new);
+#endif
     };
 
     const double cf = p.ops[(size_t)2 * W * KT + r];
@@ -292,6 +305,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
                 double dcur = e_lds_read_async<0>(aD);
                 e_lds_wait();
+#if TINY_E_EXP != 3 && TINY_E_EXP != 5
                 e_static_for<0, S>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     double dn = 0.0;
@@ -300,6 +314,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     else if (!top) xt = Step::fwd_plain(xt, dcur, m, cf);
                     dcur = dn;
                 });
+#endif
                 sE[wv * 64 + lane] = xt;
             }
             e_barrier();
@@ -359,7 +374,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     if constexpr (GCL && q + 1 < S) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
                     if constexpr (GLL && q + 1 < S) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
                     xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);
-                    if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                    if constexpr (FAM && TINY_E_EXP != 2 && TINY_E_EXP != 5) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                         double gcn, gln;
                         double gl_old, gc_old;
                         if constexpr (GC_LDS) gc_old = gccur;
@@ -493,7 +508,11 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             };
             // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
             {
+#if TINY_E_EXP != 3 && TINY_E_EXP != 5
                 const double e2 = bwd_chain(0.0, std::false_type{});
+#else
+                const double e2 = V[0];
+#endif
                 sB[wv * 64 + lane] = e2;
             }
             e_barrier();

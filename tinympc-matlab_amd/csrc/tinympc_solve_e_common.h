@@ -52,7 +52,11 @@ __device__ __forceinline__ void e_lds_write_masked(unsigned addr, double v, unsi
 }
 __device__ __forceinline__ void e_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // workgroup barrier that waits for this wavefront's LDS traffic only (not for its global stores, as __syncthreads() would)
+#if defined(TINY_E_EXP) && (TINY_E_EXP == 4 || TINY_E_EXP == 5)  // (timing experiment: no barrier)
+__device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 __device__ __forceinline__ bool e_wave_may_converge(unsigned long long bad, unsigned long long live) {
     bool any = false;

@@ -77,6 +77,42 @@ class Problem:
         bwd = 2 * nx * nu + nu + 2 * nu * nu + 2 * nx * nx + 2 * nx * nu + 2 * nx
         return (N - 1) * (fwd + bwd) + 13 * (X + U) + 2 * nx * nx + 3 * nx
 
+    def flops_per_iteration_families(self) -> dict:
+        """Flop model of what the cone / linear-inequality families and `fdyn` ADD to an ADMM iteration, counted on the
+        published upstream algorithm (the semantics behind bindings.cpp:84-85, 408-478; the repo's CPU restatement has the loops) the way
+        SURVEY.md section 8(a) counts the box path: every add, subtract, multiply, compare, divide and square root is one flop,
+        the projections at their expensive branch (a cone point outside the cone, a violated half-space). Per enabled family and
+        side, with E = nx N (state side) or nu (N-1) (input side) elements over K = N or N-1 knots:
+          slack copy  s = x + dual                       E
+          dual ascent dual += x - s                      2 E
+          linear cost q -= rho (s - dual)                3 E   (+ 3 nx for the terminal p on the state side)
+          cone of dimension n per knot (project_soc)     u0 = mu t: 1; |w|^2: 2(n-1); sqrt: 1; two compares: 2;
+                                                         scale = 0.5 (1 + u0 / a): 3; w *= scale: n-1; t = scale (a / mu): 2
+                                                         = 3 n + 6
+          linear row per knot (project_halfspaces)       a's: 2 dim; |a|^2: 2 dim; compare: 1; (a's - b) / |a|^2: 2;
+                                                         s -= dist a: 2 dim   = 6 dim + 3
+          fdyn                                            x+ += f: nx per forward step; p += APf, (.. + BPf): nx + nu per backward step
+        Returns the parts and their sum (`total`), and `with_box` = total + flops_per_iteration()."""
+        nx, nu, N = self.nx, self.nu, self.N
+        X, U = nx * N, nu * (N - 1)
+        parts = {"state_cones": 0, "input_cones": 0, "state_linear": 0, "input_linear": 0, "fdyn": 0}
+        c = self.cones or {}
+        if len(c.get("qcx", [])):
+            parts["state_cones"] = 6 * X + 3 * nx + N * sum(3 * int(n) + 6 for n in c["qcx"])
+        if len(c.get("qcu", [])):
+            parts["input_cones"] = 6 * U + (N - 1) * sum(3 * int(n) + 6 for n in c["qcu"])
+        lin = self.linear or {}
+        mx = int(np.asarray(lin.get("blin_x", [])).size)
+        mu_rows = int(np.asarray(lin.get("blin_u", [])).size)
+        if mx:
+            parts["state_linear"] = 6 * X + 3 * nx + N * mx * (6 * nx + 3)
+        if mu_rows:
+            parts["input_linear"] = 6 * U + (N - 1) * mu_rows * (6 * nu + 3)
+        if self.fdyn is not None and np.any(np.asarray(self.fdyn) != 0):
+            parts["fdyn"] = (N - 1) * (2 * nx + nu)
+        total = sum(parts.values())
+        return dict(parts, total=total, with_box=total + self.flops_per_iteration())
+
 
 def cartpole(N: int = 20, bounded: bool = True) -> Problem:
     A = np.array([[1.0, 0.01, 0.0, 0.0],
