@@ -238,8 +238,14 @@ __host__ __device__ constexpr int e_fam_row(int nxu) { return (4 * nxu + 1) & ~1
 __host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl) {
     return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 512 + 2 * wpg * 64 + 16 + wpg * 16 + 6 * 64;
 }
+// ... or, with the families evaluated one KNOT per lane (KFamilies, tinympc_solve_e_common.h; `lds_arrays` = -1), ONE exchange buffer
+// per wavefront: entry (j, t) = nx+nu doubles at (j (S+1) + t) ES, ES odd (conflict-free for the lanes that walk t), padded so that
+// the lanes beyond the last entry read inside the buffer
+__host__ __device__ constexpr int kfam_es(int nxu) { return nxu | 1; }
+__host__ __device__ constexpr int kfam_passes(int S) { return (S + 1 + 15) / 16; }
+__host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S + 1) + 16 * kfam_passes(S)) * kfam_es(nxu) + nxu + 1) & ~1; }
 __host__ __device__ constexpr int e_wave_doubles(int nxu, int nu, int S, int lds_arrays) {
-    return lds_arrays * S * e_fam_row(nxu) + e_d_doubles(nu, S);
+    return (lds_arrays < 0 ? kfam_doubles(nxu, S) : lds_arrays * S * e_fam_row(nxu)) + e_d_doubles(nu, S);
 }
 __host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays) {
     return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl) + (size_t)wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));

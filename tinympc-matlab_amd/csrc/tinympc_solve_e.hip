@@ -47,9 +47,13 @@
 #define TINY_JIT_E_CONES {0, 0, 2}, {0, 6, 8}
 #define TINY_JIT_E_NLX 1
 #define TINY_JIT_E_NLU 0
-#define TINY_JIT_E_GC_LDS 1
-#define TINY_JIT_E_GL_LDS 1
-#define TINY_JIT_E_LX_LDS 1
+#define TINY_JIT_E_GC_LDS 0
+#define TINY_JIT_E_GL_LDS 0
+#define TINY_JIT_E_LX_LDS 0
+#define TINY_JIT_E_KFAM 1
+#endif
+#ifndef TINY_JIT_E_KFAM
+#define TINY_JIT_E_KFAM 0
 #endif
 
 namespace tinympc {
@@ -78,7 +82,9 @@ constexpr int E_FIRST = 1;  // forward steps before the first "can this sweep st
 #endif
 constexpr int E_GROUP = 8;  // ... and between two later ones
 
-template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS>
+// KFAM: the families evaluated one KNOT per lane, once per iteration (KFamilies, tinympc_solve_e_common.h) instead of one (row,
+// knot) element per lane in every slot of the sweep; the placement flags GC_LDS / GL_LDS / LX_LDS belong to the element form.
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS, bool KFAM>
 __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double *smem) {
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
@@ -86,8 +92,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     constexpr int TOFF = (N + 2) * W;
     constexpr int S_LAST = NS - (WPG - 1) * S;              // slots of the last wavefront
     static_assert(WPG >= 2 && S >= 3 && S_LAST >= 3 && S_LAST <= S, "layout E: every chunk holds at least three slots");
-    constexpr bool GCL = FAM && GC_LDS, GLL = FAM && GL_LDS, LXL = FAM && LX_LDS;
-    constexpr int NLDS = (GCL ? 1 : 0) + (GLL ? 1 : 0) + (LXL ? 1 : 0);
+    constexpr bool KF = FAM && KFAM;
+    constexpr bool GCL = FAM && !KF && GC_LDS, GLL = FAM && !KF && GL_LDS, LXL = FAM && !KF && LX_LDS;
+    constexpr int NLDS = KF ? -1 : (GCL ? 1 : 0) + (GLL ? 1 : 0) + (LXL ? 1 : 0);
+    constexpr int ES = kfam_es(NXU), NPASS = kfam_passes(S);  // (KF) doubles per entry of the exchange buffer; passes of 16 entries per instance
     constexpr int RS = e_fam_row(NXU);  // doubles per slot of a families' array in LDS: the four instances' real rows, packed
     using Step = DStep<NX, NU>;
 
@@ -118,11 +126,17 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     double *sGC = sWave;                                          // [S][RS] each, where the plan puts them into LDS
     double *sGL = sGC + (GCL ? S * RS : 0);
     double *sLX = sGL + (GLL ? S * RS : 0);
-    double *sD = sLX + (LXL ? S * RS : 0);
+    double *sD = KF ? sWave + kfam_doubles(NXU, S) : sLX + (LXL ? S * RS : 0);
+    double *sKX = sWave;                                          // (KF) the exchange buffer: x | u up, the families' linear-cost term down
     // this lane's entry of a packed families' row; lanes beyond the system's rows read their instance's last real entry and
     // never write (EXEC mask of the real lanes)
     const int famIdx = j * NXU + (r < NXU ? r : NXU - 1);
     const unsigned long long mask_real = __ballot(r < NXU);
+    // (KF) this lane's two roles in the exchange buffer: as row r of instance j (slot q = entry q+1: kxRow + (q+1) ES) and as
+    // entry t = r (+ 16 per pass) of instance j (kxT + 16 pass ES .. + nx+nu)
+    const int kxRow = j * (S + 1) * ES + (r < NXU ? r : NXU - 1);
+    const int kxT = (j * (S + 1) + r) * ES;
+    const int s_real = top ? S_LAST : S;  // slots this wavefront really owns
 
     for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
         const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
@@ -160,6 +174,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             });
         }
     }
+    if constexpr (KF) {
+        if (bottom && r < NXU) sKX[kxRow] = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;  // entry 0: x_0 (constant over the solve)
+    }
     if (bottom) {  // knot 0 of the state rows and x0
         sK0[lane] = gG[0];
         sK0[64 + lane] = gV0[0];
@@ -175,8 +192,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         G[I.value] = gG[(size_t)g_row(I.value) * 64];
         V[I.value] = gV0[(size_t)v_row(I.value) * 64];
     });
-    double GC[(FAM && !GC_LDS) ? S : 1], GLr[(FAM && !GL_LDS) ? S : 1], LX[(FAM && !LX_LDS) ? S : 1];
-    if constexpr (FAM) {
+    double GC[(FAM && !KF && !GC_LDS) ? S : 1], GLr[(FAM && !KF && !GL_LDS) ? S : 1], LX[(FAM && !KF && !LX_LDS) ? S : 1];
+    if constexpr (FAM && !KF) {
         const double *const gGC = p.GC + vbase + lane, *const gGL = p.GL + vbase + lane;
         e_static_for<0, S>([&](auto I) {
             if constexpr (!GC_LDS) GC[I.value] = gGC[(size_t)v_row(I.value) * 64];
@@ -184,9 +201,29 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             if constexpr (!LX_LDS) LX[I.value] = 0.0;
         });
     }
+    // (KF) the families' duals of this lane's knots, one KFamilies per pass of 16 entries; canonical HBM layout as everywhere
+    KFamilies<NX, NU> kf[KF ? NPASS : 1];
+    unsigned long long kmask[KF ? NPASS : 1];  // lanes whose entry is a slot of this wavefront (they hand a linear-cost term back)
+    if constexpr (KF) {
+        const double *const bGC = p.GC + vbase + j * 16, *const bGL = p.GL + vbase + j * 16;
+        e_static_for<0, NPASS>([&](auto Pp) {
+            constexpr int pp = decltype(Pp)::value;
+            const int t = r + 16 * pp;
+            kmask[pp] = __ballot(t >= 1 && t <= s_real);
+            kf[pp].init(p.fam, KT, sLin, p.rho);
+            const bool ent = (t >= 1 && t <= s_real) || (t == 0 && bottom);
+            e_static_for<0, NXU>([&](auto R) {
+                constexpr int rr = decltype(R)::value;
+                const int kn = rr < NX ? s0 + t : s0 + t - 1;  // state rows: knot s0+t; input rows: knot s0+t-1 (none for entry 0)
+                const bool ok = ent && (rr < NX || t >= 1);
+                kf[pp].gc[rr] = ok ? bGC[(size_t)kn * 64 + rr] : 0.0;
+                kf[pp].gl[rr] = ok ? bGL[(size_t)kn * 64 + rr] : 0.0;
+            });
+        });
+    }
     // the families, specialised on their structure (tinympc_solve_e_common.h)
     EFamilies<NX, NU> fam_eval;
-    if constexpr (FAM) fam_eval.init(p.fam, KT, sLin, r, p.rho);
+    if constexpr (FAM && !KF) fam_eval.init(p.fam, KT, sLin, r, p.rho);
     auto families = [&](double val, double gc_old, double gl_old, double &gc_new, double &gl_new) -> double {
 #if TINY_E_EXP == 1
         gc_new = gc_old;
@@ -208,6 +245,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
     const unsigned aD = e_lds_addr(sD + dIdx), aT = e_lds_addr(sTl);
     const unsigned aGC = e_lds_addr(sGC + famIdx), aGL = e_lds_addr(sGL + famIdx), aLX = e_lds_addr(sLX + famIdx);
+    const unsigned aKX = e_lds_addr(sKX + kxRow), aKT = e_lds_addr(sKX + kxT);
     const int ct = p.check_termination;
 
     bool active = inst_ok;
@@ -227,7 +265,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         double base;
         if constexpr (CT) base = lr_c;
         else base = sTl[2 * TOFF + (I.value + 1) * W];
-        if constexpr (FAM) {
+        if constexpr (KF) base += sKX[(I.value + 1) * ES + kxRow];
+        else if constexpr (FAM) {
             if constexpr (LX_LDS) base += sLX[I.value * RS + famIdx];
             else base += LX[I.value];
         }
@@ -266,7 +305,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         wS[kn * sst] = V[i];
                     }
                 });
-                if constexpr (FAM) {
+                if constexpr (FAM && !KF) {
                     double *const wGC = p.GC + vbase + lane_o, *const wGL = p.GL + vbase + lane_o;
                     e_static_for<0, S>([&](auto I) {
                         constexpr int i = decltype(I)::value;
@@ -287,6 +326,25 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
                     for (int i = 0; i < S; ++i)
                         if (s0 + i < NS) wD[(size_t)(s0 + i) * DS] = sD[i * DS + dIdx];
+                }
+            }
+            if constexpr (KF) {  // the families' duals leave from the knot-per-lane layout (wb is uniform over an instance's 16 lanes)
+                if (wb) {
+                    double *const wGC = p.GC + vbase + j_o * 16, *const wGL = p.GL + vbase + j_o * 16;
+                    e_static_for<0, NPASS>([&](auto Pp) {
+                        constexpr int pp = decltype(Pp)::value;
+                        const int t = r_o + 16 * pp;
+                        if ((t >= 1 && t <= s_real) || (t == 0 && bottom)) {
+                            e_static_for<0, NXU>([&](auto R) {
+                                constexpr int rr = decltype(R)::value;
+                                if (rr < NX || t >= 1) {
+                                    const size_t kn = (size_t)(rr < NX ? s0 + t : s0 + t - 1);
+                                    wGC[kn * 64 + rr] = kf[pp].gc[rr];
+                                    wGL[kn * 64 + rr] = kf[pp].gl[rr];
+                                }
+                            });
+                        }
+                    });
                 }
             }
             pending = false;
@@ -342,7 +400,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 pri = is_x ? fabs(x0v - snew) : 0.0;
                 dua = is_x ? fabs(V0 - snew) : 0.0;
                 sK0[64 + lane] = snew;
-                if constexpr (FAM) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
+                if constexpr (FAM && !KF) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
                     double gcn, gln;
                     (void)families(x0v, sK0[2 * 64 + lane], sK0[3 * 64 + lane], gcn, gln);
                     if (is_x) {
@@ -374,7 +432,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     if constexpr (GCL && q + 1 < S) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
                     if constexpr (GLL && q + 1 < S) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
                     xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);
-                    if constexpr (FAM && TINY_E_EXP != 2 && TINY_E_EXP != 5) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                    // (KF) this slot's element -- x_{q+1} on state lanes, u_q on input lanes -- goes up to its knot's lane
+                    if constexpr (KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) e_lds_write_masked<(q + 1) * ES * 8>(aKX, xcur, mask_real);
+                    if constexpr (FAM && !KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                         double gcn, gln;
                         double gl_old, gc_old;
                         if constexpr (GC_LDS) gc_old = gccur;
@@ -427,6 +487,24 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             }
             if (active) it_done = it1;  // admm.cpp:143
 
+            // ---- (KF) the families of all slots of this wavefront at once, one knot per lane: rows in, projections, duals, the
+            // linear-cost term out through the same entry (read again by both backward passes; entry 0 keeps x_0)
+            if constexpr (KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) {
+                e_lds_wait();
+                e_static_for<0, NPASS>([&](auto Pp) {
+                    constexpr int pp = decltype(Pp)::value;
+                    double val[NXU], lxo[NXU];
+                    e_static_for<0, NXU>([&](auto R) { val[R.value] = e_lds_read_async<(16 * pp * ES + R.value) * 8>(aKT); });
+                    e_lds_wait();
+#if TINY_E_EXP == 1
+                    e_static_for<0, NXU>([&](auto R) { lxo[R.value] = val[R.value]; });
+#else
+                    kf[pp].eval(val, lxo);
+#endif
+                    e_static_for<0, NXU>([&](auto R) { e_lds_write_masked<(16 * pp * ES + R.value) * 8>(aKT, lxo[R.value], kmask[pp]); });
+                });
+            }
+
             // ---- R1 (admm.cpp:93-101), this wavefront's share: which of its four instances have every lane below tolerance
             if (check) {
                 const bool below = (pri < p.abs_pri_tol) && (dua * p.rho < p.abs_dua_tol);
@@ -454,7 +532,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     double lrT = lr1;
                     if (terminal) {
                         double pT = pnref;
-                        if constexpr (FAM) {
+                        if constexpr (KF) pT += sKX[(tt + 1) * ES + kxRow];
+                        else if constexpr (FAM) {
                             if constexpr (LX_LDS) pT += sLX[tt * RS + famIdx];
                             else pT += LX[tt];
                         }
@@ -593,10 +672,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
-    constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0;
-    constexpr int nlds = FAMJ ? (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0) : 0;
+    constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0;
+    constexpr int nlds = !FAMJ ? 0 : KFJ ? -1 : (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0);
     constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds);
     static_assert(bytes <= 160 * 1024, "layout E: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_e[bytes / sizeof(double)];
-    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ>(p, smem_e);
+    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ>(p, smem_e);
 }

@@ -241,4 +241,127 @@ struct EFamilies {
     }
 };
 
+// ---- the families, one KNOT per lane ("transposed" evaluation; layout E, round 4) ------------------------------------------------
+// EFamilies above evaluates ONE (row, knot) element per lane: every slot of a sweep pays the whole evaluation -- ~70 FP64
+// instructions for the rocket landing, half of layout E's iteration (profiles/r04_e_breakdown.txt) -- for the 4 x (nx+nu) real
+// elements of its 64 lanes, and needs cross-lane gathers for every norm and dot product. But the families are local to a KNOT:
+// a cone couples rows of one knot, a half-space likewise. KFamilies turns the data round: after the forward sweep has left the
+// wavefront's S slots of x | u in an LDS buffer, lane (instance j, entry t) picks up ALL nx+nu rows of its knot into registers and
+// evaluates every cone and every linear row of that knot in plain per-lane arithmetic -- no DPP, no EXEC masks, one square root per
+// cone and knot instead of one per lane -- ONCE per ADMM iteration for all slots of the wavefront at the same time (4 x (S+1) of
+// the 64 lanes busy), and hands the families' linear-cost term back through the same buffer. The families' duals gc, gl are only
+// ever touched here, so they LIVE in this layout (2 x (nx+nu) register pairs per lane) for the whole solve.
+// Entry t of a wavefront: t = 0 is knot 0 of the state rows (bottom wavefront only; x_0, its duals persist, its linear-cost term
+// reaches nothing); t >= 1 is slot t-1, i.e. state rows of knot s0+t and input rows of knot s0+t-1 (tinympc_solve_e.hip).
+// Semantics are EFamilies' (= upstream's update_slack / update_dual / update_linear_cost pattern, PARITY UNPINNED): rows of an
+// enabled side take part whether or not a cone contains them; cones of one round at once, rounds one after another; linear rows
+// one after another, row k of the state side and row k of the input side independently.
+template <int NX, int NU>
+struct KFamilies {
+    static constexpr int W = 16, NXU = NX + NU;
+    double gc[NXU], gl[NXU];  // the families' duals of this lane's knot
+    double rho;
+    bool cone_x, cone_u, lin_x, lin_u;  // (uniform) the family is enabled for the side
+    double mu_c[E_NCONE > 0 ? E_NCONE : 1], imu_c[E_NCONE > 0 ? E_NCONE : 1];  // (uniform) slope of cone c of the list and its reciprocal
+    const double *sLin;       // LDS: [E_NL][3][16]  a_k | b_k | 1/||a_k||^2, per ROW-layout lane (state lanes: the state side's row k)
+
+    __device__ __forceinline__ void init(const double *fam, int KT, const double *lin, double rho_) {
+        rho = rho_;
+        sLin = lin;
+        cone_x = fam[2 * W + 0] != 0.0;
+        cone_u = fam[2 * W + NX] != 0.0;
+        lin_x = fam[3 * W + 0] != 0.0;
+        lin_u = fam[3 * W + NX] != 0.0;
+        const double *cone_mu = fam + fam_cone_mu_offset(W, KT);
+        e_static_for<0, E_NCONE>([&](auto Cc) {
+            mu_c[Cc.value] = cone_mu[Cc.value];
+            imu_c[Cc.value] = 1.0 / cone_mu[Cc.value];
+        });
+    }
+    // one cone {F .. L}, L its t row, on the knot's slack vector (soc_project_element's arithmetic, once per knot)
+    template <int F, int L>
+    static __device__ __forceinline__ void project_cone(double (&sv)[NXU], double mu, double inv_mu) {
+        double a2 = 0.0;
+        e_static_for<F, L>([&](auto K) { a2 = (K.value == F) ? sv[K.value] * sv[K.value] : __builtin_fma(sv[K.value], sv[K.value], a2); });
+        const double t = sv[L];
+        const double u0 = t * mu;
+        const double a2c = fmax(a2, 1e-300);  // a2 = 0 -> the `inside` / `apex` cases below decide, never the quotient
+        double y = __builtin_amdgcn_rsq(a2c);
+        double g = a2c * y, h = 0.5 * y;
+        double rr = fma(-g, h, 0.5);
+        g = fma(g, rr, g);
+        h = fma(h, rr, h);
+        rr = fma(-g, h, 0.5);
+        g = fma(g, rr, g);
+        h = fma(h, rr, h);
+        const double d = fma(-g, g, a2c);
+        const double a = fma(d, h, g);   // sqrt(a2)
+        const double inv_a = h + h;      // 1 / sqrt(a2)
+        const double scale = 0.5 * (1.0 + u0 * inv_a);
+        const bool apex = a <= -u0, inside = a <= u0;
+        const double tproj = scale * (a * inv_mu);
+        e_static_for<F, L>([&](auto K) { sv[K.value] = apex ? 0.0 : (inside ? sv[K.value] : scale * sv[K.value]); });
+        sv[L] = apex ? 0.0 : (inside ? t : tproj);
+    }
+    // val: the knot's x | u rows; lx: the families' contribution to the linear cost of every row (overwritten)
+    __device__ __forceinline__ void eval(const double (&val)[NXU], double (&lx)[NXU]) {
+        e_static_for<0, NXU>([&](auto R) { lx[R.value] = 0.0; });
+        if constexpr (E_NCONE > 0) {
+            double sv[NXU];
+            e_static_for<0, NXU>([&](auto R) { sv[R.value] = val[R.value] + gc[R.value]; });
+            e_static_for<0, E_NROUND>([&](auto Rd) {
+                e_static_for<0, E_NCONE>([&](auto Cc) {
+                    constexpr EConeDesc cd = E_CONES[Cc.value];
+                    if constexpr (cd.round == Rd.value) project_cone<cd.first, cd.last>(sv, mu_c[Cc.value], imu_c[Cc.value]);
+                });
+            });
+            e_static_for<0, NXU>([&](auto R) {
+                constexpr int r = R.value;
+                const bool on = r < NX ? cone_x : cone_u;
+                const double gcn = (val[r] + gc[r]) - sv[r];
+                if (on) {
+                    gc[r] = gcn;
+                    lx[r] -= rho * (sv[r] - gcn);
+                }
+            });
+        }
+        if constexpr (E_NL > 0) {
+            double sv[NXU];
+            e_static_for<0, NXU>([&](auto R) { sv[R.value] = val[R.value] + gl[R.value]; });
+            auto row = [&](int k) {
+                const double *ak = sLin + (size_t)(3 * k + 0) * W, *bk = sLin + (size_t)(3 * k + 1) * W, *ik = sLin + (size_t)(3 * k + 2) * W;
+                if (k < E_NLX) {
+                    double dot = 0.0;
+                    e_static_for<0, NX>([&](auto R) { dot = (R.value == 0) ? ak[R.value] * sv[R.value] : __builtin_fma(ak[R.value], sv[R.value], dot); });
+                    const double dist = (dot - bk[0]) * ik[0];
+                    const bool viol = dot > bk[0];
+                    e_static_for<0, NX>([&](auto R) { sv[R.value] = viol ? fma(-dist, ak[R.value], sv[R.value]) : sv[R.value]; });
+                }
+                if (k < E_NLU) {
+                    double dot = 0.0;
+                    e_static_for<NX, NXU>([&](auto R) { dot = (R.value == NX) ? ak[R.value] * sv[R.value] : __builtin_fma(ak[R.value], sv[R.value], dot); });
+                    const double dist = (dot - bk[NX]) * ik[NX];
+                    const bool viol = dot > bk[NX];
+                    e_static_for<NX, NXU>([&](auto R) { sv[R.value] = viol ? fma(-dist, ak[R.value], sv[R.value]) : sv[R.value]; });
+                }
+            };
+            if constexpr (E_NL <= 4) {
+                e_static_for<0, E_NL>([&](auto K) { row(K.value); });
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < E_NL; ++k) row(k);
+            }
+            e_static_for<0, NXU>([&](auto R) {
+                constexpr int r = R.value;
+                const bool on = r < NX ? lin_x : lin_u;
+                const double gln = (val[r] + gl[r]) - sv[r];
+                if (on) {
+                    gl[r] = gln;
+                    lx[r] -= rho * (sv[r] - gln);
+                }
+            });
+        }
+    }
+};
+
 }  // namespace tinympc
