@@ -179,6 +179,25 @@
     "v_add_f64 %[t], %[v], -%[sn]\n\t"             \
     "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
 #define D_WAIT "s_waitcnt lgkmcnt(0)"
+// The same row-local block for the element of the PREVIOUS step (%[ap], its slot's g / v / bounds), woven into the chain of the
+// current step one instruction per column (layout E, round 4): the block is a dependent sequence of its own, the chain another, and a
+// wavefront issues in order -- back to back each instruction waits for its predecessor's result (~8 cycles for FP64), interleaved
+// the two sequences fill each other's gaps. Columns the system does not have emit nothing; the block's instructions keep their order.
+#define D_P1 "v_add_f64 %[s], %[ap], %[g]\n\t"
+#define D_P2 "v_max_f64 %[sn], %[lo], %[s]\n\t"
+#define D_P3 "v_min_f64 %[sn], %[hi], %[sn]\n\t"
+#define D_P4 "v_add_f64 %[g], %[s], -%[sn]\n\t"
+#define D_P5 "v_add_f64 %[t], %[ap], -%[sn]\n\t"
+#define D_P6 "v_max_f64 %[pri], %[pri], |%[t]|\n\t"
+#define D_P7 "v_add_f64 %[t], %[v], -%[sn]\n\t"
+#define D_P8 "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
+#define D_CHAIN_WOVEN D_C0 D_P1 D_C1 D_P2 D_C2 D_P3 D_C3 D_P4 D_C4 D_P5 D_C5 D_P6 D_C6 D_P7 D_C7 D_P8 D_C8 D_C9 D_C10 D_C11 D_C12 D_C13 D_C14 D_C15
+#define D_PROJECT_PREV D_P1 D_P2 D_P3 D_P4 D_P5 D_P6 D_P7 D_P8
+// ... and the backward step's tail (the next steps' linear-cost terms, independent of this step's chain) woven in the same way
+#define D_T1 "v_add_f64 %[t], %[v2], -%[g2]\n\t"
+#define D_T2 "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
+#define D_T3 "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t"
+#define D_CHAIN_BWD_WOVEN D_C0 D_T1 D_C1 D_C2 D_T2 D_C3 D_T3 D_C4 D_C5 D_C6 D_C7 D_C8 D_C9 D_C10 D_C11 D_C12 D_C13 D_C14 D_C15
 
 namespace tinympc {
 
@@ -206,6 +225,24 @@ struct DStep<D_NX, D_NU> {
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), D_MOPS);
         return a;
     }
+    // Forward step with the row-local block of the PREVIOUS step woven into its chain (layout E): returns a = cf + Mf * [x; d];
+    // (ap, g, v, lo, hi) belong to the previous step's slot: ap its element (the `a` that step returned -- usually `x` itself, but
+    // the caller decides), g and v are updated in place.
+    static __device__ __forceinline__ double fwd_reg_woven(double x, double d, const double (&m)[16], double cf, double ap, double lo, double hi,
+                                                           double &g, double &v, double &pri, double &dua) {
+        double a, s, t, sn;
+        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN_WOVEN D_MOV64 " %[v], %[sn]\n\t" D_WAIT
+                     : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
+                     : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [ap] "v"(ap), [lo] "v"(lo), [hi] "v"(hi), D_MOPS);
+        return a;
+    }
+    // ... and the row-local block alone, for the last step of a sweep
+    static __device__ __forceinline__ void project_prev(double ap, double lo, double hi, double &g, double &v, double &pri, double &dua) {
+        double s, t, sn;
+        asm volatile(D_PROJECT_PREV "v_mov_b64 %[v], %[sn]"
+                     : [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
+                     : [ap] "v"(ap), [lo] "v"(lo), [hi] "v"(hi));
+    }
     // The bare sweep step a = c + M * [x; d] -- no row-local block behind it (layout E: pass 1 of a chunk and the carry
     // recurrences, tinympc_solve_e.hip). Back to back, `x` is the `a` the previous block's last FMA wrote: the block's own
     // s_waitcnt, the accumulator's start and an `s_nop 1` are the wait states in front of the first DPP read.
@@ -229,6 +266,14 @@ struct DStep<D_NX, D_NU> {
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
                      "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
+                     : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
+                     : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
+    }
+    // ... the same step with its tail woven into the chain (layout E)
+    static __device__ __forceinline__ void bwd_woven(double &a, double x, double d, const double (&m)[16], double v2, double g2,
+                                                     double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
+        double t;
+        asm volatile(D_HAZ D_CHAIN_BWD_WOVEN D_WAIT
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
     }
@@ -274,6 +319,20 @@ struct DStep<D_NX, D_NU> {
 #undef D_CHAIN
 #undef D_MOPS
 #undef D_PROJECT
+#undef D_P1
+#undef D_P2
+#undef D_P3
+#undef D_P4
+#undef D_P5
+#undef D_P6
+#undef D_P7
+#undef D_P8
+#undef D_CHAIN_WOVEN
+#undef D_PROJECT_PREV
+#undef D_T1
+#undef D_T2
+#undef D_T3
+#undef D_CHAIN_BWD_WOVEN
 #undef D_WAIT
 #undef D_NX
 #undef D_NU

@@ -51,6 +51,10 @@
 #define TINY_JIT_E_GL_LDS 0
 #define TINY_JIT_E_LX_LDS 0
 #define TINY_JIT_E_KFAM 1
+#define TINY_JIT_E_DREG 1
+#endif
+#ifndef TINY_JIT_E_DREG
+#define TINY_JIT_E_DREG 0
 #endif
 #ifndef TINY_JIT_E_KFAM
 #define TINY_JIT_E_KFAM 0
@@ -72,6 +76,33 @@ struct DStep;  // tinympc_solve_d_chain.h
 #define TINY_E_EXP 0
 #endif
 
+// 9: the shader clock at the phase boundaries of iteration 10, per wavefront, left in sol_x of the workgroup's first instance
+// (tools/e_breakdown.py --stamps prints them)
+#if TINY_E_EXP == 9
+#define E_STAMP(k) do { if (it0 == 10) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define E_STAMP(k) do { } while (0)
+#endif
+
+// Issue priority between the two wavefronts of a SIMD (experiments, TINY_E_PRIO): 0 none, 1 the wavefront in the odd slot leads for
+// the whole kernel, 2 wall-clock slices of 2^TINY_E_PRIO_SHIFT x 10 ns sampled at every sweep step, 3 feedback from the barriers:
+// whoever waited less than TINY_E_PRIO_TH cycles at the last barrier (i.e. came late) leads until the next one
+#ifndef TINY_E_PRIO
+#define TINY_E_PRIO 0
+#endif
+// Woven sweep steps (tinympc_solve_d_chain.h: fwd_reg_woven / bwd_woven): the row-local block of slot q-1 rides between the chain
+// instructions of slot q, the backward tail between those of its own step. A wavefront issues in order and every FP64 result takes
+// ~8 cycles to come back: two dependent sequences interleaved fill each other's gaps (-DTINY_E_WOVEN=0: the blocks back to back).
+#ifndef TINY_E_WOVEN
+#define TINY_E_WOVEN 1
+#endif
+#ifndef TINY_E_PRIO_SHIFT
+#define TINY_E_PRIO_SHIFT 4
+#endif
+#ifndef TINY_E_PRIO_TH
+#define TINY_E_PRIO_TH 300
+#endif
+
 namespace tinympc {
 
 #ifdef TINY_E_FIRST
@@ -84,7 +115,9 @@ constexpr int E_GROUP = 8;  // ... and between two later ones
 
 // KFAM: the families evaluated one KNOT per lane, once per iteration (KFamilies, tinympc_solve_e_common.h) instead of one (row,
 // knot) element per lane in every slot of the sweep; the placement flags GC_LDS / GL_LDS / LX_LDS belong to the element form.
-template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS, bool KFAM>
+// DREG: the feed-forward d of the wavefront's slots in registers too (2 S VGPRs) instead of its LDS region: the backward chain
+// leaves d_s on the input lanes, exactly where the forward chain's DPP columns read it.
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS, bool KFAM, bool DREG>
 __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double *smem) {
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
@@ -160,10 +193,11 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     auto g_row = [&](int i) -> int { return real(i) ? (s0 + i + koff) : N; };
     auto v_row = [&](int i) -> int { return real(i) ? (s0 + i + koff) : N; };
 
-    for (int i = lane; i < S * DS; i += 64) {
-        const int row = i / DS;
-        sD[i] = (s0 + row < NS) ? gD[(size_t)(s0 + row) * DS + i % DS] : 0.0;
-    }
+    if constexpr (!DREG)
+        for (int i = lane; i < S * DS; i += 64) {
+            const int row = i / DS;
+            sD[i] = (s0 + row < NS) ? gD[(size_t)(s0 + row) * DS + i % DS] : 0.0;
+        }
     if constexpr (FAM) {
         const double *const gGC = p.GC + vbase + lane, *const gGL = p.GL + vbase + lane;
         if (r < NXU) {
@@ -175,6 +209,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         }
     }
     if constexpr (KF) {
+        for (int i = lane; i < kfam_doubles(NXU, S); i += 64) sKX[i] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (bottom && r < NXU) sKX[kxRow] = (inst_ok && is_x) ? p.x0[inst * NX + r] : 0.0;  // entry 0: x_0 (constant over the solve)
     }
     if (bottom) {  // knot 0 of the state rows and x0
@@ -187,10 +223,11 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     __syncthreads();  // (the only barrier that also waits for global loads)
 
     // ---- register-resident state of this wavefront's slots
-    double G[S], V[S];
+    double G[S], V[S], DR[DREG ? S : 1];
     e_static_for<0, S>([&](auto I) {
         G[I.value] = gG[(size_t)g_row(I.value) * 64];
         V[I.value] = gV0[(size_t)v_row(I.value) * 64];
+        if constexpr (DREG) DR[I.value] = (is_u && s0 + I.value < NS) ? gD[(size_t)(s0 + I.value) * DS + j * NU + (r - NX)] : 0.0;
     });
     double GC[(FAM && !KF && !GC_LDS) ? S : 1], GLr[(FAM && !KF && !GL_LDS) ? S : 1], LX[(FAM && !KF && !LX_LDS) ? S : 1];
     if constexpr (FAM && !KF) {
@@ -273,6 +310,29 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         return base;
     };
 
+#if TINY_E_EXP == 9
+    unsigned long long stamp[10] = {};
+#endif
+    const unsigned simd_slot = (unsigned)simd_slot_id();
+    if (TINY_E_PRIO == 1 && (simd_slot & 1u)) __builtin_amdgcn_s_setprio(3);
+    auto prio_tick = [&]() {
+        if constexpr (TINY_E_PRIO == 2) {
+            const unsigned sl = (unsigned)(__builtin_amdgcn_s_memrealtime() >> TINY_E_PRIO_SHIFT);
+            if ((sl ^ simd_slot) & 1u) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    auto barrier_fb = [&]() {  // the workgroup barrier, with the priority feedback of TINY_E_PRIO == 3
+        if constexpr (TINY_E_PRIO == 3) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            e_barrier();
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            if (t1 - t0 < (unsigned long long)TINY_E_PRIO_TH) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        } else {
+            e_barrier();
+        }
+    };
     const int max_iter = p.max_iter;
     for (int it = 0; max_iter > 0; ++it) {  // admm.cpp:129
         const int it0 = __builtin_amdgcn_readfirstlane(it);
@@ -324,8 +384,14 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 }
                 if (!x_o) {
                     double *const wD = p.D + (size_t)grp * (NS * DS) + j_o * NU + (r_o - NX);
-                    for (int i = 0; i < S; ++i)
-                        if (s0 + i < NS) wD[(size_t)(s0 + i) * DS] = sD[i * DS + dIdx];
+                    if constexpr (DREG) {
+                        e_static_for<0, S>([&](auto I) {
+                            if (s0 + I.value < NS) wD[(size_t)(s0 + I.value) * DS] = DR[I.value];
+                        });
+                    } else {
+                        for (int i = 0; i < S; ++i)
+                            if (s0 + i < NS) wD[(size_t)(s0 + i) * DS] = sD[i * DS + dIdx];
+                    }
                 }
             }
             if constexpr (KF) {  // the families' duals leave from the knot-per-lane layout (wb is uniform over an instance's 16 lanes)
@@ -351,6 +417,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         }
         if (final_round || __ballot(active) == 0ull) break;  // (uniform over the workgroup: termination is decided jointly)
         const int it1 = it0 + 1;
+        E_STAMP(0);
         const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && ((it1 % ct) == 0))) != 0;  // admm.cpp:91
 
         // One ADMM iteration of this wavefront's chunk: S slots, of which the last wavefront owns only the first S_LAST -- ONE copy of
@@ -361,21 +428,28 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // ================= forward, pass 1: the chunk's end state from a zero incoming state =================
             {
                 double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
-                double dcur = e_lds_read_async<0>(aD);
-                e_lds_wait();
+                double dcur = 0.0;
+                if constexpr (!DREG) {
+                    dcur = e_lds_read_async<0>(aD);
+                    e_lds_wait();
+                }
 #if TINY_E_EXP != 3 && TINY_E_EXP != 5
                 e_static_for<0, S>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     double dn = 0.0;
-                    if constexpr (i + 1 < S) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
+                    if constexpr (DREG) dcur = DR[i];
+                    else if constexpr (i + 1 < S) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
+                    prio_tick();
                     if constexpr (i < S_LAST) xt = Step::fwd_plain(xt, dcur, m, cf);
                     else if (!top) xt = Step::fwd_plain(xt, dcur, m, cf);
-                    dcur = dn;
+                    if constexpr (!DREG) dcur = dn;
                 });
 #endif
                 sE[wv * 64 + lane] = xt;
             }
-            e_barrier();
+            E_STAMP(1);
+            barrier_fb();
+            E_STAMP(2);
             // the true state entering the chunk: X_w = Phi^S X_(w-1) + e_(w-1), X_1 = e_0
             double xin = 0.0;
             if (!bottom) {
@@ -410,10 +484,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 }
                 xin = x0v;
             }
+            E_STAMP(3);
             double xcur = xin;
             {
-                double dcur = e_lds_read_async<0>(aD);
+                double dcur = 0.0;
+                if constexpr (!DREG) dcur = e_lds_read_async<0>(aD);
                 double locur = lo_c, hicur = hi_c, glcur = 0.0, gccur = 0.0;
+                double loprev = lo_c, hiprev = hi_c, xprev = 0.0;  // (woven steps: the previous slot's bounds and element)
                 if constexpr (!CT) {
                     locur = e_lds_read_async<W * 8>(aT);
                     hicur = e_lds_read_async<(TOFF + W) * 8>(aT);
@@ -424,14 +501,25 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 auto fstep = [&](auto Q) {
                     constexpr int q = decltype(Q)::value;
                     double dn = 0.0, lon = lo_c, hin = hi_c, gln_next = 0.0, gcn_next = 0.0;
-                    if constexpr (q + 1 < S) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
+                    if constexpr (DREG) dcur = DR[q];
+                    else if constexpr (q + 1 < S) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
                     if constexpr (!CT && q + 1 < S) {
                         lon = e_lds_read_async<(q + 2) * W * 8>(aT);
                         hin = e_lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
                     }
                     if constexpr (GCL && q + 1 < S) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
                     if constexpr (GLL && q + 1 < S) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
-                    xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);
+                    prio_tick();
+                    if constexpr (!TINY_E_WOVEN || q == 0) {
+                        xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);  // (slot 0 complete: the first "can it still converge" test reads it)
+                    } else if constexpr (q == 1) {
+                        xprev = xcur = Step::fwd_plain(xcur, dcur, m, cf);  // its row-local block rides on step 2
+                    } else {
+                        const double xp = xprev;  // slot q-1's element = this step's state operand on state lanes, u_(q-1) on input lanes
+                        xprev = xcur = Step::fwd_reg_woven(xcur, dcur, m, cf, xp, loprev, hiprev, G[q - 1], V[q - 1], pri, dua);
+                    }
+                    loprev = locur;
+                    hiprev = hicur;
                     // (KF) this slot's element -- x_{q+1} on state lanes, u_q on input lanes -- goes up to its knot's lane
                     if constexpr (KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) e_lds_write_masked<(q + 1) * ES * 8>(aKX, xcur, mask_real);
                     if constexpr (FAM && !KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
@@ -449,7 +537,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         if constexpr (LX_LDS) e_lds_write_masked<q * RS * 8>(aLX, l, mask_real);
                         else LX[q] = l;
                     }
-                    dcur = dn;
+                    if constexpr (!DREG) dcur = dn;
                     glcur = gln_next;
                     gccur = gcn_next;
                     if constexpr (!CT) {
@@ -484,8 +572,17 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         else if (!top) fstep(Q);
                     });
                 });
+                if constexpr (TINY_E_WOVEN != 0) {  // the row-local block of the sweep's last slot (every chunk has >= 3 slots)
+                    if constexpr (S_LAST == S) {
+                        Step::project_prev(xprev, loprev, hiprev, G[S - 1], V[S - 1], pri, dua);
+                    } else {
+                        if (top) Step::project_prev(xprev, loprev, hiprev, G[S_LAST - 1], V[S_LAST - 1], pri, dua);
+                        else Step::project_prev(xprev, loprev, hiprev, G[S - 1], V[S - 1], pri, dua);
+                    }
+                }
             }
             if (active) it_done = it1;  // admm.cpp:143
+            E_STAMP(4);
 
             // ---- (KF) the families of all slots of this wavefront at once, one knot per lane: rows in, projections, duals, the
             // linear-cost term out through the same entry (read again by both backward passes; entry 0 keeps x_0)
@@ -519,6 +616,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // chain of a chunk of n slots: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
             // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
             // which the chunk below owns.
+            E_STAMP(5);
             load_ops(sMb, m);
             auto bwd_chain = [&](double cin, auto STORE) -> double {
                 constexpr bool store = decltype(STORE)::value;
@@ -562,8 +660,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     const double lrmc2 = (s >= 2) ? (is_x ? lr2 + cb : cb) : cb;
                     const double rh = (s >= 2) ? rhom : 0.0;
                     double a = acc, an, rn;
-                    Step::bwd(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
-                    if constexpr (store) e_lds_write_masked<s * DS * 8>(aD, a, wr_d);  // d_s
+                    prio_tick();
+                    if constexpr (TINY_E_WOVEN != 0) Step::bwd_woven(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
+                    else Step::bwd(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
+                    if constexpr (store) {  // d_s
+                        if constexpr (DREG) e_reg_write_masked(DR[s], a, wr_d);
+                        else e_lds_write_masked<s * DS * 8>(aD, a, wr_d);
+                    }
                     px = a;
                     rcur = rnext;
                     rnext = rn;
@@ -582,7 +685,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 e_static_for<0, S_LAST - 1>([&](auto I) { block(std::integral_constant<int, S_LAST - 1 - I.value>{}); });  // S_LAST-1 .. 1
                 double a = acc;
                 Step::bwd_last(a, px, rcur, m);
-                if constexpr (store) e_lds_write_masked<0>(aD, a, wr_d);  // d of the chunk's first slot
+                if constexpr (store) {  // d of the chunk's first slot
+                    if constexpr (DREG) e_reg_write_masked(DR[0], a, wr_d);
+                    else e_lds_write_masked<0>(aD, a, wr_d);
+                }
                 return a;
             };
             // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
@@ -594,7 +700,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 #endif
                 sB[wv * 64 + lane] = e2;
             }
-            e_barrier();
+            E_STAMP(6);
+            barrier_fb();
+            E_STAMP(7);
             // ---- termination, decided jointly: an instance converged iff every wavefront saw all of its lanes below tolerance
             if (check) {
                 int all = 0xf;
@@ -623,7 +731,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 load_ops(sMb, m);
             }
             // pass 2: the real sweep; only d is kept
+            E_STAMP(8);
             (void)bwd_chain(is_x ? cin : 0.0, std::true_type{});
+            E_STAMP(9);
         }
     }
     e_lds_wait();
@@ -641,6 +751,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
         }
     }
 
+#if TINY_E_EXP == 9
+    if (lane < 10 && grp * IPW < p.batch) p.sol_x[(size_t)grp * IPW * N * NX + wv * 10 + lane] = (double)(stamp[lane] - stamp[0]);
+#endif
     // the four residual norms of the last check: rows, then wavefronts through LDS
     const double gpx = group_max<W>(is_x ? snap_pri : 0.0), gpu = group_max<W>(is_u ? snap_pri : 0.0);
     const double gdx = group_max<W>(is_x ? snap_dua : 0.0), gdu = group_max<W>(is_u ? snap_dua : 0.0);
@@ -672,10 +785,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
 tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
-    constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0;
+    constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0, DRJ = TINY_JIT_E_DREG != 0;
     constexpr int nlds = !FAMJ ? 0 : KFJ ? -1 : (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0);
     constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds);
     static_assert(bytes <= 160 * 1024, "layout E: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_e[bytes / sizeof(double)];
-    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ>(p, smem_e);
+    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ, DRJ>(p, smem_e);
 }

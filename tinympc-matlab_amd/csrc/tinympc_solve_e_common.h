@@ -50,6 +50,16 @@ __device__ __forceinline__ void e_lds_write_masked(unsigned addr, double v, unsi
                  : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
                  : "memory", "scc");
 }
+// dst <- v on the lanes of `mask` only (a register-resident array element that some instances of the wavefront must keep)
+__device__ __forceinline__ void e_reg_write_masked(double &dst, double v, unsigned long long mask) {
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "v_mov_b64 %[d], %[v]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [d] "+v"(dst)
+                 : [m] "s"(mask), [v] "v"(v)
+                 : "scc");
+}
 __device__ __forceinline__ void e_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // workgroup barrier that waits for this wavefront's LDS traffic only (not for its global stores, as __syncthreads() would)
 #if defined(TINY_E_EXP) && (TINY_E_EXP == 4 || TINY_E_EXP == 5)  // (timing experiment: no barrier)
