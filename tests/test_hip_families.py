@@ -271,7 +271,7 @@ def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
         assert np.all(s.get_stats_batch()["iter"] > 0)
         s.reset()
         return
-    assert s.launch_info()["layout"] == "E" and (info.startswith("compiled ") or info.startswith("disk-cache ")) and "scratch=0" in info, info
+    assert s.launch_info()["layout"] == "E" and info.startswith(("compiled ", "disk-cache ", "compiled-in ")) and "scratch=0" in info, info
     out = []
     for x0s in (x0a, x0b):
         s.set_x0_batch(x0s)
@@ -553,7 +553,7 @@ def test_layout_f_the_specialised_latency_kernel(pkg, kernel_layout, monkeypatch
         assert s.launch_info()["layout"] == ("F" if rnd < 2 else "A" if variant == "overlap" else "C"), s.jit_info()
         if rnd == 0:
             info = s.jit_info()
-            assert (info.startswith("compiled ") or info.startswith("disk-cache ")) and "layout=F" in info and "scratch=0" in info, info
+            assert info.startswith(("compiled ", "disk-cache ", "compiled-in ")) and "layout=F" in info and "scratch=0" in info, info
         if batch == 1:
             one, st1 = s.get_solution(), s.get_stats()
             sol = dict(states=one["states"][:, :, None], controls=one["controls"][:, :, None])

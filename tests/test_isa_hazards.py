@@ -7,6 +7,7 @@ they are there, a fresh `hipcc -S` otherwise)."""
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 
@@ -41,8 +42,11 @@ def test_every_solve_source_is_linted_by_the_build():
     assert set(SOURCES) <= set(ge.HIP_LINTED), "a solve kernel source is missing from the build's ISA lint"
     on_disk = {f for f in os.listdir(CSRC) if f.startswith("tinympc_solve") and f.endswith(".hip")}
     no_dpp_chain = {"tinympc_solve_m.hip"}  # the matrix-core kernel: no DPP operand anywhere
-    run_time_only = set(ge.HIP_LINT_ONLY)   # exist as run-time specialisations only; the build lints their default instance
+    # layouts E and F exist as specialisations only: the ones BASELINE config 4 needs are compiled in and linted by the build
+    # (HIP_BUILTINS), every other one is compiled at run time from the same source with a hazard s_nop in front of every chain block
+    run_time_only = {e[1] for e in ge.HIP_BUILTINS}
     assert run_time_only == {"tinympc_solve_e.hip", "tinympc_solve_f.hip"}
+    assert [e[0] for e in ge.HIP_BUILTINS] == ["k_builtin_e_rocket100", "k_builtin_f_rocket100"]
     assert on_disk - no_dpp_chain - run_time_only == set(SOURCES), "new solve kernel source: add it to SOURCES here and to HIP_LINTED in __graft_entry__.py"
     for f in no_dpp_chain:
         assert "_dpp" not in open(os.path.join(CSRC, f)).read()
@@ -113,12 +117,35 @@ def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, 
     assert ".private_segment_fixed_size: 0" in text, "the specialisation spills to scratch memory"
 
 
+def test_compiled_in_specialisations_are_linted_and_do_not_spill():
+    """BASELINE config 4's kernels (layout E for batches, layout F for one instance) are compiled in with the BARE chain blocks: the
+    build's ISA lint is what stands between them and the DPP hazard, and their descriptors must show no scratch."""
+    import __graft_entry__ as ge
+    for name, source, defs in ge.HIP_BUILTINS:
+        path = ge.builtin_asm_path(name)
+        if not os.path.exists(path):
+            pytest.skip("no build assembly (run __graft_entry__.build())")
+        text = open(path).read()
+        checked, bad = _lint(text)
+        assert checked > 100 and not bad, (name, bad[:3])
+        assert ".amdhsa_kernel " + name in text and ".private_segment_fixed_size: 0" in text and "vgpr_spill_count: 0" in text, name
+        # bare blocks: only the back-to-back chains of pass 1 / the carry recurrences (fwd_plain) keep their own s_nop; the sweep
+        # blocks proper start without one (the run-time builds put one in front of every chain)
+        chains = len(re.findall(r"v_fmac_f64_dpp [^\n]* row_newbcast:0 ", text))
+        with_nop = len(re.findall(r"s_nop 1\n\t\.p2align 3\n\tv_fmac_f64_dpp", text))
+        assert chains > with_nop + 10, (name, chains, with_nop)
+
+
 E_ROCKET = dict(nround=1, ncone=2, cones="{0,0,2},{0,6,8}", nlx=1, nlu=0)
+# lds: the element form's placement (gc, gl, lx in LDS), or "k" = the families one knot per lane (KFamilies), "kd" = ... and d in registers
 @pytest.mark.parametrize("nx,nu,N,ct,wpg,S,fam,lds", [
-    (6, 3, 100, 0, 8, 13, E_ROCKET, (1, 1, 1)),   # BASELINE config 4 as bench.py runs it (the build lints the same instance)
-    (6, 3, 100, 1, 8, 13, E_ROCKET, (1, 1, 1)),   # ... with constant tables
-    (6, 3, 44, 0, 4, 11, E_ROCKET, (0, 0, 0)),    # one wavefront per SIMD, everything in registers
+    (6, 3, 100, 0, 8, 13, E_ROCKET, "kd"),        # BASELINE config 4 as bench.py runs it (compiled in with these options, but bare blocks)
+    (6, 3, 100, 1, 8, 13, E_ROCKET, "kd"),        # ... with constant tables
+    (6, 3, 100, 0, 8, 13, E_ROCKET, (1, 1, 1)),   # the element form of the families, all three arrays in LDS
+    (6, 3, 44, 0, 4, 11, E_ROCKET, "k"),          # four wavefronts per workgroup
     (12, 4, 60, 1, 8, 8, dict(nround=2, ncone=3, cones="{0,0,2},{0,12,15},{1,1,4}", nlx=2, nlu=1), (0, 1, 1)),  # overlapping cones, rows on both sides
+    (8, 4, 60, 1, 8, 8, dict(nround=2, ncone=3, cones="{0,0,2},{0,8,11},{1,1,4}", nlx=2, nlu=1), "k"),          # ... one knot per lane (12 rows, d in LDS: what the plan picks; it refuses 16 rows)
+    (6, 3, 100, 1, 8, 13, dict(nround=1, ncone=1, cones="{0,6,8}", nlx=12, nlu=5), "k"),                        # many linear rows: the run-time loop (with d in registers it spills: the next placement)
     (12, 4, 200, 1, 8, 25, None, (0, 0, 0)),      # box path only, a horizon beyond layout D's plans
 ])
 def test_layout_e_specialisations_have_no_dpp_hazard_and_no_scratch(nx, nu, N, ct, wpg, S, fam, lds, tmp_path):
@@ -134,7 +161,8 @@ def test_layout_e_specialisations_have_no_dpp_hazard_and_no_scratch(nx, nu, N, c
                     "-DTINY_JIT=1", f"-DTINY_JIT_NX={nx}", f"-DTINY_JIT_NU={nu}", f"-DTINY_JIT_N={N}", f"-DTINY_JIT_CT={ct}", f"-DTINY_JIT_FAM={1 if fam else 0}",
                     f"-DTINY_JIT_E_WPG={wpg}", f"-DTINY_JIT_E_WPS={wpg // 4}", f"-DTINY_JIT_E_S={S}", f"-DTINY_JIT_E_NROUND={f['nround']}", f"-DTINY_JIT_E_NCONE={f['ncone']}",
                     f"-DTINY_JIT_E_CONES={f['cones']}", f"-DTINY_JIT_E_NLX={f['nlx']}", f"-DTINY_JIT_E_NLU={f['nlu']}",
-                    f"-DTINY_JIT_E_GC_LDS={lds[0]}", f"-DTINY_JIT_E_GL_LDS={lds[1]}", f"-DTINY_JIT_E_LX_LDS={lds[2]}",
+                    *([f"-DTINY_JIT_E_GC_LDS=0", "-DTINY_JIT_E_GL_LDS=0", "-DTINY_JIT_E_LX_LDS=0", "-DTINY_JIT_E_KFAM=1", f"-DTINY_JIT_E_DREG={1 if lds == 'kd' else 0}"]
+                      if isinstance(lds, str) else [f"-DTINY_JIT_E_GC_LDS={lds[0]}", f"-DTINY_JIT_E_GL_LDS={lds[1]}", f"-DTINY_JIT_E_LX_LDS={lds[2]}"]),
                     "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "tinympc_solve_e.hip")], check=True, timeout=900)
     text = out.read_text()
     checked, bad = _lint(text)
@@ -202,8 +230,8 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
         **{("tinympc_solve_m.hip", "_ZN7tinympc14k_admm_solve_mILi%dELb0EEEvNS_11SolveParamsE" % r): 64 for r in (13, 14, 15)},
     }
     seen = refill = 0
-    for source in ge.HIP_SOURCES:
-        built = ge.device_asm_path(source)
+    for source in ge.HIP_SOURCES + [e[0] for e in ge.HIP_BUILTINS]:
+        built = ge.device_asm_path(source) if source.endswith(".hip") else ge.builtin_asm_path(source)
         if not os.path.exists(built):
             pytest.skip("no build assembly (run __graft_entry__.build())")
         text = open(built).read()

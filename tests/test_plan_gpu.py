@@ -26,16 +26,21 @@ CASES = [
     ("quadrotor50 single", lambda P: P.quadrotor(50), 1, "box", {}, "C", ("compiled-in",), 1),
     ("quadrotor50 x512", lambda P: P.quadrotor(50), 512, "box", {}, "C", ("compiled-in",), 512),
     ("quadrotor50 x2048", lambda P: P.quadrotor(50), 2048, "box", {}, "D", ("compiled-in",), 128),
-    ("quadrotor40 x2048", lambda P: P.quadrotor(40), 2048, "box", {}, "D", ("compiled", "disk-cache"), 128),
+    ("quadrotor40 x2048", lambda P: P.quadrotor(40), 2048, "box", {}, "D", ("compiled ", "disk-cache"), 128),
     ("quadrotor40 x2048 per-knot references", lambda P: P.quadrotor(40), 2048, "varying", {}, "D", ("compiled", "disk-cache"), None),
     ("quadrotor40 x2048 no specialiser", lambda P: P.quadrotor(40), 2048, "box", {"TINYMPC_JIT": "0"}, "B", ("refused(TINYMPC_JIT=0)",), 128),
     ("quadrotor200 x2048", lambda P: P.quadrotor(200), 2048, "box", {}, "E", ("compiled", "disk-cache"), 512),
     ("cartpole250 x2048", lambda P: P.cartpole(250, True), 2048, "box", {}, "E", ("compiled", "disk-cache"), 512),
     ("quadrotor50 x8192 adaptive rho", lambda P: P.quadrotor(50), 8192, "adaptive", {}, "D", ("compiled", "disk-cache"), None),
     ("quadrotor50 single adaptive rho", lambda P: P.quadrotor(50), 1, "adaptive", {}, "A", ("compiled-in",), 1),
-    ("rocket100 single", lambda P: P.rocket(100), 1, "families", {}, "F", ("compiled", "disk-cache"), 1),
-    ("rocket100 x200", lambda P: P.rocket(100), 200, "families", {}, "F", ("compiled", "disk-cache"), 200),
-    ("rocket100 x4096", lambda P: P.rocket(100), 4096, "families", {}, "E", ("compiled", "disk-cache"), 1024),
+    # BASELINE config 4 is COMPILED IN (round 4: __graft_entry__.HIP_BUILTINS -- layout F for one instance / small batches, layout E for
+    # batches); the same configuration with the compiled-in code switched off, or any other structure, is specialised at run time
+    ("rocket100 single", lambda P: P.rocket(100), 1, "families", {}, "F", ("compiled-in",), 1),
+    ("rocket100 x200", lambda P: P.rocket(100), 200, "families", {}, "F", ("compiled-in",), 200),
+    ("rocket100 x4096", lambda P: P.rocket(100), 4096, "families", {}, "E", ("compiled-in",), 1024),
+    ("rocket100 x4096 run-time compiled", lambda P: P.rocket(100), 4096, "families", {"TINYMPC_BUILTIN": "0"}, "E", ("compiled ", "disk-cache"), 1024),
+    ("rocket100 single run-time compiled", lambda P: P.rocket(100), 1, "families", {"TINYMPC_BUILTIN": "0"}, "F", ("compiled ", "disk-cache"), 1),
+    ("rocket44 x4096", lambda P: P.rocket(44), 4096, "families", {}, "E", ("compiled ", "disk-cache"), 1024),
     ("rocket10 x4096", lambda P: P.rocket(10), 4096, "families", {}, "D", ("compiled", "disk-cache"), None),
     ("rocket100 single no specialiser", lambda P: P.rocket(100), 1, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 1),
     ("rocket100 x4096 no specialiser", lambda P: P.rocket(100), 4096, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 4096),

@@ -33,7 +33,7 @@
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
 
-#ifndef TINY_JIT  // build-time instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
+#if !defined(TINY_JIT) && !defined(TINY_BUILTIN)  // stand-alone instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
 #define TINY_CHAIN_NOP 1  // the chain blocks as the run-time specialisations get them (tinympc_solve_d_chain.h)
 #define TINY_JIT_NX 6
 #define TINY_JIT_NU 3
@@ -782,8 +782,15 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 #ifndef TINY_JIT_E_WPS
 #define TINY_JIT_E_WPS (TINY_JIT_E_WPG / 4)  // wavefronts per SIMD: a workgroup of 8 shares a CU two by two (256 registers each)
 #endif
+// the entry point: `tinympc_jit_solve` as a run-time specialisation (tinympc_jit.hip looks it up by that name), the name the build
+// gives it as a compiled-in one (TINY_BUILTIN: __graft_entry__.HIP_BUILTINS)
+#ifdef TINY_BUILTIN
+#define TINY_KERNEL_NAME TINY_BUILTIN_NAME
+#else
+#define TINY_KERNEL_NAME tinympc_jit_solve
+#endif
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
-tinympc_jit_solve(const tinympc::SolveParams p) {
+TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
     constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0, DRJ = TINY_JIT_E_DREG != 0;
     constexpr int nlds = !FAMJ ? 0 : KFJ ? -1 : (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0);

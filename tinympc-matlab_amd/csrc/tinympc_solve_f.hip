@@ -25,7 +25,7 @@
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
 
-#ifndef TINY_JIT  // build-time instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
+#if !defined(TINY_JIT) && !defined(TINY_BUILTIN)  // stand-alone instance (ISA lint, "does it compile"): the rocket landing of BASELINE config 4
 #define TINY_CHAIN_NOP 1
 #define TINY_JIT_NX 6
 #define TINY_JIT_NU 3
@@ -448,8 +448,15 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
 }  // namespace tinympc
 
 // (two wavefronts per SIMD wherever the workgroup has more than four)
+// the entry point: `tinympc_jit_solve` as a run-time specialisation (tinympc_jit.hip looks it up by that name), the name the build
+// gives it as a compiled-in one (TINY_BUILTIN: __graft_entry__.HIP_BUILTINS)
+#ifdef TINY_BUILTIN
+#define TINY_KERNEL_NAME TINY_BUILTIN_NAME
+#else
+#define TINY_KERNEL_NAME tinympc_jit_solve
+#endif
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, (TINY_JIT_F_WPG + 3) / 4 > 2 ? (TINY_JIT_F_WPG + 3) / 4 : 2)))
-tinympc_jit_solve(const tinympc::SolveParams p) {
+TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
     constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL);
     static_assert(bytes <= 160 * 1024, "layout F: the workgroup's LDS plan exceeds a CU");
