@@ -424,11 +424,73 @@ def test_twelve_linear_rows_per_side(pkg, kernel_layout, monkeypatch, layout, N,
         assert st["iter"][b] == o.stats()["iter"] and st["status"][b] == o.stats()["status"], b
         assert rel_err(sol["states"][:, :, b], o.solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], o.solution()[1]) < TOL, b
     s.reset()
-    with pytest.raises(pkg.TinyMPCError) as ei:  # the buffer's limit
+    with pytest.raises(pkg.TinyMPCError) as ei:  # the hard limit of the buffer (128 rows per side)
         s2 = make(pkg, rk, settings)
-        s2.set_linear_constraints(np.ones((33, 6)), np.ones(33), np.zeros((0, 3)), np.zeros(0))
+        s2.set_linear_constraints(np.ones((129, 6)), np.ones(129), np.zeros((0, 3)), np.zeros(0))
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     s2.reset()
+
+
+def _rounds_of(cones):
+    """The grouping of a cone list into rounds of pairwise-disjoint cones, as the library does it (family_structure)."""
+    rounds, used = 0, set()
+    for first, dim in cones:
+        rows = set(range(first, first + dim))
+        if rounds == 0:
+            rounds = 1
+        if rows & used:
+            rounds += 1
+            used = set()
+        used |= rows
+    return rounds
+
+
+@pytest.mark.layouts("A")
+@pytest.mark.parametrize("batch,N", [(1, 30), (5, 100), (300, 100), (300, 20)])
+def test_shapes_beyond_the_generic_kernels_limits(pkg, kernel_layout, monkeypatch, batch, N):
+    """The reference forwards ANY constraint list (bindings.cpp:408-478, TinyMPC.m:296-317). Up to 32 linear rows per side, 16
+    cones and 4 rounds of overlapping cones every families kernel holds; beyond that (round 4) the family buffer is sized for the
+    configuration and the structure-specialised kernels run it: 80 state + 40 input linear rows, 20 cones in 7 rounds (state
+    cones that share rows, projected one after another as upstream does), on layout F (one instance / small batches) and
+    layout E (batches) -- against the restatement's sequential loops."""
+    monkeypatch.delenv("TINYMPC_LAYOUT")
+    rk = pkg.problems.rocket(N)
+    rng = np.random.default_rng(80)
+    Ax, bx = _many_rows(rng, 80, 6, np.array([0.0, 0.0, 5.0, 0.0, 0.0, 0.0]), 30.0)
+    Au, bu = _many_rows(rng, 40, 3, np.array([0.0, 0.0, 10.0]), 40.0)
+    rk.linear = dict(Alin_x=Ax, blin_x=bx, Alin_u=Au, blin_u=bu)
+    state_cones = [(0, 3), (3, 3), (1, 3), (4, 2), (0, 2), (2, 3), (5, 1), (0, 4), (4, 2), (1, 2), (3, 3), (0, 3), (2, 2), (4, 2)]
+    input_cones = [(0, 3), (0, 2), (1, 2), (2, 1), (0, 3), (1, 2)]
+    assert len(state_cones) + len(input_cones) == 20 and _rounds_of(state_cones + [(6 + f, d) for f, d in input_cones]) >= 6
+    rk.cones = dict(Acx=[c[0] for c in state_cones], qcx=[c[1] for c in state_cones], cx=list(rng.uniform(0.3, 0.9, len(state_cones))),
+                    Acu=[c[0] for c in input_cones], qcu=[c[1] for c in input_cones], cu=list(rng.uniform(0.2, 0.6, len(input_cones))))
+    settings = dict(max_iter=40, abs_pri_tol=1e-3, abs_dua_tol=1e-4)
+    s = make(pkg, rk, settings, batch=batch)
+    x0s = rk.x0[:, None] * rng.uniform(0.7, 1.1, (1, batch)) + 0.05 * rng.standard_normal((6, batch))
+    if batch > 1:
+        s.set_x0_batch(x0s)
+    else:
+        s.set_x0(x0s[:, 0])
+    s.solve()
+    assert s.launch_info()["layout"] == ("E" if batch >= 260 else "F"), s.jit_info()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    s.solve()  # warm, from the state the first solve left (the duals of every family persist)
+    sol2, st2 = s.get_solution_batch(), s.get_stats_batch()
+    for b in sorted({0, batch // 2, batch - 1}):
+        o = oracle(rk, settings)
+        o.set_x0(x0s[:, b])
+        for so, sto in ((sol, st), (sol2, st2)):
+            o.solve()
+            assert sto["iter"][b] == o.stats()["iter"] and sto["status"][b] == o.stats()["status"], b
+            assert rel_err(so["states"][:, :, b], o.solution()[0]) < TOL and rel_err(so["controls"][:, :, b], o.solution()[1]) < TOL, b
+    s.reset()
+    # without the run-time specialiser such a configuration has no kernel: a clear refusal, no silent fallback
+    monkeypatch.setenv("TINYMPC_JIT", "0")
+    s3 = make(pkg, rk, settings, batch=batch)
+    with pytest.raises(pkg.TinyMPCError) as ei:
+        s3.solve()
+    assert ei.value.code == pkg._lib.ERR_UNSUPPORTED and "run-time" in str(ei.value)
+    s3.reset()
 
 
 @pytest.mark.layouts("A")

@@ -660,9 +660,11 @@ int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, cons
     if ((nlx > 0 && (!Alin_x || !blin_x)) || (nlu > 0 && (!Alin_u || !blin_u)))
         return fail(TINYMPC_ERR_INVALID_INPUT, "set_linear_constraints: NULL matrix for a non-empty side");
     if (s->session_active && (rc = bind_device(s))) return rc;  // the resident kernel was started with the old families
-    if (nlx > MAX_LIN_ROWS || nlu > MAX_LIN_ROWS)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d linear rows per side are supported by the HIP kernel (got %d state, %d input)",
-                    MAX_LIN_ROWS, nlx, nlu);
+    // (up to MAX_LIN_ROWS rows per side every kernel holds; beyond, the structure-specialised kernels -- layouts E and F -- size
+    // their copies from the count itself: checked at launch, where the kernel is known)
+    if (nlx > HARD_MAX_LIN_ROWS || nlu > HARD_MAX_LIN_ROWS)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d linear rows per side are supported by the HIP kernels (got %d state, %d input)",
+                    HARD_MAX_LIN_ROWS, nlx, nlu);
     auto zero_row = [](const double *A, int rows, int cols, int k) {
         for (int c = 0; c < cols; ++c)
             if (A[k + (size_t)c * rows] != 0.0) return false;
@@ -694,7 +696,8 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
     if (s->session_active && (rc = bind_device(s))) return rc;  // the resident kernel was started with the old families
     // Each cone must lie inside its vector. Cones of one side MAY share rows: upstream projects the cones of a knot one after
     // another (bindings.cpp:433-478 hands the list over in order), which the kernels reproduce by grouping the list into rounds of
-    // pairwise-disjoint cones (family_structure); at most MAX_CONES cones in MAX_ROUNDS rounds.
+    // pairwise-disjoint cones (family_structure). Up to MAX_CONES cones in MAX_ROUNDS rounds every families kernel holds; up to
+    // HARD_MAX_CONES in any number of rounds run on the structure-specialised kernels (layouts E and F).
     auto check_side = [&](const int *Ac, const int *qc, const double *c, int n, int dim, const char *side) -> int {
         for (int k = 0; k < n; ++k) {
             if (qc[k] < 1 || Ac[k] < 0 || Ac[k] + qc[k] > dim)
@@ -705,8 +708,8 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
     };
     if ((rc = check_side(Acx, qcx, cx, ncx, s->nx, "state"))) return rc;
     if ((rc = check_side(Acu, qcu, cu, ncu, s->nu, "input"))) return rc;
-    if (ncx + ncu > MAX_CONES)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d cones are supported by the HIP kernels (got %d state + %d input)", MAX_CONES, ncx, ncu);
+    if (ncx + ncu > HARD_MAX_CONES)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "at most %d cones are supported by the HIP kernels (got %d state + %d input)", HARD_MAX_CONES, ncx, ncu);
     {   // rounds of the whole list, both sides enabled (the worst case of what a launch can see)
         int rounds = 0;
         unsigned long long used = 0;
@@ -726,8 +729,8 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
             walk(Acx, qcx, ncx, 0);
             walk(Acu, qcu, ncu, s->nx);
         }
-        if (rounds > MAX_ROUNDS)
-            return fail(TINYMPC_ERR_UNSUPPORTED, "the cone list needs %d rounds of pairwise-disjoint cones; the HIP kernels support %d", rounds, MAX_ROUNDS);
+        // (more than MAX_ROUNDS rounds, like more than MAX_CONES cones: the structure-specialised kernels only -- checked at launch)
+        (void)rounds;
     }
     s->n_cone_x = ncx;
     s->n_cone_u = ncu;

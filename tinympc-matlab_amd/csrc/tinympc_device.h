@@ -216,15 +216,28 @@ __host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg
 //   cone that overlaps an earlier cone of the current round opens the next round); role / mu / Cn / Ct above describe round
 //   0, and behind cone_mu follow nround (1 double) and, for rounds 1 .. MAX_ROUNDS-1, role[W] | mu[W] | Cn[W][KT] | Ct[W][KT]:
 //   fam_round_offset(). The generic kernels that walk rounds (k_admm_solve_fam) read them from there.
-constexpr int MAX_LIN_ROWS = 32;  // per side; the coefficient block of the buffer and the kernels' LDS copies are sized for it
+// MAX_LIN_ROWS / MAX_CONES / MAX_ROUNDS are what the GENERIC kernels hold (the LDS copy of the latency kernel and of layout D's
+// families variant, the per-round registers of k_admm_solve_fam): the buffer's default capacities. A configuration beyond them
+// (round 4: up to HARD_MAX_LIN_ROWS rows per side, HARD_MAX_CONES cones, any number of rounds) gets a buffer whose blocks are sized
+// for IT -- `lin_cap`, `cone_cap`, `round_cap` of the offset functions, max(default, what the configuration has) -- and runs on the
+// structure-specialised kernels (layouts E and F), which know the counts at compile time and derive the same capacities.
+constexpr int MAX_LIN_ROWS = 32;  // per side
 constexpr int FAM_REG_ROWS = 8;   // k_admm_solve_fam keeps this many rows' coefficients in registers, the rest is read per use
 constexpr int MAX_CONES = 16;
 constexpr int MAX_ROUNDS = 4;
-__host__ __device__ inline size_t fam_cone_mu_offset(int W, int KT) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * MAX_LIN_ROWS * W; }
+constexpr int HARD_MAX_LIN_ROWS = 128, HARD_MAX_CONES = 64;
+__host__ __device__ constexpr int fam_lin_cap(int nl) { return nl > MAX_LIN_ROWS ? nl : MAX_LIN_ROWS; }
+__host__ __device__ constexpr int fam_cone_cap(int ncone) { return ncone > MAX_CONES ? ncone : MAX_CONES; }
+__host__ __device__ constexpr int fam_round_cap(int nround) { return nround > MAX_ROUNDS ? nround : MAX_ROUNDS; }
+__host__ __device__ inline size_t fam_cone_mu_offset(int W, int KT, int lin_cap = MAX_LIN_ROWS) { return (size_t)4 * W + (size_t)3 * W * KT + 1 + (size_t)3 * lin_cap * W; }
 __host__ __device__ inline size_t fam_round_doubles(int W, int KT) { return (size_t)2 * W + (size_t)2 * W * KT; }
-__host__ __device__ inline size_t fam_nround_offset(int W, int KT) { return fam_cone_mu_offset(W, KT) + MAX_CONES; }
-__host__ __device__ inline size_t fam_round_offset(int W, int KT, int round) { return fam_nround_offset(W, KT) + 1 + (size_t)(round - 1) * fam_round_doubles(W, KT); }
-__host__ __device__ inline size_t fam_doubles(int W, int KT) { return fam_round_offset(W, KT, MAX_ROUNDS); }
+__host__ __device__ inline size_t fam_nround_offset(int W, int KT, int lin_cap = MAX_LIN_ROWS, int cone_cap = MAX_CONES) { return fam_cone_mu_offset(W, KT, lin_cap) + cone_cap; }
+__host__ __device__ inline size_t fam_round_offset(int W, int KT, int round, int lin_cap = MAX_LIN_ROWS, int cone_cap = MAX_CONES) {
+    return fam_nround_offset(W, KT, lin_cap, cone_cap) + 1 + (size_t)(round - 1) * fam_round_doubles(W, KT);
+}
+__host__ __device__ inline size_t fam_doubles(int W, int KT, int lin_cap = MAX_LIN_ROWS, int cone_cap = MAX_CONES, int round_cap = MAX_ROUNDS) {
+    return fam_round_offset(W, KT, round_cap, lin_cap, cone_cap);
+}
 
 // ---- layout E (tinympc_solve_e.hip): the horizon cut across the `wpg` wavefronts of a workgroup, S slots each (the last
 // wavefront: what is left). LDS plan per workgroup, in doubles:
@@ -235,8 +248,9 @@ __host__ __device__ inline size_t fam_doubles(int W, int KT) { return fam_round_
 //   rows packed (`lds_arrays` of them) -- | d[S * 4 nu]
 __host__ __device__ constexpr int e_d_doubles(int nu, int S) { return (S * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int e_fam_row(int nxu) { return (4 * nxu + 1) & ~1; }
-__host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl) {
-    return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 512 + 2 * wpg * 64 + 16 + wpg * 16 + 6 * 64;
+__host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl, int ncone = 0) {
+    // (... | linear rows | the cones' slopes and their reciprocals [2][ncone] | ...)
+    return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 + ((2 * ncone + 1) & ~1) : 0) + 512 + 2 * wpg * 64 + 16 + wpg * 16 + 6 * 64;
 }
 // ... or, with the families evaluated one KNOT per lane (KFamilies, tinympc_solve_e_common.h; `lds_arrays` = -1), ONE exchange buffer
 // per wavefront: entry (j, t) = nx+nu doubles at (j (S+1) + t) ES, ES odd (conflict-free for the lanes that walk t), padded so that
@@ -247,8 +261,8 @@ __host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S
 __host__ __device__ constexpr int e_wave_doubles(int nxu, int nu, int S, int lds_arrays) {
     return (lds_arrays < 0 ? kfam_doubles(nxu, S) : lds_arrays * S * e_fam_row(nxu)) + e_d_doubles(nu, S);
 }
-__host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays) {
-    return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl) + (size_t)wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));
+__host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays, int ncone = 0) {
+    return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl, ncone) + (size_t)wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));
 }
 
 #ifndef __HIPCC_RTC__  // host side only
@@ -258,7 +272,9 @@ __host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct
 // linear rows per side.
 struct FamilyStructure {
     int ncone = 0, nround = 0, nlx = 0, nlu = 0;
-    int cone[MAX_CONES][3] = {};
+    int cone[HARD_MAX_CONES][3] = {};
+    // beyond what the generic kernels hold (their LDS copies / per-round registers): only layouts E and F run such a configuration
+    bool beyond_generic() const { return ncone > MAX_CONES || nround > MAX_ROUNDS || nlx > MAX_LIN_ROWS || nlu > MAX_LIN_ROWS; }
 };
 // Layout E (tinympc_solve_e.hip, run-time specialised only): the horizon cut across the wavefronts of a workgroup
 bool solve_e_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *wpg, size_t *lds_bytes);

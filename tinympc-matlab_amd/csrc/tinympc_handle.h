@@ -135,6 +135,8 @@ struct tinympc_solver {
     std::vector<int> Acx, qcx, Acu, qcu;
     std::vector<double> cx, cu, Alin_x, blin_x, Alin_u, blin_u;
     double *dfam = nullptr, *dGC = nullptr, *dGL = nullptr, *dLX = nullptr;
+    int fam_lin_cap = 0, fam_cone_cap = 0, fam_round_cap = 0;  // capacities `dfam` is laid out for (fam_doubles(), tinympc_device.h)
+    size_t fam_alloc_doubles = 0;
     double *h_x0 = nullptr, *h_u0 = nullptr;  // pinned staging for tinympc_mpc_step_batch (and x0 of single-instance handles)
     // Single-instance handles (batch == 1, what the MEX shim creates): set_x0 only fills the pinned h_x0, the next
     // launch reads it from there (and mirrors it into dx0), and the kernels also write solution + statistics into the

@@ -158,7 +158,7 @@ FamilyStructure family_structure(const tinympc_solver *s, double *mu) {
     unsigned long long used = 0;  // lanes taken by the cones of the current round
     auto add = [&](bool on, const std::vector<int> &Ac, const std::vector<int> &qc, const std::vector<double> &c, int base) {
         if (!on) return;
-        for (size_t k = 0; k < Ac.size() && fs.ncone < MAX_CONES; ++k) {
+        for (size_t k = 0; k < Ac.size() && fs.ncone < HARD_MAX_CONES; ++k) {
             const int first = base + Ac[k], last = first + qc[k] - 1;
             unsigned long long lanes = 0;
             for (int r = first; r <= last; ++r) lanes |= 1ull << (r & 63);
@@ -186,9 +186,28 @@ FamilyStructure family_structure(const tinympc_solver *s, double *mu) {
 // Masks and user coefficients only -- no solver arithmetic happens here.
 int refresh_families(tinympc_solver *s) {
     const int W = s->W, KT = s->KT, nx = s->nx, nu = s->nu, nxu = nx + nu;
-    if (!s->dfam) {
+    // the buffer's capacities: the generic kernels' (the default layout every kernel reads), or this configuration's own counts
+    // where it has more -- such a configuration runs on layouts E / F only (launch() checks)
+    std::vector<double> cmu(HARD_MAX_CONES, 0.0);
+    const FamilyStructure fs = family_structure(s, cmu.data());
+    const int lin_cap = fam_lin_cap(fs.nlx > fs.nlu ? fs.nlx : fs.nlu), cone_cap = fam_cone_cap(fs.ncone), round_cap = fam_round_cap(fs.nround);
+    // (the layout follows the CURRENT configuration's capacities exactly: the specialised kernels derive theirs from the counts
+    // they were compiled for; a block that has become too small is replaced, the old one stays on the handle's free list)
+    const size_t need = fam_doubles(W, KT, lin_cap, cone_cap, round_cap);
+    if (!s->dfam || need > s->fam_alloc_doubles) {
         int rc;
-        if ((rc = dalloc(s, &s->dfam, fam_doubles(W, KT)))) return rc;
+        if ((rc = dalloc(s, &s->dfam, need))) return rc;
+        s->fam_alloc_doubles = need;
+        s->fam_dirty = true;
+    }
+    if (lin_cap != s->fam_lin_cap || cone_cap != s->fam_cone_cap || round_cap != s->fam_round_cap) {
+        s->fam_lin_cap = lin_cap;
+        s->fam_cone_cap = cone_cap;
+        s->fam_round_cap = round_cap;
+        s->fam_dirty = true;
+    }
+    if (!s->dGC) {
+        int rc;
         if ((rc = dalloc(s, &s->dGC, s->v_doubles()))) return rc;
         if ((rc = dalloc(s, &s->dGL, s->v_doubles()))) return rc;
         if ((rc = dalloc(s, &s->dLX, s->v_doubles()))) return rc;
@@ -198,7 +217,8 @@ int refresh_families(tinympc_solver *s) {
         s->fam_dirty = true;
     }
     if (!s->fam_dirty) return TINYMPC_OK;
-    std::vector<double> f(fam_doubles(W, KT), 0.0);
+    const int LC = s->fam_lin_cap, CC = s->fam_cone_cap, RC = s->fam_round_cap;
+    std::vector<double> f(fam_doubles(W, KT, LC, CC, RC), 0.0);
     double *role = f.data(), *mu = role + W, *famc = mu + W, *faml = famc + W;
     double *Cn = faml + W, *Ct = Cn + (size_t)W * KT, *Ty = Ct + (size_t)W * KT, *lin = Ty + (size_t)W * KT;
     const bool cone_x = s->st.en_state_soc && s->n_cone_x > 0, cone_u = s->st.en_input_soc && s->n_cone_u > 0;
@@ -213,14 +233,12 @@ int refresh_families(tinympc_solver *s) {
     // cones, round by round (family_structure: cones of one round are pairwise disjoint): round 0 into the arrays every kernel
     // reads, later rounds -- they exist only where cones share rows -- behind them for the kernels that walk rounds
     {
-        std::vector<double> cmu(MAX_CONES, 0.0);
-        const FamilyStructure fs = family_structure(s, cmu.data());
-        f[fam_nround_offset(W, KT)] = (double)(fs.nround > 0 ? fs.nround : 1);
+        f[fam_nround_offset(W, KT, LC, CC)] = (double)(fs.nround > 0 ? fs.nround : 1);
         for (int c = 0; c < fs.ncone; ++c) {
             const int q = fs.cone[c][0], first = fs.cone[c][1], last = fs.cone[c][2];
             double *rl = role, *m = mu, *cn = Cn, *ct = Ct;
             if (q >= 1) {
-                rl = f.data() + fam_round_offset(W, KT, q);
+                rl = f.data() + fam_round_offset(W, KT, q, LC, CC);
                 m = rl + W;
                 cn = m + W;
                 ct = cn + (size_t)W * KT;
@@ -239,7 +257,7 @@ int refresh_families(tinympc_solver *s) {
     const int nl = nlx > nlu ? nlx : nlu;
     lin[0] = (double)nl;
     const double inf = std::numeric_limits<double>::infinity();
-    for (int k = 0; k < MAX_LIN_ROWS; ++k) {
+    for (int k = 0; k < LC; ++k) {
         double *ak = lin + 1 + (size_t)(3 * k + 0) * W, *bk = ak + W, *nk = bk + W;
         double nrm_x = 0.0, nrm_u = 0.0;
         if (k < nlx) for (int c = 0; c < nx; ++c) { const double a = s->Alin_x[k + (size_t)c * s->n_lin_x]; nrm_x += a * a; }
@@ -250,7 +268,7 @@ int refresh_families(tinympc_solver *s) {
             if (r >= nx && r < nxu && k < nlu) { ak[r] = s->Alin_u[k + (size_t)(r - nx) * s->n_lin_u]; bk[r] = s->blin_u[k]; nk[r] = nrm_u; }
         }
     }
-    (void)family_structure(s, f.data() + fam_cone_mu_offset(W, KT));  // slopes of the active cones, in list order (layout E)
+    for (int c = 0; c < fs.ncone; ++c) f[fam_cone_mu_offset(W, KT, LC) + c] = cmu[c];  // slopes of the active cones, in list order (layouts E, F)
     int rc = upload(s, s->dfam, f.data(), f.size());
     if (rc) return rc;
     s->fam_dirty = false;

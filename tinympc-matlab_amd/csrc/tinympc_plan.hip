@@ -43,7 +43,8 @@ void decide_layout_d_variants(tinympc_solver *s) {
         // time -- the answer is cached inside -- because it also depends on the tables' kind.
         // (cones that share rows need the round-by-round projection, which layout D's families variant and the latency kernel
         // do not have: layout E or k_admm_solve_fam run those)
-        s->d_fam = (s->W == 16 && family_structure(s).nround <= 1 && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+        const FamilyStructure fsd = family_structure(s);
+        s->d_fam = (s->W == 16 && fsd.nround <= 1 && !fsd.beyond_generic() && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
     }
 }
 
@@ -90,7 +91,10 @@ int decide_layout_f(tinympc_solver *s) {
     // round-1 latency kernel. The box path stays on layout C: with four wavefronts (plan_f) layout F is 4 % ahead there too
     // (quadrotor N=50: 2.75 against 2.86 us), but layout C stages per-tick references from pinned memory inside the kernel, runs the
     // resident session (bit-identical ticks) and needs no run-time specialisation for a new shape.
-    bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin && s->fam_c;
+    // (a configuration beyond what the generic kernels hold -- more than MAX_LIN_ROWS rows, MAX_CONES cones, MAX_ROUNDS rounds -- has
+    // no other kernel at these batch sizes)
+    bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin &&
+                (s->fam_c || family_structure(s).beyond_generic());
     if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
     if (!want) {
         s->f_ok = false;
@@ -255,6 +259,10 @@ int launch(tinympc_solver *s, bool timed) {
         return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
     if (s->layout_m && (adaptive || fam))
         return fail(TINYMPC_ERR_UNSUPPORTED, "systems with nx+nu > 64 support box constraints only (no cone / linear families, no adaptive_rho)");
+    if (fam && pl.kernel != KernelId::E && pl.kernel != KernelId::F && family_structure(s).beyond_generic())
+        return fail(TINYMPC_ERR_UNSUPPORTED, "more than %d linear rows per side, %d cones or %d rounds of overlapping cones run on the run-time "
+                    "specialised kernels only (nx+nu <= 16, TINYMPC_JIT not 0): this configuration has none (%s)", MAX_LIN_ROWS, MAX_CONES, MAX_ROUNDS,
+                    s->W != 16 ? "nx+nu > 16" : "the specialiser refused it, see tinympc_get_jit_info");
     if (adaptive) {  // tiny tables from the current cache, sensitivities and Xref; rebuilt per launch (a few microseconds)
         AdaptTableParams a{};
         a.nx = s->nx; a.nu = s->nu; a.N = s->N; a.W = s->W; a.KT = s->KT;

@@ -129,8 +129,9 @@ int tinympc_session_begin(tinympc_solver *s) {
     if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
     if (s->families_active() && s->chunk_len > 4)
         return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
-    if (s->families_active() && family_structure(s).nround > 1)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows are not supported by the resident kernel");
+    if (s->families_active() && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()))
+        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows (or more than %d cones / %d linear rows per side) are not supported by the resident kernel",
+                    MAX_CONES, MAX_LIN_ROWS);
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
     if (!s->h_mail) {
         HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));

@@ -149,7 +149,8 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     double *sOps = smem;                                          // [2][16 k][16 r]
     double *sT = sOps + 512;                                      // tables (!CT)
     double *sLin = sT + (CT ? 0 : 3 * (N + 2) * 16 + 16);         // [E_NL][3][16]  a_k | b_k | 1/||a_k||^2 (FAM)
-    double *sPow = sLin + (FAM ? 3 * E_NL * 16 : 0);              // Phi^S | Psi^S, [16 k][16 r] each
+    double *sMu = sLin + (FAM ? 3 * E_NL * 16 : 0);               // [2][E_NCONE] the cones' slopes | their reciprocals (FAM)
+    double *sPow = sMu + (FAM ? ((2 * E_NCONE + 1) & ~1) : 0);    // Phi^S | Psi^S, [16 k][16 r] each
     double *sE = sPow + 512;                                      // [WPG][64] forward carries
     double *sB = sE + WPG * 64;                                   // [WPG][64] backward carries
     int *sFlag = reinterpret_cast<int *>(sB + WPG * 64);          // [WPG] per-instance "below tolerance" bits (16 doubles)
@@ -179,6 +180,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     if constexpr (!CT)
         for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
     if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, 64 * WPG);
+    if constexpr (FAM) KFamilies<NX, NU>::stage_cone_slopes(p.fam, KT, sMu, (int)threadIdx.x);
 
     // canonical HBM layout, shared with every other kernel
     const size_t vbase = ((size_t)grp * v_rows(N) + V_PAD) * 64;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             constexpr int pp = decltype(Pp)::value;
             const int t = r + 16 * pp;
             kmask[pp] = __ballot(t >= 1 && t <= s_real);
-            kf[pp].init(p.fam, KT, sLin, p.rho);
+            kf[pp].init(p.fam, KT, sLin, sMu, p.rho);
             const bool ent = (t >= 1 && t <= s_real) || (t == 0 && bottom);
             e_static_for<0, NXU>([&](auto R) {
                 constexpr int rr = decltype(R)::value;
@@ -794,7 +796,7 @@ TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
     constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0, DRJ = TINY_JIT_E_DREG != 0;
     constexpr int nlds = !FAMJ ? 0 : KFJ ? -1 : (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0);
-    constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds);
+    constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds, tinympc::E_NCONE);
     static_assert(bytes <= 160 * 1024, "layout E: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_e[bytes / sizeof(double)];
     tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ, DRJ>(p, smem_e);

@@ -142,7 +142,9 @@ constexpr EConeDesc E_CONES[] = {{-1, 0, 0}};
 #endif
 constexpr int E_NCONE = TINY_JIT_E_NCONE, E_NROUND = TINY_JIT_E_NROUND, E_NLX = TINY_JIT_E_NLX, E_NLU = TINY_JIT_E_NLU;
 constexpr int E_NL = E_NLX > E_NLU ? E_NLX : E_NLU;
-static_assert(E_NCONE <= MAX_CONES && E_NROUND <= (E_NCONE > 0 ? E_NCONE : 1), "cone list");
+static_assert(E_NCONE <= HARD_MAX_CONES && E_NROUND <= (E_NCONE > 0 ? E_NCONE : 1) && E_NL <= HARD_MAX_LIN_ROWS, "cone list / linear rows");
+// the capacities of the family buffer for THIS structure (tinympc_device.h: the defaults, or the structure's own counts beyond them)
+constexpr int E_LIN_CAP = fam_lin_cap(E_NL), E_CONE_CAP = fam_cone_cap(E_NCONE);
 
 
 // The families' per-lane data and their row-local evaluation for ONE (row, knot) element (admm.cpp's update_slack / update_dual /
@@ -175,7 +177,7 @@ struct EFamilies {
             mu_r[q] = 0.0;
             imu_r[q] = 0.0;
         }
-        const double *cone_mu = fam + fam_cone_mu_offset(W, KT);
+        const double *cone_mu = fam + fam_cone_mu_offset(W, KT, E_LIN_CAP);
         e_static_for<0, E_NCONE>([&](auto Cc) {
             constexpr EConeDesc cd = E_CONES[Cc.value];
             const bool in = (r >= cd.first) && (r <= cd.last);
@@ -272,21 +274,28 @@ struct KFamilies {
     double gc[NXU], gl[NXU];  // the families' duals of this lane's knot
     double rho;
     bool cone_x, cone_u, lin_x, lin_u;  // (uniform) the family is enabled for the side
-    double mu_c[E_NCONE > 0 ? E_NCONE : 1], imu_c[E_NCONE > 0 ? E_NCONE : 1];  // (uniform) slope of cone c of the list and its reciprocal
+    const double *sMu;        // LDS: [2][E_NCONE] slope of cone c of the list | its reciprocal (uniform reads: no registers for up to 64 cones)
     const double *sLin;       // LDS: [E_NL][3][16]  a_k | b_k | 1/||a_k||^2, per ROW-layout lane (state lanes: the state side's row k)
 
-    __device__ __forceinline__ void init(const double *fam, int KT, const double *lin, double rho_) {
+    // (by the first E_NCONE threads of the workgroup; a barrier must follow)
+    static __device__ __forceinline__ void stage_cone_slopes(const double *fam, int KT, double *mu, int tid) {
+        if constexpr (E_NCONE > 0) {
+            if (tid < E_NCONE) {
+                const double m = fam[fam_cone_mu_offset(W, KT, E_LIN_CAP) + tid];
+                mu[tid] = m;
+                mu[E_NCONE + tid] = 1.0 / m;
+            }
+        }
+    }
+    __device__ __forceinline__ void init(const double *fam, int KT, const double *lin, const double *mu, double rho_) {
         rho = rho_;
         sLin = lin;
+        sMu = mu;
         cone_x = fam[2 * W + 0] != 0.0;
         cone_u = fam[2 * W + NX] != 0.0;
         lin_x = fam[3 * W + 0] != 0.0;
         lin_u = fam[3 * W + NX] != 0.0;
-        const double *cone_mu = fam + fam_cone_mu_offset(W, KT);
-        e_static_for<0, E_NCONE>([&](auto Cc) {
-            mu_c[Cc.value] = cone_mu[Cc.value];
-            imu_c[Cc.value] = 1.0 / cone_mu[Cc.value];
-        });
+        (void)KT;
     }
     // one cone {F .. L}, L its t row, on the knot's slack vector (soc_project_element's arithmetic, once per knot)
     template <int F, int L>
@@ -322,7 +331,7 @@ struct KFamilies {
             e_static_for<0, E_NROUND>([&](auto Rd) {
                 e_static_for<0, E_NCONE>([&](auto Cc) {
                     constexpr EConeDesc cd = E_CONES[Cc.value];
-                    if constexpr (cd.round == Rd.value) project_cone<cd.first, cd.last>(sv, mu_c[Cc.value], imu_c[Cc.value]);
+                    if constexpr (cd.round == Rd.value) project_cone<cd.first, cd.last>(sv, sMu[Cc.value], sMu[E_NCONE + Cc.value]);
                 });
             });
             e_static_for<0, NXU>([&](auto R) {
