@@ -15,6 +15,8 @@
 // Summation order: an MFMA adds its four products and then the accumulator, the reference (and k_precompute) one product at a
 // time -- differences of an ulp per product that the contraction of the Riccati map does not amplify (caches against the
 // oracle: 1e-9 in tests/test_large_systems_gpu.py, as for k_precompute).
+#include <cstdlib>
+
 #include "tinympc_device.h"
 
 namespace tinympc {
@@ -29,10 +31,13 @@ template <bool TA, bool TB, int EPI>
 __global__ void __launch_bounds__(256) k_dgemm_mfma(double *C, const double *A, const double *B, int m, int k, int n, const double *X, const double *dg,
                                                      const int *done) {
     if (done && *done) return;
+    // ONE tile of C per workgroup, k split over its four wavefronts (round 4: at the sizes of a setup -- 36 tiles at nx = 96 -- a
+    // product is a chain of L2 round trips, one per sixteen columns of k; four wavefronts walk a quarter of it each, and a grid of
+    // `tiles` workgroups instead of tiles / 4 spreads over more of the chip) and summed in wavefront order through LDS.
+    __shared__ double part[3][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_m = (m + 15) / 16, tiles_n = (n + 15) / 16;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= tiles_m * tiles_n) return;
+    const int tiles_m = (m + 15) / 16;
+    const int tile = blockIdx.x;
     const int i0 = (tile % tiles_m) * 16, j0 = (tile / tiles_m) * 16;
     const int li = lane & 15, kk = lane >> 4;
     const int ia = i0 + li, jb = j0 + li;  // this lane's row of op(A) / column of op(B)
@@ -42,7 +47,7 @@ __global__ void __launch_bounds__(256) k_dgemm_mfma(double *C, const double *A, 
     auto ld_b = [&](int l) -> double { return (jb_ok && l < k) ? (TB ? B[jb + (size_t)l * n] : B[l + (size_t)jb * k]) : 0.0; };
     // sixteen columns of k per trip: four loads each in flight, two accumulation chains (a dependent FP64 MFMA only issues when
     // its predecessor has left the pipe); acc0 takes blocks 0 and 2, acc1 blocks 1 and 3 -- added in block order at the end
-    for (int l0 = 0; l0 < k; l0 += 16) {
+    for (int l0 = 16 * wave; l0 < k; l0 += 64) {
         double a[4], b[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -54,13 +59,19 @@ __global__ void __launch_bounds__(256) k_dgemm_mfma(double *C, const double *A, 
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][lane][r] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
     // result register r of a lane: row i0 + (lane >> 4) + 4 r, column j0 + (lane & 15)
     const int j = j0 + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + kk + 4 * r;
         if (i < m && j < n) {
-            double v = acc0[r] + acc1[r];
+            double v = ((acc0[r] + acc1[r]) + part[0][lane][r]) + (part[1][lane][r] + part[2][lane][r]);
             if constexpr (EPI == PL_X_MINUS) v = X[i + (size_t)j * m] - v;
             if constexpr (EPI == PL_PLUS_DIAG) v = ((i == j) ? dg[i] : 0.0) + v;
             C[i + (size_t)j * m] = v;
@@ -71,7 +82,7 @@ __global__ void __launch_bounds__(256) k_dgemm_mfma(double *C, const double *A, 
 template <bool TA, bool TB, int EPI>
 static void dgemm(double *C, const double *A, const double *B, int m, int k, int n, const double *X, const double *dg, const int *done, hipStream_t st) {
     const int tiles = ((m + 15) / 16) * ((n + 15) / 16);
-    hipLaunchKernelGGL((k_dgemm_mfma<TA, TB, EPI>), dim3((tiles + 3) / 4), dim3(256), 0, st, C, A, B, m, k, n, X, dg, done);
+    hipLaunchKernelGGL((k_dgemm_mfma<TA, TB, EPI>), dim3(tiles), dim3(256), 0, st, C, A, B, m, k, n, X, dg, done);
 }
 
 // One workgroup: S = R1 + BtP B (nu x nu), Sinv by partial-pivot LU, T1 = Sinv B' (nu x nx). (B'P was a dgemm; nu <= 64 here.)
@@ -148,9 +159,81 @@ __global__ void __launch_bounds__(256) k_gain_solve(double *T1, double *Sinv, do
     }
 }
 
+// The same inverse for nu <= 64 (round 4): ONE wavefront, S and its inverse in LDS, lane j = column j. k_gain_solve above keeps S in
+// global memory and walks it with one or a few threads -- every pivot search, row swap and substitution step a chain of L2 round
+// trips: 307 us per call at nu = 32, 129 calls = 40 of the 44 ms a setup at nx = 96 took (profiles/r03_large_system_stats.csv).
+// Here the products around it are launches on the matrix cores like every other product of the iteration (S = B'P B + R1,
+// T1 = S^-1 B') and the LU lives in LDS: partial pivoting (largest magnitude, lowest row on ties, as Eigen's PartialPivLU),
+// the elimination column by column with the arithmetic of k_gain_solve in its order, then the solve against the permuted identity,
+// one right-hand side per lane. Rows of the LDS copies are padded to an odd length: lanes walk columns AND rows without conflicts.
+__global__ void __launch_bounds__(64) k_lu_inverse(double *Sinv, const double *S, int nu, const int *done) {
+    if (done && *done) return;
+    constexpr int LD = 65;
+    __shared__ double sA[64 * LD];
+    __shared__ double sX[64 * LD];
+    __shared__ int sPerm[64];
+    const int lane = threadIdx.x;
+    const bool col = lane < nu;
+    if (col)
+        for (int i = 0; i < nu; ++i) sA[i * LD + lane] = S[i + (size_t)lane * nu];
+    sPerm[lane] = lane;
+    __syncthreads();
+    for (int k = 0; k < nu; ++k) {
+        // pivot of column k among rows k .. nu-1
+        double v = (lane >= k && col) ? fabs(sA[lane * LD + k]) : -1.0;
+        int idx = lane;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const double ov = __shfl_xor(v, m, 64);
+            const int oi = __shfl_xor(idx, m, 64);
+            if (ov > v || (ov == v && oi < idx)) {
+                v = ov;
+                idx = oi;
+            }
+        }
+        const int piv = __builtin_amdgcn_readfirstlane(idx);
+        if (piv != k) {
+            if (col) {
+                const double t = sA[k * LD + lane];
+                sA[k * LD + lane] = sA[piv * LD + lane];
+                sA[piv * LD + lane] = t;
+            }
+            if (lane == 0) {
+                const int t = sPerm[k];
+                sPerm[k] = sPerm[piv];
+                sPerm[piv] = t;
+            }
+        }
+        __syncthreads();
+        const double pivot = sA[k * LD + k];
+        if (lane > k && col) sA[lane * LD + k] /= pivot;
+        __syncthreads();
+        if (lane > k && col) {
+            const double u = sA[k * LD + lane];
+            for (int i = k + 1; i < nu; ++i) sA[i * LD + lane] -= sA[i * LD + k] * u;
+        }
+        __syncthreads();
+    }
+    if (col) {  // column `lane` of the inverse: L U x = P e_lane
+        for (int i = 0; i < nu; ++i) {
+            double x = (sPerm[i] == lane) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) x -= sA[i * LD + j] * sX[j * LD + lane];
+            sX[i * LD + lane] = x;
+        }
+        for (int i = nu - 1; i >= 0; --i) {
+            double x = sX[i * LD + lane];
+            for (int j = i + 1; j < nu; ++j) x -= sA[i * LD + j] * sX[j * LD + lane];
+            sX[i * LD + lane] = x / sA[i * LD + i];
+        }
+        for (int i = 0; i < nu; ++i) Sinv[i + (size_t)lane * nu] = sX[i * LD + lane];
+    }
+}
+
 // The truncation test and the hand-over to the next iteration. ctl[0] = done, ctl[1] = steps taken.
-__global__ void __launch_bounds__(1024) k_riccati_step(const double *K, double *Kprev, const double *Pnew, double *P, int nx, int nu, int it, int *ctl) {
+// (the iteration index lives in ctl[2]: every iteration's launches have the same arguments, so a chunk of iterations is ONE graph)
+__global__ void __launch_bounds__(1024) k_riccati_step(const double *K, double *Kprev, const double *Pnew, double *P, int nx, int nu, int *ctl) {
     if (ctl[0]) return;
+    const int it = ctl[2];
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     double mx = 0.0;
@@ -171,6 +254,7 @@ __global__ void __launch_bounds__(1024) k_riccati_step(const double *K, double *
     }
     for (int i = tid; i < nu * nx; i += 1024) Kprev[i] = K[i];       // :164
     for (int i = tid; i < nx * nx; i += 1024) P[i] = Pnew[i];       // :165
+    if (tid == 0) ctl[2] = it + 1;
 }
 
 __global__ void __launch_bounds__(256) k_pl_init(double *Q1d, double *R1d, double *Kprev, double *P, const double *Qd, const double *Rd, double rho, int nx, int nu,
@@ -183,6 +267,7 @@ __global__ void __launch_bounds__(256) k_pl_init(double *Q1d, double *R1d, doubl
     if (g == 0) {
         ctl[0] = 0;
         ctl[1] = 1000;
+        ctl[2] = 0;
     }
 }
 
@@ -209,8 +294,8 @@ __global__ void __launch_bounds__(256) k_pl_matvec(double *y, const double *M, c
 }
 
 size_t precompute_large_scratch_doubles(int nx, int nu) {
-    // K, Kprev, BtP, T1, T2 (nu*nx) + P, Pnew, AtP, AmBK (nx*nx) + S, Sinv (nu*nu) + Q1d, R1d, Pf + perm (nu+1 ints) + ctl (2 ints)
-    return (size_t)5 * nu * nx + (size_t)4 * nx * nx + (size_t)2 * nu * nu + 2 * nx + nu + (nu + 2) + 2;
+    // K, Kprev, BtP, T1, T2 (nu*nx) + P, Pnew, AtP, AmBK (nx*nx) + S, Sinv (nu*nu) + Q1d, R1d, Pf + perm (nu+1 ints) + ctl (3 ints)
+    return (size_t)5 * nu * nx + (size_t)4 * nx * nx + (size_t)2 * nu * nu + 2 * nx + nu + (nu + 2) + 4;
 }
 
 hipError_t launch_precompute_large(const PrecomputeParams &p, hipStream_t st) {
@@ -234,20 +319,29 @@ hipError_t launch_precompute_large(const PrecomputeParams &p, hipStream_t st) {
     int *ctl = reinterpret_cast<int *>(w);
     const double *A = p.A, *B = p.B;
     hipLaunchKernelGGL(k_pl_init, dim3(64), dim3(256), 0, st, Q1d, R1d, Kprev, P, p.Qd, p.Rd, p.rho, nx, nu, ctl);
-    constexpr int CHUNK = 16;  // iterations enqueued between two looks at `done`
+    // Iterations are enqueued in chunks of CHUNK between two looks at `done`. (Captured into a HIP graph and replayed, a chunk was
+    // no faster -- 17.1 against 16.2 ms at nx = 96: what an iteration costs is the ten DEPENDENT kernels' start-to-end latency on the
+    // GPU, ~12 us each at these sizes, not the host's launch calls.)
+    constexpr int CHUNK = 16;
     int host_ctl[2] = {0, 1000};
     for (int it = 0; it < 1000 && !host_ctl[0];) {
         for (int c = 0; c < CHUNK && it < 1000; ++c, ++it) {
             // :154  K = (R1 + B'PB)^-1 B' P A, evaluated left to right
             dgemm<true, false, PL_NONE>(BtP, B, P, nu, nx, nx, nullptr, nullptr, ctl, st);
-            hipLaunchKernelGGL(k_gain_solve, dim3(1), dim3(256), 0, st, T1, Sinv, S, perm, BtP, B, R1d, nx, nu, ctl);
+            if (nu <= 64) {  // S = B'P B + R1 and T1 = S^-1 B' on the matrix cores, the inverse in LDS
+                dgemm<false, false, PL_PLUS_DIAG>(S, BtP, B, nu, nx, nu, nullptr, R1d, ctl, st);
+                hipLaunchKernelGGL(k_lu_inverse, dim3(1), dim3(64), 0, st, Sinv, S, nu, ctl);
+                dgemm<false, true, PL_NONE>(T1, Sinv, B, nu, nu, nx, nullptr, nullptr, ctl, st);
+            } else {
+                hipLaunchKernelGGL(k_gain_solve, dim3(1), dim3(256), 0, st, T1, Sinv, S, perm, BtP, B, R1d, nx, nu, ctl);
+            }
             dgemm<false, false, PL_NONE>(T2, T1, P, nu, nx, nx, nullptr, nullptr, ctl, st);
             dgemm<false, false, PL_NONE>(K, T2, A, nu, nx, nx, nullptr, nullptr, ctl, st);
             // :155  Pnew = Q1 + A'P (A - B K)
             dgemm<true, false, PL_NONE>(AtP, A, P, nx, nx, nx, nullptr, nullptr, ctl, st);
             dgemm<false, false, PL_X_MINUS>(AmBK, B, K, nx, nu, nx, A, nullptr, ctl, st);
             dgemm<false, false, PL_PLUS_DIAG>(Pnew, AtP, AmBK, nx, nx, nx, nullptr, Q1d, ctl, st);
-            hipLaunchKernelGGL(k_riccati_step, dim3(1), dim3(1024), 0, st, K, Kprev, Pnew, P, nx, nu, it, ctl);  // :157, :164-165
+            hipLaunchKernelGGL(k_riccati_step, dim3(1), dim3(1024), 0, st, K, Kprev, Pnew, P, nx, nu, ctl);  // :157, :164-165
         }
         hipError_t e = hipMemcpyAsync(host_ctl, ctl, sizeof(host_ctl), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return e;
@@ -255,7 +349,12 @@ hipError_t launch_precompute_large(const PrecomputeParams &p, hipStream_t st) {
     }
     // :169  Quu_inv = (R1 + B' Pinf B)^-1 ; :170  AmBKt = (A - B Kinf)'   (K, Pnew: the iteration that met the test)
     dgemm<true, false, PL_NONE>(BtP, B, Pnew, nu, nx, nx, nullptr, nullptr, nullptr, st);
-    hipLaunchKernelGGL(k_gain_solve, dim3(1), dim3(256), 0, st, (double *)nullptr, Sinv, S, perm, BtP, B, R1d, nx, nu, (const int *)nullptr);
+    if (nu <= 64) {
+        dgemm<false, false, PL_PLUS_DIAG>(S, BtP, B, nu, nx, nu, nullptr, R1d, nullptr, st);
+        hipLaunchKernelGGL(k_lu_inverse, dim3(1), dim3(64), 0, st, Sinv, S, nu, (const int *)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_gain_solve, dim3(1), dim3(256), 0, st, (double *)nullptr, Sinv, S, perm, BtP, B, R1d, nx, nu, (const int *)nullptr);
+    }
     dgemm<false, false, PL_X_MINUS>(AmBK, B, K, nx, nu, nx, A, nullptr, nullptr, st);
     hipLaunchKernelGGL(k_pl_finish, dim3(64), dim3(256), 0, st, p, K, Pnew, Sinv, AmBK, ctl);
     // affine-dynamics terms (upstream TinyMPC main; PARITY UNPINNED): APf = AmBKt Pinf f, BPf = B' Pinf f
