@@ -46,7 +46,7 @@ def test_every_solve_source_is_linted_by_the_build():
     # (HIP_BUILTINS), every other one is compiled at run time from the same source with a hazard s_nop in front of every chain block
     run_time_only = {e[1] for e in ge.HIP_BUILTINS}
     assert run_time_only == {"tinympc_solve_e.hip", "tinympc_solve_f.hip"}
-    assert [e[0] for e in ge.HIP_BUILTINS] == ["k_builtin_e_rocket100", "k_builtin_f_rocket100"]
+    assert [e[0] for e in ge.HIP_BUILTINS] == ["k_builtin_e_rocket100", "k_builtin_f_rocket100", "k_builtin_f_rocket100_session"]
     assert on_disk - no_dpp_chain - run_time_only == set(SOURCES), "new solve kernel source: add it to SOURCES here and to HIP_LINTED in __graft_entry__.py"
     for f in no_dpp_chain:
         assert "_dpp" not in open(os.path.join(CSRC, f)).read()
@@ -128,7 +128,17 @@ def test_compiled_in_specialisations_are_linted_and_do_not_spill():
         text = open(path).read()
         checked, bad = _lint(text)
         assert checked > 100 and not bad, (name, bad[:3])
-        assert ".amdhsa_kernel " + name in text and ".private_segment_fixed_size: 0" in text and "vgpr_spill_count: 0" in text, name
+        assert ".amdhsa_kernel " + name in text, name
+        if name.endswith("_session"):
+            # the resident session kernel may spill in its RARE paths (mailbox, reference refresh, the write-back when it leaves:
+            # once per tick or per session); its sweeps -- the blocks made of DPP FMAs -- must not touch scratch
+            body = re.search(r"^%s:(.*?)^\.Lfunc_end" % re.escape(name), text, re.S | re.M).group(1)
+            sweeps = [b for b in re.split(r"^\.LBB\d+_\d+:", body, flags=re.M) if b.count("v_fmac_f64_dpp") >= 9]
+            assert len(sweeps) >= 4, name
+            for b in sweeps:
+                assert "scratch_" not in b, f"{name}: a sweep block of the session kernel uses scratch"
+        else:
+            assert ".private_segment_fixed_size: 0" in text and "vgpr_spill_count: 0" in text, name
         # bare blocks: only the back-to-back chains of pass 1 / the carry recurrences (fwd_plain) keep their own s_nop; the sweep
         # blocks proper start without one (the run-time builds put one in front of every chain)
         chains = len(re.findall(r"v_fmac_f64_dpp [^\n]* row_newbcast:0 ", text))
@@ -249,6 +259,8 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
                 for b in sweeps:
                     assert "scratch_" not in b, f"{m.group(1)}: a sweep block of the slot-refill variant uses scratch"
                 continue
+            if m.group(1).endswith("_session"):
+                continue  # (rare paths may spill: test_compiled_in_specialisations_are_linted_and_do_not_spill checks its sweeps)
             assert size <= allowed.get((source, m.group(1)), 0), f"{source}: {m.group(1)} uses {size} bytes of scratch per lane"
     assert seen > 50 and refill >= 3
 

@@ -184,3 +184,58 @@ def test_setup_and_reset_of_another_handle_do_not_wait_for_the_resident_kernel(p
     np.testing.assert_array_equal(np.array(us), np.array(ur))
     a.reset()
     ref.reset()
+
+
+def test_rocket_landing_closed_loop_resident_at_the_full_horizon(pkg, monkeypatch):
+    """BASELINE config 4 as the reference uses it (rocket_landing_constraints.m:86-121: a closed loop, references re-sent every
+    tick) at N = 100: beyond what the latency kernel's session holds with the families (N <= 65), so the resident kernel is layout
+    F's (round 4). Its ticks must equal LAUNCHED ticks of layout F bit for bit -- first controls, iteration counts, the whole
+    solution -- through receding-horizon references that are a shift (one column travels), a jump (full re-read), a tick without a
+    new reference, the idle time-out (the kernel is restarted transparently), and the handle must go on with ordinary launches from
+    the session's state; every tick is also checked against the restatement."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    prob = P.rocket(100)
+    settings = dict(abs_pri_tol=5e-2, abs_dua_tol=5e-2, max_iter=200)  # (loose: the 100-knot landing converges slowly, and ticks must CONVERGE for the stale-slack roll-back to be exercised)
+    a, b = _solver(pkg, prob, settings, True), _solver(pkg, prob, settings, True)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    goal = np.zeros(prob.nx)
+    ref_at = lambda jk: prob.x0 + (goal - prob.x0) * min(jk, 140) / 140
+    a.prepare()
+    assert a.launch_info()["layout"] == "F" and a.jit_info().startswith(("compiled-in", "compiled ", "disk-cache")), a.jit_info()
+    a.session_begin()  # (after jit_info: pushing settings ends a session)
+    assert a.launch_info()["layout"] == "F"
+    x = prob.x0.copy()
+    iters = []
+    for k in range(16):
+        off = k if k != 6 else 40  # tick 6: a jump, not a shift
+        if k != 9:                 # tick 9: no new reference at all
+            x_ref = np.stack([ref_at(i + off) for i in range(prob.N)], axis=1)
+            u_ref = prob.u_ref + 0.01 * (k if k != 6 else 3)  # (changes every tick, never a shift: the full re-read of the input side)
+            for h in (a, b):
+                h.set_x_ref(x_ref)
+                if k % 2 == 0:
+                    h.set_u_ref(u_ref)
+            orc.set_x_ref(x_ref)
+            if k % 2 == 0:
+                orc.set_u_ref(u_ref)
+        if k == 12:
+            time.sleep(2.6)  # longer than the resident kernel's idle time-out: the next step restarts it
+        ua = a.session_step(x)
+        ub = b.mpc_step(x)[:, 0]
+        orc.set_x0(x)
+        orc.solve()
+        np.testing.assert_array_equal(ua, ub, err_msg="tick %d" % k)
+        assert a.get_stats()["iter"] == b.get_stats()["iter"] == orc.stats()["iter"], (k, a.get_stats(), b.get_stats(), orc.stats())
+        np.testing.assert_array_equal(a.get_solution()["states"], b.get_solution()["states"])
+        np.testing.assert_array_equal(a.get_solution()["controls"], b.get_solution()["controls"])
+        assert rel_err(a.get_solution()["controls"], orc.solution()[1]) < 1e-9 and rel_err(a.get_solution()["states"], orc.solution()[0]) < 1e-9, k
+        iters.append(a.get_stats()["iter"])
+        x = prob.A @ x + prob.B @ ua + prob.fdyn
+    assert len(set(iters)) >= 2  # (warm starts: the ticks do not all take the same number of iterations)
+    a.session_end()
+    ua, ub = a.mpc_step(x)[:, 0], b.mpc_step(x)[:, 0]  # ordinary launches from the session's ADMM state
+    np.testing.assert_array_equal(ua, ub)
+    assert a.get_stats()["iter"] == b.get_stats()["iter"]
+    a.reset()
+    b.reset()

@@ -195,8 +195,8 @@ struct AdaptTableParams {
 // wavefronts. LDS per workgroup, in doubles: operators | tables (!ct) | linear rows (fam) | carry matrices [2][4][16][16] |
 // wavefront totals [2][wpg][16] | flags [16] | residual partials [4 wpg][4] | per wavefront d[S * 4 nu]
 __host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg, int S, bool fam, int nl) {
-    return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg +
-                             (size_t)wpg * ((S * 4 * nu + 1) & ~1));
+    return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg + 64 +
+                             (size_t)wpg * ((S * 4 * nu + 1) & ~1));  // (+ 64: the session's mailbox copy)
 }
 
 // Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
@@ -286,6 +286,8 @@ void solve_jit_describe(int W, int nx, int nu, int N, bool const_tables, bool fa
 bool solve_f_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *chunks, int *wpg, size_t *lds_bytes);
 bool solve_f_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
 hipError_t launch_solve_f(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
+bool solve_f_session_supported(int nx, int nu, int N, bool families, const FamilyStructure &fs);  // the resident closed-loop variant (compiles)
+hipError_t launch_solve_f_session(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
 void solve_f_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);

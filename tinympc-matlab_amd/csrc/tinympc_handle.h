@@ -147,6 +147,7 @@ struct tinympc_solver {
     // from this mailbox in pinned memory (layout: SolveParams::mail).
     double *h_mail = nullptr;          // [64]
     bool session_active = false;
+    bool session_on_f = false;  // ... and its resident kernel is layout F's (families beyond what the latency kernel's session holds)
     // Taken by everything that writes the mailbox or (re)starts the resident kernel: session_step (for the whole tick), end_session
     // and park_sessions_on_device -- the one place where a thread reaches into a handle it does not own. Lock order: the session
     // registry (tinympc_session.hip) first, then this.

@@ -86,7 +86,7 @@ int decide_layout_e(tinympc_solver *s) {
 // first time; cached inside tinympc_jit.hip). TINYMPC_LAYOUT=F forces it at any batch size (tests), any other value excludes it.
 int decide_layout_f(tinympc_solver *s) {
     const bool fam = s->families_active();
-    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && !s->session_active && s->N >= 6;
+    const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && (!s->session_active || s->session_on_f) && s->N >= 6;
     // Default: the families at small batches -- rocket landing N=100, one instance: 4.5 us per iteration against 6.55 on the
     // round-1 latency kernel. The box path stays on layout C: with four wavefronts (plan_f) layout F is 4 % ahead there too
     // (quadrotor N=50: 2.75 against 2.86 us), but layout C stages per-tick references from pinned memory inside the kernel, runs the

@@ -48,8 +48,15 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
 }
 
 int launch_session_kernel(tinympc_solver *s) {
-    int rc = refresh_derived(s);
-    if (rc) return rc;
+    int rc;
+    // (layout F's kernel has no staging of references left in pinned memory in its prologue: the ordinary upload first)
+    // (... also on a restart after the idle time-out: reference shifts of the session so far only reached the LDS tables of the
+    // kernel that has left; the pinned copies are current)
+    if (s->session_on_f && (s->refs_on_host || s->session_refs_shifted || s->xref_shift || s->uref_shift)) {
+        if ((rc = flush_host_refs(s))) return rc;
+        s->session_refs_shifted = false;
+    }
+    if ((rc = refresh_derived(s))) return rc;
     const bool fam = s->families_active();
     if (fam && (rc = refresh_families(s))) return rc;
     if ((rc = materialize_cold_state(s))) return rc;  // (the resident kernel loads its state from HBM)
@@ -73,6 +80,12 @@ int launch_session_kernel(tinympc_solver *s) {
     p.mail = s->h_mail;
     p.session_expect = (double)(s->session_seq + 1);
     p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
+    if (s->session_on_f) {
+        p.const_tables = 0;  // (the session kernel always carries per-knot tables: references may change from tick to tick)
+        p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
+        HIP_TRY(launch_solve_f_session(p, s->f_fs, s->stream));
+        return TINYMPC_OK;
+    }
     HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
     return TINYMPC_OK;
 }
@@ -112,6 +125,7 @@ int tinympc::host::end_session(tinympc_solver *s) {
     if (!s->session_active) return TINYMPC_OK;
     write_command(s, 1, nullptr);  // stop
     s->session_active = false;     // (before anything that could come back here)
+    s->session_on_f = false;
     if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
     s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -124,15 +138,23 @@ int tinympc_session_begin(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;  // (ends a session that is still open)
-    if (!s->host_path() || !(s->layout_c || (s->families_active() && s->fam_c)))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles on the latency kernel only (batch 1, nx+nu <= 16, N <= 129)");
     if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
-    if (s->families_active() && s->chunk_len > 4)
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cone / linear families are supported for horizons up to N = 65 (got %d)", s->N);
-    if (s->families_active() && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "session: cones that share rows (or more than %d cones / %d linear rows per side) are not supported by the resident kernel",
-                    MAX_CONES, MAX_LIN_ROWS);
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
+    // Which resident kernel: the latency kernel's SESSION variant (layout C) wherever it holds the configuration -- box path, families up
+    // to N = 65 with disjoint cones --, else layout F's (round 4: the structure-specialised latency kernel; families at any horizon it
+    // plans, overlapping cones, constraint lists beyond the generic kernels' capacities), where the handle's launches run on layout F.
+    const bool fam = s->families_active();
+    const bool c_ok = s->host_path() && (s->layout_c || (fam && s->fam_c)) && !(fam && s->chunk_len > 4) &&
+                      !(fam && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()));
+    s->session_on_f = false;
+    if (!c_ok) {
+        if (!s->host_path()) return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles only (batch 1, nx+nu <= 16)");
+        if ((rc = resolve_plan(s))) return rc;
+        if (current_plan(s).kernel != KernelId::F || !solve_f_session_supported(s->nx, s->nu, s->N, fam, s->f_fs))
+            return fail(TINYMPC_ERR_UNSUPPORTED, "session: neither the latency kernel (box path; families up to N = 65, disjoint cones) nor layout F "
+                        "(run-time specialised; TINYMPC_JIT not 0) has a resident kernel for this configuration (N = %d)", s->N);
+        s->session_on_f = true;
+    }
     if (!s->h_mail) {
         HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
         std::memset(s->h_mail, 0, sizeof(double) * 64);

@@ -18,8 +18,12 @@
 // wavefronts' totals through LDS behind ONE barrier and a Horner recurrence with P^4S, a last mat-vec (P^jS) per row.
 // Given exact carries pass 2 IS the sequential sweep; results differ from the other layouts through the rounding of the carries
 // (~1e-14 relative), iteration counts match the restatement in every test. Same persistent HBM state as every other kernel;
-// single-instance handles' pinned-host paths (x0 in, solution / statistics / completion stamp out) as in layout C. No session,
-// no adaptive rho.
+// single-instance handles' pinned-host paths (x0 in, solution / statistics / completion stamp out) as in layout C. No adaptive rho.
+// SESSION (round 4, TINY_JIT_F_SESSION): the resident closed-loop variant -- layout C's mailbox protocol (tinympc_session.hip,
+// tinympc_solve_c.hip) around this kernel's iteration, so that the rocket landing's closed loop (rocket_landing_constraints.m:86-121:
+// N = 100, new references every tick) runs without a launch per tick; the latency kernel's own session ends at N = 65 with families.
+// The ADMM state stays in registers from tick to tick; references live in the LDS copy of the tables (always per-knot tables here),
+// refreshed from pinned memory on request or shifted by one knot with the new last column that came with the command.
 #include <type_traits>
 
 #include "tinympc_device.h"
@@ -40,6 +44,9 @@
 #define TINY_JIT_E_NLX 1
 #define TINY_JIT_E_NLU 0
 #endif
+#ifndef TINY_JIT_F_SESSION
+#define TINY_JIT_F_SESSION 0
+#endif
 
 namespace tinympc {
 template <int NX, int NU>
@@ -52,8 +59,9 @@ struct DStep;  // tinympc_solve_d_chain.h
 
 namespace tinympc {
 
-template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM>
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool SESSION>
 __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double *smem) {
+    static_assert(!SESSION || !CT, "layout F: the session kernel keeps its references in the LDS copy of the per-knot tables");
     constexpr int W = 16, NXU = NX + NU, NS = N - 1, DS = 4 * NU;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
     constexpr int KS = NX <= 8 ? 8 : NX <= 12 ? 12 : 16;    // row stride of the carry matrices (chunk_ks)
@@ -84,7 +92,8 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     double *sY = sPow + 2 * 4 * 256;                        // [2][WPG][16] the wavefronts' totals of a scan, double-buffered
     int *sFlag = reinterpret_cast<int *>(sY + 2 * WPG * 16);  // [2][WPG] "every lane below tolerance" per wavefront (16 doubles)
     double *sRes = sY + 2 * WPG * 16 + 16;                  // [4 WPG][4] residual maxima per chunk
-    double *sD = sRes + 4 * WPG * 4 + (size_t)wv * ((S * DS + 1) & ~1);  // per wavefront: d[S][4 rows x nu]
+    double *sMail = sRes + 4 * WPG * 4;                     // [64] the session's mailbox as last polled (+ the poller's verdict)
+    double *sD = sMail + 64 + (size_t)wv * ((S * DS + 1) & ~1);  // per wavefront: d[S][4 rows x nu]
 
     for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
         const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
@@ -127,7 +136,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     const bool k0 = bottomc && is_x;
     double G0 = k0 ? gG[0] : 0.0, V0 = k0 ? gV[0] : 0.0, V0p = V0;
     double GC0 = (FAM && k0) ? (p.GC + vbase)[0] : 0.0, GL0 = (FAM && k0) ? (p.GL + vbase)[0] : 0.0;
-    const double x0v = k0 ? p.x0[inst * NX + r] : 0.0;
+    double x0v = k0 ? p.x0[inst * NX + r] : 0.0;
     if (p.x0_mirror && k0) p.x0_mirror[inst * NX + r] = x0v;  // x0 came from pinned host memory: keep the device copy current
     __syncthreads();  // (the only barrier that also waits for global loads)
 
@@ -136,7 +145,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
 
     const double cf = p.ops[(size_t)2 * W * KT + r];
     const double cb = p.ops[(size_t)2 * W * KT + W + r];
-    const double pnref = p.tables[(size_t)3 * TOFF + r];
+    double pnref = p.tables[(size_t)3 * TOFF + r];
     const double nrho = -p.rho;
     const double rhom = is_x ? nrho : 0.0;
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
@@ -218,7 +227,140 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     bool res_valid = false, converged = false;
     double snap_pri = 0.0, snap_dua = 0.0;
 
+    // ---- write-back of the persistent ADMM state (one-shot: after the solve; session: when the kernel leaves). A converged solve
+    // returned before v <- vnew (admm.cpp:181-197): its canonical slack is the previous iterate.
+    auto write_state = [&](bool conv) {
+        e_static_for<0, S>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if ((i < nsl) && row_ok) {
+                const size_t k = (size_t)(s0 + i), kn = k + koff;
+                gG[kn * 64] = G[i];
+                gV[kn * 64] = conv ? Vp[i] : V[i];
+                if constexpr (FAM) {
+                    (p.GC + vbase)[kn * 64] = GC[i];
+                    (p.GL + vbase)[kn * 64] = GL[i];
+                }
+                if (is_u) gD[k * DS] = sD[i * DS + dIdx];
+            }
+        });
+        if (k0) {
+            gG[0] = G0;
+            gV[0] = conv ? V0p : V0;
+            if constexpr (FAM) {
+                (p.GC + vbase)[0] = GC0;
+                (p.GL + vbase)[0] = GL0;
+            }
+        }
+    };
+
     const int max_iter = p.max_iter;
+    const int tid = (int)threadIdx.x;
+    double expect = p.session_expect;
+    for (;;) {  // ---- SESSION: every pass is one closed-loop tick (one pass otherwise)
+    if constexpr (SESSION) {
+        // Poll the mailbox (layout: SolveParams::mail; protocol and checksum as in tinympc_solve_c.hip): lanes 0..55 fetch its lines
+        // in one load, everybody takes the same decision from LDS. The poller's clock ends the session after p.session_idle
+        // ticks without a command -- the exit every wavefront reaches even if the host process is gone.
+        const unsigned long long t_idle0 = __builtin_amdgcn_s_memrealtime();
+        bool go = false, quit = false;
+        while (!go && !quit) {
+            if (tid < 56) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+            __syncthreads();
+            auto line_ok = [&](int l) -> bool {
+                unsigned long long x = 0ull;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) x ^= (unsigned long long)__builtin_bit_cast(long long, sMail[8 * l + q]);
+                return sMail[8 * l + 7] == mail_stamp(expect, x);
+            };
+            go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
+            const int f0 = go ? (int)sMail[0] : 0;
+            const int npay = 1 + NX + ((f0 & 4) ? NX : 0) + ((f0 & 8) ? NU : 0), nlines = (npay + 6) / 7;
+            for (int l = 1; l < nlines; ++l) go = go && line_ok(l);
+            quit = !go && sMail[56] != 0.0;
+            __syncthreads();  // (the next poll overwrites sMail)
+        }
+        const int flags = go ? (int)sMail[0] : 1;
+        if (quit || (flags & 1)) {  // stop requested, or nobody is talking to this kernel any more
+            write_state(false);     // (a converged tick already rolled its slack back, see the end of the loop)
+            break;
+        }
+        auto payload = [&](int q) -> double { return sMail[8 * (q / 7) + q % 7]; };
+        if (k0) {
+            x0v = payload(1 + r);
+            if (p.x0_mirror) p.x0_mirror[inst * NX + r] = x0v;
+        }
+        double *const tab = const_cast<double *>(p.tables);  // (mirror: the table rows the other kernels read)
+        if (flags & 2) {
+            // the references changed: fetch them again from the pinned copies (tinympc_set_x_ref / _u_ref filled them), derive the
+            // table rows -(Xref o Q), -(Uref o R) (the expressions of k_build_tables) and pNref. Acquire: the stamp was observed,
+            // what the host wrote before it must be too.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            const double *const dg = p.ops + (size_t)2 * W * KT + 2 * W;
+            for (int i = tid; i < NX * N; i += 64 * WPG) {
+                const double x = p.href_x[i];
+                const int kn = i / NX, rr = i % NX;
+                p.dXref[i] = x;
+                const double v = -(x * dg[rr]);
+                sT[2 * TOFF + (kn + 1) * W + rr] = v;
+                tab[(size_t)2 * TOFF + (size_t)(kn + 1) * W + rr] = v;
+            }
+            for (int i = tid; i < NU * NS; i += 64 * WPG) {
+                const double u = p.href_u[i];
+                const int kn = i / NU, rr = NX + i % NU;
+                p.dUref[i] = u;
+                const double v = -(u * dg[rr]);
+                sT[2 * TOFF + (kn + 1) * W + rr] = v;
+                tab[(size_t)2 * TOFF + (size_t)(kn + 1) * W + rr] = v;
+            }
+            double acc = 0.0;  // pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81), the sum term by term in the order of k_build_tables
+            if (is_x) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) acc += p.href_x[q + (size_t)(N - 1) * NX] * p.Pinf[q + (size_t)r * NX];
+                acc = -acc;
+            }
+            pnref = acc;
+            if (wv == 0 && j == 0) tab[(size_t)3 * TOFF + r] = pnref;
+        } else if (flags & 12) {
+            // Receding horizon (rocket_landing_constraints.m:96-101): the new reference is the previous one moved up by one knot plus
+            // ONE new last column, which came with the command -- no 7 KB PCIe read, a shift of the LDS table's rows. The host
+            // checked, bit for bit, that it IS a shift; the device copies / global tables lag until the session ends (the host knows).
+            const double *const dg = p.ops + (size_t)2 * W * KT + 2 * W;
+            constexpr int NT = 64 * WPG, NEL = (N - 1) * W, NQ = (NEL + NT - 1) / NT;
+            double tmp[NQ];
+            e_static_for<0, NQ>([&](auto Q) {
+                const int idx = tid + Q.value * NT, kn = idx >> 4, rr = idx & 15;
+                const bool mine = rr < NX ? ((flags & 4) != 0 && kn <= N - 2) : (rr < NXU ? ((flags & 8) != 0 && kn <= N - 3) : false);
+                tmp[Q.value] = (idx < NEL && mine) ? sT[2 * TOFF + (kn + 2) * W + rr] : 0.0;
+            });
+            __syncthreads();
+            e_static_for<0, NQ>([&](auto Q) {
+                const int idx = tid + Q.value * NT, kn = idx >> 4, rr = idx & 15;
+                const bool mine = rr < NX ? ((flags & 4) != 0 && kn <= N - 2) : (rr < NXU ? ((flags & 8) != 0 && kn <= N - 3) : false);
+                if (idx < NEL && mine) sT[2 * TOFF + (kn + 1) * W + rr] = tmp[Q.value];
+            });
+            if (tid < NXU) {
+                const int rr = tid;
+                if (rr < NX && (flags & 4)) sT[2 * TOFF + N * W + rr] = -(payload(1 + NX + rr) * dg[rr]);                                        // knot N-1
+                if (rr >= NX && (flags & 8)) sT[2 * TOFF + (N - 1) * W + rr] = -(payload(1 + NX + ((flags & 4) ? NX : 0) + (rr - NX)) * dg[rr]);  // knot N-2
+            }
+            if (flags & 4) {  // pNref from the new last column
+                double acc = 0.0;
+                if (is_x) {
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) acc += payload(1 + NX + q) * p.Pinf[q + (size_t)r * NX];
+                    acc = -acc;
+                }
+                pnref = acc;
+            }
+        }
+        __syncthreads();  // sMail has been read by everyone; the table rows are in place
+        it_done = 0;
+        status = 11;
+        res_valid = false;
+        converged = false;
+        snap_pri = snap_dua = 0.0;
+    }
     for (int it = 0; it < max_iter; ++it) {  // admm.cpp:129
         const int it0 = __builtin_amdgcn_readfirstlane(it);
         const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && (((it0 + 1) % ct) == 0))) != 0;  // admm.cpp:91
@@ -377,19 +519,12 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     if (r < 4) sRes[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gdx : (r == 2) ? gpu : gdu;
     e_barrier();
 
-    // ---- write-back: solution (device + pinned host), the ADMM state for the next launch. A converged solve returned before
-    // v <- vnew: its canonical slack is the previous iterate.
+    // ---- write-back: solution (device + pinned host); one-shot launches also leave the ADMM state for the next launch
     if (max_iter > 0) {
         e_static_for<0, S>([&](auto I) {
             constexpr int i = decltype(I)::value;
             if ((i < nsl) && row_ok) {
-                const size_t k = (size_t)(s0 + i), kn = k + koff;
-                gG[kn * 64] = G[i];
-                gV[kn * 64] = converged ? Vp[i] : V[i];
-                if constexpr (FAM) {
-                    (p.GC + vbase)[kn * 64] = GC[i];
-                    (p.GL + vbase)[kn * 64] = GL[i];
-                }
+                const size_t kn = (size_t)(s0 + i) + koff;
                 if (is_x) {
                     p.sol_x[((size_t)inst * N + kn) * NX + r] = V[i];
                     if (p.host_sol) p.host_sol[kn * NX + r] = V[i];
@@ -397,20 +532,14 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                     p.sol_u[((size_t)inst * NS + kn) * NU + (r - NX)] = V[i];
                     if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * NU + (r - NX)] = V[i];  // first controls straight to the host
                     if (p.host_sol) p.host_sol[(size_t)N * NX + kn * NU + (r - NX)] = V[i];
-                    gD[k * DS] = sD[i * DS + dIdx];
                 }
             }
         });
         if (k0) {
-            gG[0] = G0;
-            gV[0] = converged ? V0p : V0;
-            if constexpr (FAM) {
-                (p.GC + vbase)[0] = GC0;
-                (p.GL + vbase)[0] = GL0;
-            }
             p.sol_x[(size_t)inst * N * NX + r] = V0;
             if (p.host_sol) p.host_sol[r] = V0;
         }
+        if constexpr (!SESSION) write_state(converged);
     }
     if (threadIdx.x == 0) {
         double res[4] = {0.0, 0.0, 0.0, 0.0};
@@ -437,12 +566,22 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             }
         }
     }
-    if (p.host_sol && p.host_seq != 0.0) {  // (uniform) everything above is in pinned memory: raise the completion stamp
+    if (p.host_sol && (SESSION || p.host_seq != 0.0)) {  // (uniform) everything above is in pinned memory: raise the completion stamp
         __threadfence_system();
         __syncthreads();
+        // (a system-scope atomic store: a plain store may sit in the L2 until the kernel ends -- which a resident session kernel does not do)
         if (threadIdx.x == 0)
-            __hip_atomic_store(p.host_sol + (size_t)N * NX + (size_t)NS * NU + 6, p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.host_sol + (size_t)N * NX + (size_t)NS * NU + 6, SESSION ? expect : p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if constexpr (!SESSION) break;
+    // The next tick warm-starts from the registers. A converged solve returns before v <- vnew (admm.cpp:181-197): its canonical
+    // slack is the previous iterate -- what an ordinary launch would have written back and read again.
+    if (converged) {
+        e_static_for<0, S>([&](auto I) { V[I.value] = Vp[I.value]; });
+        V0 = V0p;
+    }
+    expect += 1.0;
+    }  // ticks
 }
 
 }  // namespace tinympc
@@ -458,8 +597,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, (TINY_JIT_F_WPG + 3) / 4 > 2 ? (TINY_JIT_F_WPG + 3) / 4 : 2)))
 TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
+    constexpr bool SESJ = TINY_JIT_F_SESSION != 0;
     constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL);
     static_assert(bytes <= 160 * 1024, "layout F: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_f[bytes / sizeof(double)];
-    tinympc::k_admm_solve_f_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ>(p, smem_f);
+    tinympc::k_admm_solve_f_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, SESJ>(p, smem_f);
 }
