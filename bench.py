@@ -119,6 +119,7 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
     import pyoracle as O  # checker / baseline only
     import __graft_entry__ as ge
 
+    import numpy as np
     prob = ge.load_package().problems.rocket(100)
     solver = O.OraclePort(prob).load_problem(prob, dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=iters, check_termination=1))
     total = 0
@@ -128,7 +129,24 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
         solver.set_x0(prob.x0)
         solver.solve()
         total += solver.stats()["iter"]
-    print(total, time.perf_counter() - t0, flush=True)
+    elapsed_iter = time.perf_counter() - t0
+    # ... and BASELINE config 4 as the reference uses it (rocket_landing_constraints.m:86-121): a closed loop with the reference
+    # trajectory re-sent every tick, tol 5e-2, max_iter 200, 100 ticks -- same loop as bench.py's `rocket_closed_loop` leg
+    solver = O.OraclePort(prob).load_problem(prob, dict(abs_pri_tol=5e-2, abs_dua_tol=5e-2, max_iter=200, check_termination=1))
+    x, goal = prob.x0.copy(), np.zeros(prob.nx)
+    tl, its = 0.0, 0
+    for k in range(110):
+        x_ref = np.stack([prob.x0 + (goal - prob.x0) * min(i + k, 140) / 140 for i in range(prob.N)], axis=1)
+        t1 = time.perf_counter()
+        solver.set_x_ref(x_ref)
+        solver.set_x0(x)
+        solver.solve()
+        u0 = solver.solution()[1][:, 0]
+        if k >= 10:
+            tl += time.perf_counter() - t1
+            its += solver.stats()["iter"]
+        x = prob.A @ x + prob.B @ u0 + prob.fdyn
+    print(total, elapsed_iter, 1e6 * tl / 100, its / 100, flush=True)
     return 0
 
 
@@ -306,7 +324,10 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
                 "(%s physical cores) and %.0f s of work took %.1f s of wall clock" % (len(rates), eff, physical, seconds, wall))
     rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.split()
-    rocket_us = 1e6 * float(rocket[-1]) / int(rocket[-2]) if len(rocket) >= 2 and int(rocket[-2]) > 0 else None
+    rocket_us = rocket_tick_us = rocket_tick_its = None
+    if len(rocket) >= 4 and int(rocket[-4]) > 0:
+        rocket_us = 1e6 * float(rocket[-3]) / int(rocket[-4])
+        rocket_tick_us, rocket_tick_its = float(rocket[-2]), float(rocket[-1])
     lat = {}
     try:
         lat = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-latency", "--cpu-seconds", "1"],
@@ -314,6 +335,7 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     except (ValueError, IndexError):
         pass
     return {"value": value, "rocket_us_per_iter_single_process": rocket_us,
+            "rocket_closed_loop_us_per_tick_single_process": rocket_tick_us, "rocket_closed_loop_iterations_per_tick": rocket_tick_its,
             "cartpole_us_per_iter_single_process": lat.get("cartpole_us_per_iter"),
             "closed_loop_us_per_tick_single_process": lat.get("closed_loop_us_per_tick"),
             "closed_loop_iterations_per_tick": lat.get("closed_loop_iterations_per_tick"),
@@ -887,6 +909,43 @@ def main() -> int:
             tick["cpu_reference_iterations_per_tick"] = cpu.get("closed_loop_iterations_per_tick") if cpu else None
             tick["cpu_reference_note"] = ("the reference's own core (oracle/_ref) on one host core: set_x0 + solve + first control per tick, the loop in "
                                           "compiled code; no MATLAB / MEX overhead on its side, the Python mirror's ctypes calls on the GPU's side")
+            # ... and BASELINE config 4's own closed loop (rocket_landing_constraints.m:86-121): N = 100, cones + linear row + fdyn, the
+            # reference trajectory re-sent every tick (a receding horizon: inside a session only its new last column travels)
+            rk = P.rocket(100)
+            goal = np.zeros(rk.nx)
+            rtick = {}
+            for mode in ("launch", "session"):
+                tk = pkg.TinyMPC()
+                tk.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=dev_index, rho=rk.rho, fdyn=rk.fdyn, abs_pri_tol=5e-2, abs_dua_tol=5e-2, max_iter=200)
+                tk.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
+                tk.set_u_ref(rk.u_ref)
+                tk.set_cone_constraints(**rk.cones)
+                tk.set_linear_constraints(**rk.linear)
+                tk.set_x_ref(rk.x_ref)
+                tk.prepare()
+                layout = tk.launch_info()["layout"]
+                if mode == "session":
+                    tk.session_begin()
+                x = rk.x0.copy()
+                dts, its = [], 0
+                for k in range(110):
+                    x_ref = np.stack([rk.x0 + (goal - rk.x0) * min(i + k, 140) / 140 for i in range(rk.N)], axis=1)
+                    t0 = time.perf_counter()
+                    tk.set_x_ref(x_ref)
+                    u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
+                    dt = time.perf_counter() - t0
+                    if k >= 10:
+                        dts.append(dt)
+                        its += int(tk.get_stats()["iter"])
+                    x = rk.A @ x + rk.B @ u0 + rk.fdyn
+                if mode == "session":
+                    tk.session_end()
+                rtick[mode] = {"us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick": 1e6 * float(np.mean(dts)), "iterations_per_tick": its / 100, "layout": layout}
+                tk.reset()
+            rtick["cpu_port_us_per_tick"] = cpu.get("rocket_closed_loop_us_per_tick_single_process") if cpu else None
+            rtick["cpu_port_iterations_per_tick"] = cpu.get("rocket_closed_loop_iterations_per_tick") if cpu else None
+            out["rocket_closed_loop"] = dict(workload="rocket landing N=100, cones + linear row + fdyn, one instance, warm start, tol 5e-2, the reference trajectory "
+                                                      "re-sent every tick, 100 ticks (set_x_ref + tick, through the Python mirror)", **rtick)
             out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -915,7 +974,9 @@ def main() -> int:
                 "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),
                 "cartpole_batch_8192_iters_per_s": leg("cartpole/batch_8192/iters_per_s"), "cartpole_batch_8192_fp64_frac": leg("cartpole/batch_8192/fp64_frac"),
                 "closed_loop_tick_launch_us": leg("closed_loop_tick/launch/us_per_tick_median"), "closed_loop_tick_session_us": leg("closed_loop_tick/session/us_per_tick_median"),
-                "closed_loop_tick_cpu_reference_us": leg("cpu_baseline/closed_loop_us_per_tick_single_process")}
+                "closed_loop_tick_cpu_reference_us": leg("cpu_baseline/closed_loop_us_per_tick_single_process"),
+                "rocket_closed_loop_launch_us": leg("rocket_closed_loop/launch/us_per_tick_median"), "rocket_closed_loop_session_us": leg("rocket_closed_loop/session/us_per_tick_median"),
+                "rocket_closed_loop_cpu_port_us": leg("cpu_baseline/rocket_closed_loop_us_per_tick_single_process")}
         legs = {k: v for k, v in legs.items() if v is not None}
         for k, v in legs.items():
             if k != "value_as_asked":
