@@ -149,17 +149,19 @@ def test_unsupported_family_shapes_fail_loudly(pkg):
     rk = P.rocket(10, with_linear=False)
     rk.cones = {}
     s = make(pkg, rk, {})
-    with pytest.raises(pkg.TinyMPCError) as ei:  # a chain of five cones, each sharing a row with its predecessor: five rounds
-        s.set_cone_constraints([0, 1, 2, 3, 4], [2, 2, 2, 2, 2], [0.5] * 5, [], [], [])
+    with pytest.raises(pkg.TinyMPCError) as ei:  # more cones than the family buffer ever holds (64)
+        s.set_cone_constraints([0] * 65, [2] * 65, [0.5] * 65, [], [], [])
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     with pytest.raises(pkg.TinyMPCError) as ei:  # cone outside the state vector
         s.set_cone_constraints([4], [3], [0.5], [], [], [])
     assert ei.value.code == pkg._lib.ERR_INVALID_INPUT
-    with pytest.raises(pkg.TinyMPCError) as ei:  # more rows than the family buffer holds
-        s.set_linear_constraints(np.ones((33, 6)), np.ones(33), np.zeros((0, 3)), np.zeros(0))
+    with pytest.raises(pkg.TinyMPCError) as ei:  # more rows than the family buffer ever holds (128 per side)
+        s.set_linear_constraints(np.ones((129, 6)), np.ones(129), np.zeros((0, 3)), np.zeros(0))
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
     s.solve()  # nothing was installed by the failed calls: plain box solve still works
     s.reset()
+    # (a chain of five cones, each sharing a row with its predecessor -- five rounds --, 33 linear rows: refused until round 3, run on the
+    # structure-specialised kernels since round 4: test_shapes_beyond_the_generic_kernels_limits)
 
 
 def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
