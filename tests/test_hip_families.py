@@ -191,9 +191,11 @@ def test_large_batch_of_long_horizons_default_kernel_choice(pkg, monkeypatch):
 @pytest.mark.parametrize("variant", ["cones", "linear", "both", "both_constant_references"])
 @pytest.mark.parametrize("N", [10, 20, 28])
 def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
-    """Short horizons, large batches: the families ride on the run-time specialised layout D (gc, gl, lx in registers next to
-    g and v; tinympc_jit.hip with -DTINY_JIT_FAM=1). The library's own choice; cold start and a warm start against the
-    restatement for every instance, then the same two solves on k_admm_solve_fam (TINYMPC_JIT=0)."""
+    """Short horizons, large batches. The library's own choice since round 4: layout E's UNCUT form (one wavefront per group of four
+    instances, the families one knot per lane) up to N = 20, its cut form beyond; layout D's families variant (gc, gl, lx in
+    registers next to g and v; -DTINY_JIT_FAM=1) remains behind TINYMPC_LAYOUT=D up to N = 22. Cold start and a warm start against
+    the restatement for every instance on the library's choice; the same two solves on layout D's variant and on k_admm_solve_fam
+    (TINYMPC_JIT=0) against it."""
     monkeypatch.delenv("TINYMPC_LAYOUT")
     P = pkg.problems
     rk = P.rocket(N, with_linear=variant != "cones")
@@ -207,8 +209,14 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
     x0a = rk.x0[:, None] * rng.uniform(0.6, 1.2, (1, batch)) + 0.1 * rng.standard_normal((6, batch))
     x0b = x0a + 0.05 * rng.standard_normal((6, batch))
     results = {}
-    for jit in ("1", "0"):
-        monkeypatch.setenv("TINYMPC_JIT", jit)
+    for jit in ("1", "D", "0"):
+        if jit == "D" and N > 22:
+            continue
+        monkeypatch.setenv("TINYMPC_JIT", "0" if jit == "0" else "1")
+        if jit == "D":
+            monkeypatch.setenv("TINYMPC_LAYOUT", "D")
+        else:
+            monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
         s = make(pkg, rk, settings, batch=batch)
         out = []
         for x0s in (x0a, x0b):
@@ -217,9 +225,14 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
             out.append((s.get_solution_batch(), s.get_stats_batch()))
         # (without the specialiser: k_admm_solve_fam, whatever the box path's layout; N = 28 is beyond what layout D holds in
         # registers with the families -- layout E takes it, four wavefronts per workgroup on the 512-register plan)
-        assert s.launch_info()["layout"] == ("A" if jit == "0" else "D" if N <= 22 else "E"), s.jit_info()
+        if jit == "1":  # (N = 20 with constant tables: the uncut form's register estimate says no -- layout D's variant takes it)
+            assert s.launch_info()["layout"] == ("D" if (N == 20 and variant == "both_constant_references") else "E"), s.jit_info()
+            assert ("uncut" in s.jit_info()) == (N <= 20 and s.launch_info()["layout"] == "E"), s.jit_info()
+        else:
+            assert s.launch_info()["layout"] == ("A" if jit == "0" else "D"), s.jit_info()
         results[jit] = out
         s.reset()
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
     orc = [oracle(rk, settings) for _ in range(batch)]
     for rnd, x0s in enumerate((x0a, x0b)):
         sol, st = results["1"][rnd]
@@ -233,9 +246,11 @@ def test_families_on_layout_d(pkg, kernel_layout, monkeypatch, variant, N):
         for b in range(0, batch, 7):
             assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL
             assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL
-        sol0, st0 = results["0"][rnd]
-        np.testing.assert_array_equal(st["iter"], st0["iter"])
-        assert rel_err(sol["controls"], sol0["controls"]) < TOL and rel_err(sol["states"], sol0["states"]) < TOL
+        for other in ("0", "D"):
+            if other in results:
+                sol0, st0 = results[other][rnd]
+                np.testing.assert_array_equal(st["iter"], st0["iter"])
+                assert rel_err(sol["controls"], sol0["controls"]) < TOL and rel_err(sol["states"], sol0["states"]) < TOL
     assert (results["1"][0][1]["status"] == 1).any() and (results["1"][1][1]["iter"] < results["1"][0][1]["iter"]).any()
 
 
@@ -247,8 +262,8 @@ def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
     a workgroup, run-time specialised on the cone list and the linear rows per side). Cold start and a warm start against the
     restatement for every instance -- iteration counts and statuses exact --, and against the latency kernel on the same handle
     (the two share the persistent HBM state). N=100: eight chunks of 13, the last one 8; N=44: eight chunks would leave the last
-    wavefront one slot, so the plan is four wavefronts (one per SIMD, 512 registers) with chunks of 11 and 10; N=10: no plan at all
-    (chunks of at least three slots) -- the refusal path: the handle says so and runs on another kernel."""
+    wavefront one slot, so the plan is four wavefronts (one per SIMD, 512 registers) with chunks of 11 and 10; N=10: the UNCUT form
+    (round 4: one wavefront per group, no pass 1, no carries; until round 3 this shape had no plan at all)."""
     monkeypatch.setenv("TINYMPC_LAYOUT", "E")
     P = pkg.problems
     rk = P.rocket(N, with_linear=variant in ("linear", "both", "both_constant_references"))
@@ -266,13 +281,7 @@ def test_families_on_layout_e(pkg, kernel_layout, monkeypatch, variant, N):
     s = make(pkg, rk, settings, batch=batch)
     s.prepare()
     info = s.jit_info()
-    if N == 10:
-        assert s.launch_info()["layout"] != "E" and info.startswith("refused("), info
-        s.set_x0_batch(x0a)
-        s.solve()  # (on the fallback kernel)
-        assert np.all(s.get_stats_batch()["iter"] > 0)
-        s.reset()
-        return
+    assert ("uncut" in info) == (N == 10), info
     assert s.launch_info()["layout"] == "E" and info.startswith(("compiled ", "disk-cache ", "compiled-in ")) and "scratch=0" in info, info
     out = []
     for x0s in (x0a, x0b):
@@ -327,12 +336,12 @@ def test_prepare_specialises_before_the_first_solve(pkg, kernel_layout, monkeypa
     monkeypatch.delenv("TINYMPC_LAYOUT")
     rk = pkg.problems.rocket(10)
     s = make(pkg, rk, dict(max_iter=30, abs_pri_tol=1e-3, abs_dua_tol=1e-3), batch=1500)
-    assert s.launch_info()["layout"] != "D"  # not decided yet: k_admm_solve_fam would run
+    assert s.launch_info()["layout"] not in ("D", "E")  # not decided yet: k_admm_solve_fam would run
     s.prepare()
-    assert s.launch_info()["layout"] == "D"
+    assert s.launch_info()["layout"] == "E" and "uncut" in s.jit_info()
     s.set_x0_batch(np.repeat(rk.x0[:, None], 1500, axis=1))
     s.solve()
-    assert s.launch_info()["layout"] == "D" and np.all(s.get_stats_batch()["iter"] > 0)
+    assert s.launch_info()["layout"] == "E" and np.all(s.get_stats_batch()["iter"] > 0)
     s.reset()
 
 
@@ -385,7 +394,8 @@ def test_layout_d_variants_share_the_persistent_state_with_the_other_kernels(pkg
     if what == "box":  # (the box kernel is chosen at setup; only the variants are decided per launch)
         assert seen == ["D"] * 4, seen
     else:
-        assert seen[0] == "D" and seen[2] == "D" and seen[1] != "D" and seen[3] != "D", seen
+        fast = "E" if what == "families" else "D"  # (families at this horizon: layout E's uncut form since round 4)
+        assert seen[0] == fast and seen[2] == fast and seen[1] not in ("D", "E") and seen[3] not in ("D", "E"), seen
     s.reset()
 
 

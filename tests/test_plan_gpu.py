@@ -41,7 +41,8 @@ CASES = [
     ("rocket100 x4096 run-time compiled", lambda P: P.rocket(100), 4096, "families", {"TINYMPC_BUILTIN": "0"}, "E", ("compiled ", "disk-cache"), 1024),
     ("rocket100 single run-time compiled", lambda P: P.rocket(100), 1, "families", {"TINYMPC_BUILTIN": "0"}, "F", ("compiled ", "disk-cache"), 1),
     ("rocket44 x4096", lambda P: P.rocket(44), 4096, "families", {}, "E", ("compiled ", "disk-cache"), 1024),
-    ("rocket10 x4096", lambda P: P.rocket(10), 4096, "families", {}, "D", ("compiled", "disk-cache"), None),
+    ("rocket10 x4096", lambda P: P.rocket(10), 4096, "families", {}, "E", ("compiled ", "disk-cache"), 256),  # (the uncut form: four groups per workgroup)
+    ("rocket10 x4096 on layout D", lambda P: P.rocket(10), 4096, "families", {"TINYMPC_LAYOUT": "D"}, "D", ("compiled ", "disk-cache"), None),
     ("rocket100 single no specialiser", lambda P: P.rocket(100), 1, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 1),
     ("rocket100 x4096 no specialiser", lambda P: P.rocket(100), 4096, "families", {"TINYMPC_JIT": "0"}, "C", ("refused(TINYMPC_JIT=0)",), 4096),
     ("rocket100 overlapping cones single", lambda P: P.rocket(100), 1, "overlap", {}, "F", ("compiled", "disk-cache"), 1),

@@ -28,7 +28,7 @@ def _wide_system(P, nx, nu, N, seed=0, a_scale=0.03, b_scale=0.1, diag=1.0):
     return prob
 
 
-CASES = [("A", "rocket", 10, 64), ("D", "rocket", 10, 64), ("E", "rocket", 100, 32), ("F", "rocket", 100, 8),
+CASES = [("A", "rocket", 10, 64), ("D", "rocket", 10, 64), ("E", "rocket", 10, 64), ("E", "rocket", 20, 64), ("E", "rocket", 100, 32), ("F", "rocket", 100, 8),
          ("A", "quadrotor", 50, 64), ("B", "quadrotor", 50, 64), ("C", "quadrotor", 50, 64), ("D", "quadrotor", 50, 64), ("D", "quadrotor", 20, 200),
          ("D", "wide32", 30, 64), ("D", "wide64", 20, 32), ("M", "large", 10, 48), ("E", "quadrotor", 125, 64), ("D", "quadrotor", 100, 64)]
 

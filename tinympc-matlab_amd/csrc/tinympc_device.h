@@ -248,9 +248,9 @@ __host__ __device__ inline size_t fam_doubles(int W, int KT, int lin_cap = MAX_L
 //   rows packed (`lds_arrays` of them) -- | d[S * 4 nu]
 __host__ __device__ constexpr int e_d_doubles(int nu, int S) { return (S * 4 * nu + 1) & ~1; }
 __host__ __device__ constexpr int e_fam_row(int nxu) { return (4 * nxu + 1) & ~1; }
-__host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl, int ncone = 0) {
-    // (... | linear rows | the cones' slopes and their reciprocals [2][ncone] | ...)
-    return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 + ((2 * ncone + 1) & ~1) : 0) + 512 + 2 * wpg * 64 + 16 + wpg * 16 + 6 * 64;
+__host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool fam, int nl, int ncone = 0, int gpw = 1) {
+    // (... | linear rows | the cones' slopes and their reciprocals [2][ncone] | carry matrices | per group: carries, flags, partials, knot 0)
+    return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 + ((2 * ncone + 1) & ~1) : 0) + 512 + gpw * (2 * wpg * 64 + 16 + wpg * 16 + 6 * 64);
 }
 // ... or, with the families evaluated one KNOT per lane (KFamilies, tinympc_solve_e_common.h; `lds_arrays` = -1), ONE exchange buffer
 // per wavefront: entry (j, t) = nx+nu doubles at (j (S+1) + t) ES, ES odd (conflict-free for the lanes that walk t), padded so that
@@ -261,8 +261,8 @@ __host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S
 __host__ __device__ constexpr int e_wave_doubles(int nxu, int nu, int S, int lds_arrays) {
     return (lds_arrays < 0 ? kfam_doubles(nxu, S) : lds_arrays * S * e_fam_row(nxu)) + e_d_doubles(nu, S);
 }
-__host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays, int ncone = 0) {
-    return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl, ncone) + (size_t)wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));
+__host__ __device__ constexpr size_t e_lds_bytes(int nxu, int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int lds_arrays, int ncone = 0, int gpw = 1) {
+    return sizeof(double) * ((size_t)e_shared_doubles(N, ct, wpg, fam, nl, ncone, gpw) + (size_t)gpw * wpg * e_wave_doubles(nxu, nu, S, fam ? lds_arrays : 0));
 }
 
 #ifndef __HIPCC_RTC__  // host side only
@@ -277,7 +277,8 @@ struct FamilyStructure {
     bool beyond_generic() const { return ncone > MAX_CONES || nround > MAX_ROUNDS || nlx > MAX_LIN_ROWS || nlu > MAX_LIN_ROWS; }
 };
 // Layout E (tinympc_solve_e.hip, run-time specialised only): the horizon cut across the wavefronts of a workgroup
-bool solve_e_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *wpg, size_t *lds_bytes);
+bool solve_e_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *wpg, size_t *lds_bytes, int *gpw);
+bool solve_jit_enabled();  // TINYMPC_JIT is not 0
 bool solve_e_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
 hipError_t launch_solve_e(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
 void solve_e_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);

@@ -106,7 +106,7 @@ struct tinympc_solver {
     tinympc::FamilyStructure fs;
     std::string e_sig;
     bool e_ok = false;
-    int e_chunk_len = 0, e_wpg = 0;
+    int e_chunk_len = 0, e_wpg = 0, e_gpw = 1;
     size_t e_lds = 0;
     // Layout F (tinympc_solve_f.hip): the latency kernel as a run-time specialisation (shape, chunk plan and the families'
     // structure compiled in); decided per launch like layout E

@@ -44,7 +44,17 @@ void decide_layout_d_variants(tinympc_solver *s) {
         // (cones that share rows need the round-by-round projection, which layout D's families variant and the latency kernel
         // do not have: layout E or k_admm_solve_fam run those)
         const FamilyStructure fsd = family_structure(s);
-        s->d_fam = (s->W == 16 && fsd.nround <= 1 && !fsd.beyond_generic() && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+        // Round 4: at these horizons layout E has an UNCUT form (one wavefront per group, the families one knot per lane) that does in
+        // ~200 instructions per iteration what this variant pays in every slot -- it takes precedence where it builds (TINYMPC_LAYOUT=D
+        // keeps the variant for the tests and A/B runs).
+        bool e_uncut = false;
+        const char *env = getenv("TINYMPC_LAYOUT");
+        if (s->W == 16 && s->batch > 1 && s->N - 1 <= 31 && !(env && (env[0] == 'D' || env[0] == 'd'))) {
+            int wpg = 0;
+            e_uncut = solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), true, fsd, nullptr, &wpg, nullptr, nullptr) && wpg == 1 &&
+                      solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), true, fsd);
+        }
+        s->d_fam = (!e_uncut && s->W == 16 && fsd.nround <= 1 && !fsd.beyond_generic() && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
     }
 }
 
@@ -69,11 +79,12 @@ int decide_layout_e(tinympc_solver *s) {
     std::string sig = s->tables_const() ? "ct|" : "var|";
     for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
     sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
+    sig += solve_jit_enabled() ? "|jit" : "|nojit";  // (TINYMPC_JIT=0 switches the specialised kernels off from the next launch on)
     if (sig == s->e_sig) return TINYMPC_OK;
     s->e_sig = sig;
     s->fs = fs;
     s->e_ok = solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), fam, fs) &&
-              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds);
+              solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), fam, fs, &s->e_chunk_len, &s->e_wpg, &s->e_lds, &s->e_gpw);
     if (s->e_ok && !s->dctab_e) {
         int rc = dalloc(s, &s->dctab_e, chunk_table_doubles(s->nx, 1));
         if (rc) return rc;
@@ -105,6 +116,7 @@ int decide_layout_f(tinympc_solver *s) {
     std::string sig = s->tables_const() ? "ct|" : "var|";
     for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
     sig += "|" + std::to_string(fs.nlx) + "," + std::to_string(fs.nlu) + (fam ? "|fam" : "|box");
+    sig += solve_jit_enabled() ? "|jit" : "|nojit";
     if (sig == s->f_sig) return TINYMPC_OK;
     s->f_sig = sig;
     s->f_fs = fs;
@@ -168,7 +180,7 @@ LaunchPlan current_plan(const tinympc_solver *s) {
         case KernelId::E:
             pl.layout = 'E';
             pl.jit = true;
-            pl.workgroups = s->groups;
+            pl.workgroups = (s->groups + s->e_gpw - 1) / s->e_gpw;
             pl.lds_bytes = s->e_lds;
             break;
         case KernelId::F:

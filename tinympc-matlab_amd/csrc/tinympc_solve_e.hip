@@ -86,7 +86,9 @@ struct DStep;  // tinympc_solve_d_chain.h
 
 // Issue priority between the two wavefronts of a SIMD (experiments, TINY_E_PRIO): 0 none, 1 the wavefront in the odd slot leads for
 // the whole kernel, 2 wall-clock slices of 2^TINY_E_PRIO_SHIFT x 10 ns sampled at every sweep step, 3 feedback from the barriers:
-// whoever waited less than TINY_E_PRIO_TH cycles at the last barrier (i.e. came late) leads until the next one
+// whoever waited less than TINY_E_PRIO_TH cycles at the last barrier (i.e. came late) leads until the next one, 4 a RELAY between
+// the two barriers: the wavefront in the even slot leads (priority 2 against 1) through the first part of the interval, then drops
+// to 0 while its partner rises to 3 (TINY_E_RELAY_A / _B: where, 1 = early, 2 = late)
 #ifndef TINY_E_PRIO
 #define TINY_E_PRIO 0
 #endif
@@ -101,6 +103,12 @@ struct DStep;  // tinympc_solve_d_chain.h
 #endif
 #ifndef TINY_E_PRIO_TH
 #define TINY_E_PRIO_TH 300
+#endif
+#ifndef TINY_E_RELAY_A
+#define TINY_E_RELAY_A 1
+#endif
+#ifndef TINY_E_RELAY_B
+#define TINY_E_RELAY_B 2
 #endif
 
 namespace tinympc {
@@ -117,14 +125,22 @@ constexpr int E_GROUP = 8;  // ... and between two later ones
 // knot) element per lane in every slot of the sweep; the placement flags GC_LDS / GL_LDS / LX_LDS belong to the element form.
 // DREG: the feed-forward d of the wavefront's slots in registers too (2 S VGPRs) instead of its LDS region: the backward chain
 // leaves d_s on the input lanes, exactly where the forward chain's DPP columns read it.
-template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS, bool KFAM, bool DREG>
+// WPG == 1 (round 4): the horizon is NOT cut -- one wavefront sweeps all of it, no pass 1, no carries, no workgroup barrier inside the
+// iteration: layout D's data flow with this kernel's knot-per-lane families, for the families at SHORT horizons (the rocket landing of
+// the reference's own example, N = 10: layout D's families variant pays the element-per-lane evaluation in every slot). A workgroup
+// is then GPW independent groups of four instances, one wavefront each, sharing the LDS copies of the operators and tables.
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool GC_LDS, bool GL_LDS, bool LX_LDS, bool KFAM, bool DREG, int GPW = 1>
 __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double *smem) {
     constexpr int W = 16, IPW = 4, NXU = NX + NU, NS = N - 1, DS = IPW * NU;
     constexpr int KT = NXU <= 8 ? 8 : NXU <= 12 ? 12 : 16;  // row stride of p.ops (choose_geometry)
     constexpr int KS = NX <= 8 ? 8 : NX <= 12 ? 12 : 16;    // row stride of the carry matrices (chunk_ks)
     constexpr int TOFF = (N + 2) * W;
     constexpr int S_LAST = NS - (WPG - 1) * S;              // slots of the last wavefront
-    static_assert(WPG >= 2 && S >= 3 && S_LAST >= 3 && S_LAST <= S, "layout E: every chunk holds at least three slots");
+    static_assert(WPG >= 1 && S >= 3 && S_LAST >= 3 && S_LAST <= S, "layout E: every chunk holds at least three slots");
+    static_assert(GPW == 1 || WPG == 1, "several groups per workgroup: only where a group is one wavefront");
+    constexpr bool CUT = WPG > 1;                            // the horizon is cut across wavefronts: pass 1, carries, barriers
+    constexpr int NTHREADS = 64 * WPG * GPW;
+    constexpr int PG = 2 * WPG * 64 + 16 + WPG * 16 + 6 * 64;  // LDS doubles per group: carries | flags | residual partials | knot 0
     constexpr bool KF = FAM && KFAM;
     constexpr bool GCL = FAM && !KF && GC_LDS, GLL = FAM && !KF && GL_LDS, LXL = FAM && !KF && LX_LDS;
     constexpr int NLDS = KF ? -1 : (GCL ? 1 : 0) + (GLL ? 1 : 0) + (LXL ? 1 : 0);
@@ -133,10 +149,14 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     using Step = DStep<NX, NU>;
 
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wavefront in the workgroup
+    const int wv = CUT ? wib : 0;   // wavefront of its group (its chunk of the horizon)
+    const int gi = CUT ? 0 : wib;   // group of the workgroup
     const int j = lane >> 4, r = lane & 15;
-    const long grp = blockIdx.x;  // one workgroup = one group of four instances
-    const long inst = grp * IPW + j;
+    const long grp_raw = (long)blockIdx.x * GPW + gi;  // one group = four instances
+    const long grp = grp_raw < p.groups ? grp_raw : (long)p.groups - 1;  // (a workgroup's last groups may not exist: they load a real group's
+                                                                          // state and store nothing -- every store is gated by inst_ok)
+    const long inst = grp_raw * IPW + j;
     const bool is_x = r < NX;
     const bool is_u = (r >= NX) && (r < NXU);
     const bool inst_ok = inst < p.batch;
@@ -151,12 +171,12 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     double *sLin = sT + (CT ? 0 : 3 * (N + 2) * 16 + 16);         // [E_NL][3][16]  a_k | b_k | 1/||a_k||^2 (FAM)
     double *sMu = sLin + (FAM ? 3 * E_NL * 16 : 0);               // [2][E_NCONE] the cones' slopes | their reciprocals (FAM)
     double *sPow = sMu + (FAM ? ((2 * E_NCONE + 1) & ~1) : 0);    // Phi^S | Psi^S, [16 k][16 r] each
-    double *sE = sPow + 512;                                      // [WPG][64] forward carries
+    double *sE = sPow + 512 + (size_t)gi * PG;                    // per group: [WPG][64] forward carries
     double *sB = sE + WPG * 64;                                   // [WPG][64] backward carries
     int *sFlag = reinterpret_cast<int *>(sB + WPG * 64);          // [WPG] per-instance "below tolerance" bits (16 doubles)
     double *sRes = sB + WPG * 64 + 16;                            // [WPG][4 instances][4]
     double *sK0 = sRes + WPG * 16;                                // [6][64] knot 0 of the state rows (g, v, gc, gl) and x0: the bottom wavefront's
-    double *sWave = sK0 + 6 * 64 + (size_t)wv * e_wave_doubles(NXU, NU, S, NLDS);
+    double *sWave = sPow + 512 + (size_t)GPW * PG + (size_t)(gi * WPG + wv) * e_wave_doubles(NXU, NU, S, NLDS);
     double *sGC = sWave;                                          // [S][RS] each, where the plan puts them into LDS
     double *sGL = sGC + (GCL ? S * RS : 0);
     double *sLX = sGL + (GLL ? S * RS : 0);
@@ -172,14 +192,14 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     const int kxT = (j * (S + 1) + r) * ES;
     const int s_real = top ? S_LAST : S;  // slots this wavefront really owns
 
-    for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
+    for (int i = threadIdx.x; i < 512; i += NTHREADS) {
         const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
         sOps[i] = (k < KT) ? p.ops[(size_t)which * W * KT + (size_t)rr * KT + k] : 0.0;
-        sPow[i] = (k < NX && rr < NX) ? p.ctab[(size_t)which * W * KS + (size_t)rr * KS + k] : 0.0;
+        if constexpr (CUT) sPow[i] = (k < NX && rr < NX) ? p.ctab[(size_t)which * W * KS + (size_t)rr * KS + k] : 0.0;
     }
     if constexpr (!CT)
-        for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
-    if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, 64 * WPG);
+        for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += NTHREADS) sT[i] = p.tables[i];
+    if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, NTHREADS);
     if constexpr (FAM) KFamilies<NX, NU>::stage_cone_slopes(p.fam, KT, sMu, (int)threadIdx.x);
 
     // canonical HBM layout, shared with every other kernel
@@ -324,6 +344,20 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             else __builtin_amdgcn_s_setprio(0);
         }
     };
+    // TINY_E_PRIO == 4: start of an interval between two barriers / the hand-over inside it
+    const bool relay_first = (simd_slot & 1u) == 0u;
+    auto relay_start = [&]() {
+        if constexpr (TINY_E_PRIO == 4) {
+            if (relay_first) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        }
+    };
+    auto relay_handover = [&]() {
+        if constexpr (TINY_E_PRIO == 4) {
+            if (relay_first) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+    };
     auto barrier_fb = [&]() {  // the workgroup barrier, with the priority feedback of TINY_E_PRIO == 3
         if constexpr (TINY_E_PRIO == 3) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -428,7 +462,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             double m[16];
             load_ops(sMf, m);
             // ================= forward, pass 1: the chunk's end state from a zero incoming state =================
-            {
+            if constexpr (CUT) {
                 double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
                 double dcur = 0.0;
                 if constexpr (!DREG) {
@@ -450,11 +484,12 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 sE[wv * 64 + lane] = xt;
             }
             E_STAMP(1);
-            barrier_fb();
+            if constexpr (CUT) barrier_fb();
+            relay_start();
             E_STAMP(2);
             // the true state entering the chunk: X_w = Phi^S X_(w-1) + e_(w-1), X_1 = e_0
             double xin = 0.0;
-            if (!bottom) {
+            if (CUT && !bottom) {
                 // (requesting all carries at once, ahead of the recurrence, measured no faster and costs 14 VGPRs -- with them the
                 // rocket's all-in-registers plan spilled)
                 double ph[16];
@@ -584,6 +619,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 }
             }
             if (active) it_done = it1;  // admm.cpp:143
+            if constexpr (TINY_E_RELAY_A == 1) relay_handover();
             E_STAMP(4);
 
             // ---- (KF) the families of all slots of this wavefront at once, one knot per lane: rows in, projections, duals, the
@@ -618,6 +654,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // chain of a chunk of n slots: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
             // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
             // which the chunk below owns.
+            if constexpr (TINY_E_RELAY_A == 2) relay_handover();
             E_STAMP(5);
             load_ops(sMb, m);
             auto bwd_chain = [&](double cin, auto STORE) -> double {
@@ -694,7 +731,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 return a;
             };
             // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
-            {
+            if constexpr (CUT) {
 #if TINY_E_EXP != 3 && TINY_E_EXP != 5
                 const double e2 = bwd_chain(0.0, std::false_type{});
 #else
@@ -703,7 +740,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 sB[wv * 64 + lane] = e2;
             }
             E_STAMP(6);
-            barrier_fb();
+            if constexpr (CUT) barrier_fb();
+            else e_lds_wait();  // (one wavefront: its own flag write is all there is to wait for)
+            relay_start();
             E_STAMP(7);
             // ---- termination, decided jointly: an instance converged iff every wavefront saw all of its lanes below tolerance
             if (check) {
@@ -724,7 +763,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             }
             // the carry entering from above: c_w = e''_(w+1) + Psi^S c_(w+1), c of the last wavefront = 0
             double cin = 0.0;
-            if (!top) {
+            if (CUT && !top) {
                 double ps[16];
                 load_pow(sPow + 256 + r, ps);
                 cin = sB[(WPG - 1) * 64 + lane];
@@ -733,8 +772,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 load_ops(sMb, m);
             }
             // pass 2: the real sweep; only d is kept
+            if constexpr (TINY_E_RELAY_B == 1) relay_handover();
             E_STAMP(8);
             (void)bwd_chain(is_x ? cin : 0.0, std::true_type{});
+            if constexpr (TINY_E_RELAY_B == 2) relay_handover();
             E_STAMP(9);
         }
     }
@@ -759,9 +800,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
     // the four residual norms of the last check: rows, then wavefronts through LDS
     const double gpx = group_max<W>(is_x ? snap_pri : 0.0), gpu = group_max<W>(is_u ? snap_pri : 0.0);
     const double gdx = group_max<W>(is_x ? snap_dua : 0.0), gdu = group_max<W>(is_u ? snap_dua : 0.0);
-    e_barrier();  // (sRes shares nothing, but every wavefront has left the iteration loop's LDS traffic behind)
+    if constexpr (CUT) e_barrier();  // (sRes shares nothing, but every wavefront has left the iteration loop's LDS traffic behind)
     if (r < 4) sRes[(wv * 4 + j) * 4 + r] = (r == 0) ? gpx : (r == 1) ? gdx : (r == 2) ? gpu : gdu;
-    e_barrier();
+    if constexpr (CUT) e_barrier();
+    else e_lds_wait();
     if (bottom && inst_ok && r == 0) {
         double res[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -784,6 +826,9 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 #ifndef TINY_JIT_E_WPS
 #define TINY_JIT_E_WPS (TINY_JIT_E_WPG / 4)  // wavefronts per SIMD: a workgroup of 8 shares a CU two by two (256 registers each)
 #endif
+#ifndef TINY_JIT_E_GPW
+#define TINY_JIT_E_GPW 1  // groups of four instances per workgroup (more than one only where a group is ONE wavefront, TINY_JIT_E_WPG = 1)
+#endif
 // the entry point: `tinympc_jit_solve` as a run-time specialisation (tinympc_jit.hip looks it up by that name), the name the build
 // gives it as a compiled-in one (TINY_BUILTIN: __graft_entry__.HIP_BUILTINS)
 #ifdef TINY_BUILTIN
@@ -791,13 +836,13 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
 #else
 #define TINY_KERNEL_NAME tinympc_jit_solve
 #endif
-extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
+extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_E_WPG * TINY_JIT_E_GPW) __attribute__((amdgpu_waves_per_eu(TINY_JIT_E_WPS, TINY_JIT_E_WPS)))
 TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
     constexpr bool GCJ = TINY_JIT_E_GC_LDS != 0, GLJ = TINY_JIT_E_GL_LDS != 0, LXJ = TINY_JIT_E_LX_LDS != 0, KFJ = TINY_JIT_E_KFAM != 0, DRJ = TINY_JIT_E_DREG != 0;
     constexpr int nlds = !FAMJ ? 0 : KFJ ? -1 : (GCJ ? 1 : 0) + (GLJ ? 1 : 0) + (LXJ ? 1 : 0);
-    constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds, tinympc::E_NCONE);
+    constexpr size_t bytes = tinympc::e_lds_bytes(TINY_JIT_NX + TINY_JIT_NU, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, tinympc::E_NL, nlds, tinympc::E_NCONE, TINY_JIT_E_GPW);
     static_assert(bytes <= 160 * 1024, "layout E: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_e[bytes / sizeof(double)];
-    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ, DRJ>(p, smem_e);
+    tinympc::k_admm_solve_e_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_E_WPG, TINY_JIT_E_S, FAMJ, GCJ, GLJ, LXJ, KFJ, DRJ, TINY_JIT_E_GPW>(p, smem_e);
 }
