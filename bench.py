@@ -246,17 +246,24 @@ def usable_cpus():
     return cpus, quota, src
 
 
+PROFILE_TAG = "r04"
+
+
 def leg_counters(leg: str, iters_per_s: float) -> dict:
-    """What rocprofv3 measured for this leg's kernel (profiles/r03_<leg>_pmc.json, tools/profile_legs.sh + collect_leg_profiles.py):
+    """What rocprofv3 measured for this leg's kernel (profiles/<tag>_<leg>_pmc.json, tools/profile_legs.sh + collect_leg_profiles.py):
     VALU issue fraction of the chip, HBM bytes per instance-iteration -> measured GB/s at the LIVE rate of this run. Empty when
-    the profile is absent. The counters belong to the kernels of the round's last collection; the rates are this run's."""
-    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % leg)
+    the profile is absent; DROPPED (with a note) when it was collected on other kernel sources than the library running now --
+    counters of an older kernel next to a fresh rate would be a stale 'measured' figure."""
+    name = "%s_%s_pmc.json" % (PROFILE_TAG, leg)
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return {}
-    out = {"source": "profiles/r03_%s_pmc.json" % leg}
+    if d.get("library_hash") != library_hash():
+        return {"measured": {"source": "profiles/" + name, "dropped": "collected on other kernel sources (%s, now %s)" % (d.get("library_hash"), library_hash())}}
+    out = {"source": "profiles/" + name, "library_hash": d.get("library_hash")}
     dd, hb = d.get("derived") or {}, d.get("hbm") or {}
     for k in ("valu_per_wave_iteration", "valu_issue_fraction_of_chip", "shader_clock_ghz_grbm"):
         if k in dd:

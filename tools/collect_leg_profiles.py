@@ -20,7 +20,7 @@ FLOPS = {"headline": 60848, "long_horizon": None, "adaptive_rho_batch": 60848}  
 
 
 def solve_kernel(names):
-    ks = [n for n in names if "k_admm_solve" in n or "tinympc_jit_solve" in n]
+    ks = [n for n in names if "k_admm_solve" in n or "tinympc_jit_solve" in n or "k_builtin_" in n]
     return ks
 
 
@@ -38,7 +38,9 @@ def main():
             plain = json.loads([l for l in open(os.path.join(d, "plain.json")) if l.startswith("{")][-1])
         except (OSError, IndexError, ValueError):
             pass
-        out = {"leg": leg, "workload": plain}
+        sys.path.insert(0, ROOT)
+        from bench import library_hash  # (the kernel sources these counters belong to: bench.py drops them when its library differs)
+        out = {"leg": leg, "workload": plain, "library_hash": library_hash()}
         dbs = glob.glob(os.path.join(d, "trace", "**", "*_results.db"), recursive=True)
         kname = None
         if dbs:
@@ -48,7 +50,7 @@ def main():
                 o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
                 for name, calls, total, avg, pct in rows:
                     o.write('"%s",%d,%.0f,%.0f,%.4f\n' % (name, calls, total * 1e3, avg * 1e3, pct))
-            ks = [r for r in rows if "k_admm_solve" in r[0] or "tinympc_jit_solve" in r[0]]
+            ks = [r for r in rows if "k_admm_solve" in r[0] or "tinympc_jit_solve" in r[0] or "k_builtin_" in r[0]]
             if ks:
                 k = max(ks, key=lambda r: r[2])
                 kname = k[0]
@@ -63,7 +65,7 @@ def main():
             for db in glob.glob(os.path.join(d, sub, "**", "*_results.db"), recursive=True):
                 con = sqlite3.connect(db)
                 for name, cn, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
-                    if kname and name == kname or (not kname and ("k_admm_solve" in name or "tinympc_jit_solve" in name)):
+                    if kname and name == kname or (not kname and ("k_admm_solve" in name or "tinympc_jit_solve" in name or "k_builtin_" in name)):
                         counters.setdefault(cn, []).append(float(v))
         c = {k: {"launches": len(v), "mean": st.mean(v)} for k, v in counters.items()}
         out["counters_per_launch"] = c

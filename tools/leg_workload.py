@@ -3,7 +3,7 @@
 extra legs, a few launches each, nothing else in the process (no torch import: numpy + the C ABI only).
 
     python tools/leg_workload.py <leg> [launches]
-legs: headline, rocket_batch, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance,
+legs: headline, rocket_batch, rocket_batch_n10, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance,
       converging_batch, converging_batch_plain
 Prints one JSON line: leg, kernel layout, launches, iterations per launch, instances, median kernel ms (HIP events)."""
 import json
@@ -67,6 +67,8 @@ def build(leg):
         return rocket_handle(100, 4096, 100), 4096, 100
     if leg == "rocket_instance":
         return rocket_handle(100, 1, 200), 1, 200
+    if leg == "rocket_batch_n10":  # (the reference example's own horizon: layout E's uncut form)
+        return rocket_handle(10, 4096, 100), 4096, 100
     if leg == "wide_system":
         return synthetic(24, 8, 30, 4096, 100, 0, 0.03, 0.1), 4096, 100
     if leg == "long_horizon":
