@@ -905,10 +905,14 @@ def main() -> int:
                             slow.append({"tick": k, "us": 1e6 * dt, "library_launch_call_us": split[0], "library_wait_us": split[1],
                                          "polls": int(split[2]), "polling_budget_ran_out": bool(split[3])})
                     x = prob.A @ x + prob.B @ u0
+                # ... and the same 200 ticks driven from C (tinympc_bench_closed_loop: no Python call inside a tick) -- how the reference
+                # core beside it is timed too (oracle/ref_shim.cpp: ref_bench_closed_loop)
+                cl = tk.bench_closed_loop(prob.A, prob.B, prob.x0, 220, 20, session=(mode == "session"))
                 if mode == "session":
                     tk.session_end()
                 tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick_max": 1e6 * float(np.max(dts)),
-                              "iterations_per_tick": its / 200}
+                              "iterations_per_tick": its / 200,
+                              "c_loop": {k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")}}
                 if slow:
                     tick[mode]["ticks_above_1ms"] = slow
                 tk.reset()
@@ -981,6 +985,8 @@ def main() -> int:
                 "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),
                 "cartpole_batch_8192_iters_per_s": leg("cartpole/batch_8192/iters_per_s"), "cartpole_batch_8192_fp64_frac": leg("cartpole/batch_8192/fp64_frac"),
                 "closed_loop_tick_launch_us": leg("closed_loop_tick/launch/us_per_tick_median"), "closed_loop_tick_session_us": leg("closed_loop_tick/session/us_per_tick_median"),
+                "closed_loop_tick_launch_c_loop_us": leg("closed_loop_tick/launch/c_loop/us_per_tick_median"),
+                "closed_loop_tick_session_c_loop_us": leg("closed_loop_tick/session/c_loop/us_per_tick_median"),
                 "closed_loop_tick_cpu_reference_us": leg("cpu_baseline/closed_loop_us_per_tick_single_process"),
                 "rocket_closed_loop_launch_us": leg("rocket_closed_loop/launch/us_per_tick_median"), "rocket_closed_loop_session_us": leg("rocket_closed_loop/session/us_per_tick_median"),
                 "rocket_closed_loop_cpu_port_us": leg("cpu_baseline/rocket_closed_loop_us_per_tick_single_process")}

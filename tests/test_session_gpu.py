@@ -239,3 +239,30 @@ def test_rocket_landing_closed_loop_resident_at_the_full_horizon(pkg, monkeypatc
     assert a.get_stats()["iter"] == b.get_stats()["iter"]
     a.reset()
     b.reset()
+
+
+def test_closed_loop_driven_from_c_equals_the_python_loop(pkg):
+    """tinympc_bench_closed_loop (the measurement helper bench.py's c_loop numbers come from) runs the same ticks as a loop of
+    mpc_step / session_step calls: same final state bit for bit, same iteration total, launched and resident."""
+    P = pkg.problems
+    prob = P.quadrotor(50)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    for session in (False, True):
+        a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
+        if session:
+            a.session_begin()
+            b.session_begin()
+        out = a.bench_closed_loop(prob.A, prob.B, prob.x0, 30, 5, session=session)
+        x, its = prob.x0.copy(), 0
+        for k in range(30):
+            u0 = b.session_step(x) if session else b.mpc_step(x)[:, 0]
+            if k >= 5:
+                its += b.get_stats()["iter"]
+            x = prob.A @ x + prob.B @ u0
+        assert out["iterations_per_tick"] * 25 == its and out["us_per_tick"] > 0
+        np.testing.assert_allclose(out["x"], x, rtol=1e-12, atol=1e-15)  # (the plant step's summation order differs from numpy's)
+        if session:
+            a.session_end()
+            b.session_end()
+        a.reset()
+        b.reset()

@@ -74,6 +74,8 @@ SIGNATURES = {
     "tinympc_compute_sensitivity": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     "tinympc_setup_batch": (C.c_int, [C.POINTER(Handle), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                       C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tinympc_bench_closed_loop": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
+                                            c_double_p, C.POINTER(C.c_long), c_double_p]),
     "tinympc_set_x0_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
     "tinympc_set_x0_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_int, C.c_int]),
     "tinympc_reset_workspace": (C.c_int, [Handle]),

@@ -484,6 +484,47 @@ int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out)
 
 
 // (diagnostic: where the last zero-copy tick spent its time -- launch us, wait us, polls, 1 if the polling budget ran out)
+// Measurement helper (not a MEX verb): `ticks` closed-loop ticks of a single-instance handle driven from C -- x0 in, warm-started
+// solve, first controls out, plant step x+ = A x + B u0 (+ f) -- through tinympc_mpc_step_batch (session == 0) or through the open
+// session (session != 0; the caller opened it). Only the tick verb itself is inside the timed region, the first `skip` ticks are
+// untimed: what a caller written in C pays per tick, next to the reference core timed the same way (oracle/ref_shim.cpp:
+// ref_bench_closed_loop) -- bench.py's Python loop adds its ctypes calls on top.
+int tinympc_bench_closed_loop(tinympc_solver *s, const double *A, const double *B, const double *f, double *x, int ticks, int skip, int session,
+                              double *seconds, long *iterations, double *tick_us) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (!A || !B || !x || ticks < 1 || skip < 0 || s->batch != 1)
+        return fail(TINYMPC_ERR_INVALID_INPUT, "bench_closed_loop: single-instance handle, A, B, x and ticks >= 1 required");
+    const int nx = s->nx, nu = s->nu;
+    std::vector<double> u0(nu), xn(nx);
+    double acc = 0.0;
+    long its = 0;
+    for (int k = 0; k < ticks; ++k) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = session ? tinympc_session_step(s, x, u0.data()) : tinympc_mpc_step_batch(s, x, u0.data());
+        const auto t1 = std::chrono::steady_clock::now();
+        if (rc) return rc;
+        const double us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        if (tick_us) tick_us[k] = us;
+        if (k >= skip) {
+            acc += 1e-6 * us;
+            int it = 0;
+            if ((rc = tinympc_get_stats(s, &it, nullptr, nullptr, nullptr, 0))) return rc;  // (a host copy after a tick: outside the timed region)
+            its += it;
+        }
+        for (int i = 0; i < nx; ++i) {
+            double v = f ? f[i] : 0.0;
+            for (int q = 0; q < nx; ++q) v += A[i + (size_t)q * nx] * x[q];
+            for (int q = 0; q < nu; ++q) v += B[i + (size_t)q * nx] * u0[q];
+            xn[i] = v;
+        }
+        for (int i = 0; i < nx; ++i) x[i] = xn[i];
+    }
+    if (seconds) *seconds = acc;
+    if (iterations) *iterations = its;
+    return TINYMPC_OK;
+}
+
 int tinympc_debug_tick_timing(tinympc_solver *s, double *out4) {
     int rc = check_handle(s);
     if (rc) return rc;

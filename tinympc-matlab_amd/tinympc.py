@@ -339,6 +339,22 @@ class TinyMPC:
         _lib.check(self._L.tinympc_session_step(self._h, _p(a), _p(u0)))
         return u0
 
+    def bench_closed_loop(self, A, B, x0, ticks: int, skip: int = 0, session: bool = False, fdyn=None) -> dict:
+        """`ticks` closed-loop ticks driven from C (tinympc_bench_closed_loop): what a caller written in C pays per tick -- no
+        Python call inside a tick. With session=True the caller has opened the session. Returns the per-tick durations (us) of the
+        counted ticks, their mean / median, the iterations per tick and the final state."""
+        self._check_setup()
+        a, b = _f(A), _f(B)
+        x = _f(np.asarray(x0, dtype=np.float64).reshape(-1, 1).copy())
+        f = _f(np.asarray(fdyn, dtype=np.float64).reshape(-1, 1)) if fdyn is not None else None
+        sec, its = C.c_double(0.0), C.c_long(0)
+        per = np.zeros(ticks)
+        _lib.check(self._L.tinympc_bench_closed_loop(self._h, _p(a), _p(b), _p(f) if f is not None else None, _p(x), int(ticks), int(skip), int(bool(session)),
+                                                     C.byref(sec), C.byref(its), _p(per)))
+        n = max(ticks - skip, 1)
+        return dict(us_per_tick=1e6 * sec.value / n, us_per_tick_median=float(np.median(per[skip:])), us_per_tick_max=float(np.max(per[skip:])),
+                    iterations_per_tick=its.value / n, x=x.ravel().copy())
+
     def session_end(self):
         self._check_setup()
         _lib.check(self._L.tinympc_session_end(self._h))
