@@ -31,7 +31,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             print("   %4d " % w + " ".join("%11.0f" % v for v in d) + "  %10.0f" % (st[w][-1] - st[w][0]))
         s.reset()
         sys.exit(0)
-    print("%-44s layout %s  %7.3f ms  %6.1f M iters/s   %s" % (os.environ.get("TINYMPC_JIT_DEFS", "(product)"), s.launch_info()["layout"], t, B * it / t / 1e3, s.jit_info()[:60]), flush=True)
+    ck = float(np.abs(s.get_solution_batch(0, 64)["controls"]).sum())  # (a changed checksum = a build whose results differ)
+    print("%-44s layout %s  %7.3f ms  %6.1f M iters/s  sum|u| %.12g  %s" % (os.environ.get("TINYMPC_JIT_DEFS", "(product)"), s.launch_info()["layout"], t, B * it / t / 1e3, ck, s.jit_info()[:60]), flush=True)
     s.reset()
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "--stamps":
