@@ -113,6 +113,73 @@ def test_systems_beyond_128_rows(pkg, nx, nu, N, varying):
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("nx,nu,N,batch", [(96, 32, 12, 21), (70, 10, 8, 5), (160, 32, 8, 19), (300, 20, 5, 17)])
+def test_families_on_large_systems(pkg, nx, nu, N, batch):
+    """Cones and linear rows beyond 64 rows (bindings.cpp:408-478 take any nx, nu): layout M's families phase (wavefront w evaluates
+    knots w, w + NW, ... between the sweeps, tinympc_solve_m.hip). A cone inside one 16-row tile, one across a tile boundary, two
+    that share rows (projected one after another), one over three tiles, an input cone that starts in the tile the state rows end
+    in; three dense state rows, two input rows; fdyn. R = 8, 5, 12 (streamed operators) and 20 (two row tiles per wavefront).
+    Against the restatement: iteration counts, 1e-9 on the trajectories, cold start + two warm starts; then the families switched
+    off again (the box path of the same handle)."""
+    P = pkg.problems
+    rng = np.random.default_rng(nx * 10 + nu)
+    A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    if nx >= 256:
+        A = 0.6 * np.eye(nx) + (0.1 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    Bm = 0.3 * rng.standard_normal((nx, nu))
+    prob = P.Problem("largefam", A, Bm, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 1.5, rng.standard_normal(nx))
+    prob.x_min, prob.x_max = np.full(nx, -3.0), np.full(nx, 3.0)
+    prob.u_min, prob.u_max = np.full(nu, -1.0), np.full(nu, 1.0)
+    prob.fdyn = 0.01 * rng.standard_normal(nx)
+    prob.cones = dict(Acx=[0, 13, 15, 20], qcx=[3, 6, 3, 41], cx=[0.8, 0.6, 1.1, 0.9], Acu=[0, 5], qcu=[3, 4], cu=[0.7, 1.3])
+    prob.linear = dict(Alin_x=rng.standard_normal((3, nx)) / np.sqrt(nx), blin_x=rng.uniform(0.1, 0.4, 3),
+                       Alin_u=rng.standard_normal((2, nu)) / np.sqrt(nu), blin_u=rng.uniform(0.1, 0.3, 2))
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+    s = pkg.TinyMPC()
+    s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, **settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    s.set_cone_constraints(**prob.cones)
+    s.set_linear_constraints(**prob.linear)
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.1, 1.0, batch)[None, :]
+    checked = sorted({0, batch // 2, 15 if batch > 16 else 1, batch - 1})
+    orc = {b: O.OraclePort(prob).load_problem(prob, settings) for b in checked}
+    moved = 0.0
+    for rnd in range(3):
+        xs = x0s * (1.0 - 0.3 * rnd)
+        s.set_x0_batch(xs)
+        s.solve()
+        assert s.launch_info()["layout"] == "M"
+        sol, st = s.get_solution_batch(), s.get_stats_batch()
+        for b in checked:
+            orc[b].set_x0(xs[:, b])
+            orc[b].solve()
+            ob = orc[b].stats()
+            assert st["iter"][b] == ob["iter"] and st["status"][b] == ob["status"], (rnd, b, st["iter"][b], ob["iter"])
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL, (rnd, b)
+            assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+            np.testing.assert_allclose(st["residuals"][:, b], [ob["pri_x"], ob["dua_x"], ob["pri_u"], ob["dua_u"]], rtol=1e-6, atol=1e-10)
+        if rnd == 0:  # the families do something here: the box-only problem has another answer
+            box = pkg.TinyMPC()
+            box.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, **settings)
+            box.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            box.set_x0_batch(xs)
+            box.solve()
+            moved = float(np.abs(box.get_solution_batch()["controls"] - sol["controls"]).max())
+            box.reset()
+    assert moved > 1e-3, moved
+    # families off again: the same handle on the box path, from its warm state, against an oracle brought to the same state
+    s.update_settings(en_state_soc=0, en_input_soc=0, en_state_linear=0, en_input_linear=0)
+    for b in checked:
+        orc[b].update_settings(en_state_soc=0, en_input_soc=0, en_state_linear=0, en_input_linear=0)
+    s.solve()
+    sol, st = s.get_solution_batch(), s.get_stats_batch()
+    for b in checked:
+        orc[b].solve()
+        assert st["iter"][b] == orc[b].stats()["iter"], b
+        assert rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, b
+    s.reset()
+
+
 def test_large_system_single_instance_and_unsupported_features(pkg):
     prob = _system(pkg, 66, 6, 6, 1, False)
     settings = dict(max_iter=80, abs_pri_tol=1e-3, abs_dua_tol=1e-3)

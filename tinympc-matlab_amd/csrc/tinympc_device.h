@@ -363,6 +363,10 @@ int solve_m_geometry(int nx, int nu);
 size_t solve_m_tiled_ops_doubles(int nx, int nu);  // beyond 128 rows: the tile-major copy of the operators the kernel streams (0 otherwise)
 hipError_t launch_tile_operators_m(const double *ops, double *out, int nx, int nu, hipStream_t stream);  // W = KT of the operators / tables of a large system: 128, 256 (beyond 128 rows) or 512 (beyond 256)
 size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
+// the families' description for layout M (compact: tinympc_solve_m.hip, FAM): size for `nl` linear rows, and where its blocks start
+size_t solve_m_fam_doubles(int nx, int nu, int nl);
+size_t solve_m_fam_cone_offset();
+size_t solve_m_fam_lin_offset();
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).

@@ -184,7 +184,63 @@ FamilyStructure family_structure(const tinympc_solver *s, double *mu) {
 
 // Per-lane description of the cone / linear families for k_admm_solve_fam (layout: fam_doubles()).
 // Masks and user coefficients only -- no solver arithmetic happens here.
+// Layout M (nx+nu > 64): the compact description of tinympc_solve_m.hip -- counts, the active cones in list order as first row /
+// last row / slope, one coefficient vector per linear row k (state side row k and input side row k share it: disjoint rows).
+static int refresh_families_m(tinympc_solver *s) {
+    const int nx = s->nx, nu = s->nu, GW = solve_m_geometry(nx, nu);
+    std::vector<double> cmu(HARD_MAX_CONES, 0.0);
+    const FamilyStructure fs = family_structure(s, cmu.data());
+    const int nl = fs.nlx > fs.nlu ? fs.nlx : fs.nlu;
+    const size_t need = solve_m_fam_doubles(nx, nu, nl);
+    int rc;
+    if (!s->dfam || need > s->fam_alloc_doubles) {
+        if ((rc = dalloc(s, &s->dfam, need))) return rc;
+        s->fam_alloc_doubles = need;
+        s->fam_dirty = true;
+    }
+    if (!s->dGC) {  // (allocated once, in the tile layout: v_doubles())
+        if ((rc = dalloc(s, &s->dGC, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dGL, s->v_doubles()))) return rc;
+        if ((rc = dalloc(s, &s->dLX, s->v_doubles()))) return rc;
+        HIP_TRY(hipMemsetAsync(s->dGC, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dGL, 0, sizeof(double) * s->v_doubles(), s->stream));
+        HIP_TRY(hipMemsetAsync(s->dLX, 0, sizeof(double) * s->v_doubles(), s->stream));
+        s->fam_dirty = true;
+    }
+    if (!s->fam_dirty) return TINYMPC_OK;
+    std::vector<double> f(need, 0.0);
+    int ncx = 0, ncu = 0;
+    for (int c = 0; c < fs.ncone; ++c) {
+        double *cd = f.data() + solve_m_fam_cone_offset() + (size_t)3 * c;
+        cd[0] = (double)fs.cone[c][1];
+        cd[1] = (double)fs.cone[c][2];
+        cd[2] = cmu[c];
+        (fs.cone[c][1] < nx ? ncx : ncu) += 1;
+    }
+    f[0] = (double)ncx; f[1] = (double)ncu; f[2] = (double)fs.nlx; f[3] = (double)fs.nlu;
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int k = 0; k < nl; ++k) {
+        double *ak = f.data() + solve_m_fam_lin_offset() + (size_t)k * (GW + 4);
+        double nrm_x = 0.0, nrm_u = 0.0;
+        ak[GW] = inf; ak[GW + 1] = inf; ak[GW + 2] = 1.0; ak[GW + 3] = 1.0;
+        if (k < fs.nlx) {
+            for (int c = 0; c < nx; ++c) { const double a = s->Alin_x[k + (size_t)c * s->n_lin_x]; ak[c] = a; nrm_x += a * a; }
+            ak[GW] = s->blin_x[k];
+            ak[GW + 2] = 1.0 / nrm_x;
+        }
+        if (k < fs.nlu) {
+            for (int c = 0; c < nu; ++c) { const double a = s->Alin_u[k + (size_t)c * s->n_lin_u]; ak[nx + c] = a; nrm_u += a * a; }
+            ak[GW + 1] = s->blin_u[k];
+            ak[GW + 3] = 1.0 / nrm_u;
+        }
+    }
+    if ((rc = upload(s, s->dfam, f.data(), f.size()))) return rc;
+    s->fam_dirty = false;
+    return TINYMPC_OK;
+}
+
 int refresh_families(tinympc_solver *s) {
+    if (s->layout_m) return refresh_families_m(s);
     const int W = s->W, KT = s->KT, nx = s->nx, nu = s->nu, nxu = nx + nu;
     // the buffer's capacities: the generic kernels' (the default layout every kernel reads), or this configuration's own counts
     // where it has more -- such a configuration runs on layouts E / F only (launch() checks)

@@ -269,9 +269,9 @@ int launch(tinympc_solver *s, bool timed) {
     if ((rc = refresh_derived(s))) return rc;
     if (adaptive && fam)
         return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho together with cone / linear constraint families is not supported");
-    if (s->layout_m && (adaptive || fam))
-        return fail(TINYMPC_ERR_UNSUPPORTED, "systems with nx+nu > 64 support box constraints only (no cone / linear families, no adaptive_rho)");
-    if (fam && pl.kernel != KernelId::E && pl.kernel != KernelId::F && family_structure(s).beyond_generic())
+    if (s->layout_m && adaptive)
+        return fail(TINYMPC_ERR_UNSUPPORTED, "adaptive_rho is not supported for systems with nx+nu > 64");
+    if (fam && pl.kernel != KernelId::E && pl.kernel != KernelId::F && pl.kernel != KernelId::M && family_structure(s).beyond_generic())
         return fail(TINYMPC_ERR_UNSUPPORTED, "more than %d linear rows per side, %d cones or %d rounds of overlapping cones run on the run-time "
                     "specialised kernels only (nx+nu <= 16, TINYMPC_JIT not 0): this configuration has none (%s)", MAX_LIN_ROWS, MAX_CONES, MAX_ROUNDS,
                     s->W != 16 ? "nx+nu > 16" : "the specialiser refused it, see tinympc_get_jit_info");
@@ -295,6 +295,10 @@ int launch(tinympc_solver *s, bool timed) {
     p.families = fam ? 1 : 0;
     p.adaptive = adaptive ? 1 : 0;
     p.scratch = s->state_in_global ? s->dscratch_state : nullptr;
+    if (s->layout_m && fam) {  // layout M with families: the forward sweep leaves its rollout x | u here for the families' phase
+        if (!s->dscratch_state && (rc = dalloc(s, &s->dscratch_state, s->v_doubles()))) return rc;
+        p.scratch = s->dscratch_state;
+    }
 #ifdef TINY_CLOCK_STAMP  // diagnostic build (tools/clock_check.py): layout D stamps its iteration loop into this buffer
     if (!s->state_in_global) {
         if (!s->dclock && (rc = dalloc(s, &s->dclock, (size_t)8 * s->groups))) return rc;

@@ -27,6 +27,7 @@
 // parity: a converged solve must keep the PREVIOUS iterate (admm.cpp:181-197), which is then simply the buffer last read.
 // Arithmetic intensity ~ nxu / 20 flop per byte of state: HBM-bound below nxu ~ 128, at a few tenths of the FP64 peak.
 #include "tinympc_device.h"
+#include "tinympc_sweep.h"  // soc_project_element, halfspace_project_element
 
 #ifndef TINY_EXP_M
 #define TINY_EXP_M 0  // timing experiments (tools/build_m_variants.sh): 1 = no state traffic in the sweeps, 2 = no MFMAs
@@ -42,7 +43,6 @@ typedef double double4_m __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_exchange_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int M_INST = 16;       // instances per tile (the N dimension of the MFMA)
-constexpr int M_WAVES = 8;       // one 16-row output tile per wavefront (R <= 8)
 // wavefronts per workgroup: eight up to 128 rows; R of them for 9 <= R <= 16 row tiles (one tile each: no wavefront carries two
 // while its neighbours carry one), sixteen beyond
 __host__ __device__ constexpr int m_waves(int R) {
@@ -80,7 +80,146 @@ int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 // barrier. Sixteen wavefronts are four per SIMD: 128 registers, which the streamed form meets (123-128) because its tile loops
 // are never unrolled and never start from a constant the compiler can see (see the body). A step reads each operator tile once
 // per workgroup (<= 2 MB per operator, L2-resident) while the matrix pipe works 4R x 64 cycles per tile on it.
-template <int R, bool CT>
+//
+// FAM (round 4): the second-order-cone and linear-inequality families (bindings.cpp:408-478; the restated algorithm of
+// oracle/, tinympc_solve_fam.hip has the bookkeeping) at these sizes. A cone or a linear row couples rows of ONE knot that may sit
+// in any row tile, i.e. in any wavefront's result registers -- so the families are not part of the sweep step: the forward sweep
+// also leaves its rollout x | u in HBM (p.scratch, the tile's own layout), and between the sweeps wavefront w takes knots
+// w, w + NW, ... of the tile's sixteen instances: the four lanes (kq = 0..3) of an instance share the knot's rows exactly as the
+// state layout stores them -- every access of the phase is a full 512-byte line --, a cone's ||w||^2 and a row's a_k' s are
+// per-lane partial sums + two cross-lane adds. Duals gc | gl persist in the tile layout (p.GC, p.GL); the linear-cost term goes
+// to p.LX, which the backward sweep reads next to V and G. Cones are projected one after another in list order (overlapping
+// cones need no rounds here), linear rows likewise. The description is compact (m_fam_*: counts, cones as first / last / slope,
+// one coefficient vector per linear row) -- the mask matrices of the other layouts would be 6 MB at 512 rows.
+__host__ __device__ constexpr size_t m_fam_cone_offset() { return 8; }                                   // [c][first, last, mu]
+__host__ __device__ constexpr size_t m_fam_lin_offset() { return 8 + (size_t)3 * HARD_MAX_CONES; }      // [k][GW coefficients | b_x, b_u, 1/|a_x|^2, 1/|a_u|^2]
+__host__ __device__ constexpr size_t m_fam_lin_stride(int GW) { return (size_t)GW + 4; }
+size_t solve_m_fam_doubles(int nx, int nu, int nl) { return m_fam_lin_offset() + (size_t)nl * m_fam_lin_stride(solve_m_geometry(nx, nu)); }
+size_t solve_m_fam_cone_offset() { return m_fam_cone_offset(); }
+size_t solve_m_fam_lin_offset() { return m_fam_lin_offset(); }
+
+// The families of one iterate for the tile's instances (see FAM above). X: rollout x | u in, garbage out; GCa / GLa: duals in and
+// out; LXa: out. Called by every wavefront of the workgroup between two __syncthreads(); nothing in here crosses wavefronts, and
+// lanes only communicate through the two cross-lane adds of a reduction (program order covers a lane's own stores and loads).
+// Per knot:   A   s_c = x + gc -> X and GC (GC then holds vcnew while the cones work on it), s_l = x + gl -> GL and LX (LX: vlnew)
+//             B   cones in list order on GC: ||w||^2, t, then the rows (soc_project_element);   C   linear rows in order on LX
+//             Z   gc <- s_c - vcnew, gl <- s_l - vlnew, LX <- -rho (vcnew - gc) - rho (vlnew - gl)   (admm.cpp:65-69, :77-80 with the
+//                 families' terms as the oracle restates them)
+template <int R, int NW>
+__device__ __forceinline__ void m_families(const SolveParams &p, double *X, double *GCa, double *GLa, double *LXa, int wv, int lane, bool active) {
+    constexpr int GW = m_geometry(R), NS = 4 * R;
+    const size_t KD = m_knot_doubles(R);
+    const double *F = p.fam;
+    const int nx = p.nx, nxu = p.nx + p.nu, N = p.N;
+    const int ncx = __builtin_amdgcn_readfirstlane((int)F[0]), ncu = __builtin_amdgcn_readfirstlane((int)F[1]);
+    const int nlx = __builtin_amdgcn_readfirstlane((int)F[2]), nlu = __builtin_amdgcn_readfirstlane((int)F[3]);
+    const int nc = ncx + ncu, nl = nlx > nlu ? nlx : nlu;
+    const int kq = lane >> 4;
+    const double rho = p.rho;
+    auto sum4 = [](double v) -> double {  // over the four lanes of an instance; the same bits in all four (a + b = b + a)
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    };
+    for (int kn = wv; kn < N; kn += NW) {
+        double *x = X + (size_t)kn * KD, *gc = GCa + (size_t)kn * KD, *gl = GLa + (size_t)kn * KD, *lx = LXa + (size_t)kn * KD;
+        const bool has_u = kn < N - 1;  // (uniform) input rows: knots 0 .. N-2
+        auto row_at = [&](int sl) -> int { return 16 * (sl >> 2) + kq + 4 * (sl & 3); };
+        auto cone_on = [&](int r) -> bool { return r < nx ? ncx > 0 : (r < nxu && has_u && ncu > 0); };
+        auto lin_on = [&](int r) -> bool { return r < nx ? nlx > 0 : (r < nxu && has_u && nlu > 0); };
+        // ---- A
+#pragma unroll 4
+        for (int sl = 0; sl < NS; ++sl) {
+            const int r = row_at(sl);
+            const unsigned o = (unsigned)(sl * 64 + lane);
+            const double xv = x[o], gcv = gc[o], glv = gl[o];
+            if (active && cone_on(r)) {
+                const double sc = xv + gcv;
+                x[o] = sc;
+                gc[o] = sc;
+            }
+            if (active && lin_on(r)) {
+                const double s0 = xv + glv;
+                gl[o] = s0;
+                lx[o] = s0;
+            }
+        }
+        // ---- B: cones one after another (project_soc per cone in list order; state cones, then input cones)
+        for (int c = 0; c < nc; ++c) {
+            const double *cd = F + m_fam_cone_offset() + 3 * c;
+            const int first = __builtin_amdgcn_readfirstlane((int)cd[0]), last = __builtin_amdgcn_readfirstlane((int)cd[1]);
+            const double mu = cd[2];
+            if (first >= nx && !has_u) continue;
+            const double inv_mu = (mu != 0.0) ? 1.0 / mu : 0.0;
+            const int s_first = 4 * (first >> 4) + ((first & 15) >> 2), s_last = 4 * (last >> 4) + ((last & 15) >> 2);
+            double a2 = 0.0, t = 0.0;
+            for (int sl = s_first; sl <= s_last; ++sl) {
+                const int r = row_at(sl);
+                const double v = gc[(unsigned)(sl * 64 + lane)];
+                a2 += (r >= first && r < last) ? v * v : 0.0;
+                t += (r == last) ? v : 0.0;
+            }
+            a2 = sum4(a2);
+            t = sum4(t);
+            for (int sl = s_first; sl <= s_last; ++sl) {
+                const int r = row_at(sl);
+                const unsigned o = (unsigned)(sl * 64 + lane);
+                const double v = gc[o];
+                if (active && r >= first && r <= last) gc[o] = soc_project_element(v, a2, t, mu, inv_mu, r == last ? 2 : 1);
+            }
+        }
+        // ---- C: half-spaces one after another (row k of the state side and row k of the input side in one pass: disjoint rows)
+        for (int k = 0; k < nl; ++k) {
+            const double *ak = F + m_fam_lin_offset() + (size_t)k * m_fam_lin_stride(GW);
+            const double bx = ak[GW], bu = ak[GW + 1], inx = ak[GW + 2], inu = ak[GW + 3];
+            double dx = 0.0, du = 0.0;
+#pragma unroll 4
+            for (int sl = 0; sl < NS; ++sl) {
+                const int r = row_at(sl);
+                const double a = ak[r];
+                const double v = lx[(unsigned)(sl * 64 + lane)];
+                const double prod = lin_on(r) ? a * v : 0.0;
+                dx += (r < nx) ? prod : 0.0;
+                du += (r < nx) ? 0.0 : prod;
+            }
+            dx = sum4(dx);
+            du = sum4(du);
+            const bool viol = (dx > bx) || (du > bu);
+            if (__ballot(viol && active) == 0ull) continue;  // (uniform) nothing to move
+#pragma unroll 4
+            for (int sl = 0; sl < NS; ++sl) {
+                const int r = row_at(sl);
+                const unsigned o = (unsigned)(sl * 64 + lane);
+                const double a = ak[r];
+                const double v = lx[o];
+                const bool sx = r < nx;
+                if (active && lin_on(r)) lx[o] = halfspace_project_element(v, sx ? dx : du, a, sx ? bx : bu, sx ? inx : inu);
+            }
+        }
+        // ---- Z
+#pragma unroll 4
+        for (int sl = 0; sl < NS; ++sl) {
+            const int r = row_at(sl);
+            const unsigned o = (unsigned)(sl * 64 + lane);
+            const double sc = x[o], vc = gc[o], s0 = gl[o], vl = lx[o];
+            const bool real = r < nx || (r < nxu && has_u);
+            double l = 0.0;
+            if (cone_on(r)) {
+                const double gcn = sc - vc;  // gc + x - vcnew
+                l -= rho * (vc - gcn);
+                if (active) gc[o] = gcn;
+            }
+            if (lin_on(r)) {
+                const double gln = s0 - vl;
+                l -= rho * (vl - gln);
+                if (active) gl[o] = gln;
+            }
+            if (active && real) lx[o] = l;
+        }
+    }
+}
+
+template <int R, bool CT, bool FAM = false>
 __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolveParams p) {
     constexpr int KB = 4 * R;            // k-blocks of 4 operand rows (columns beyond nxu are zero in the operator)
     constexpr int NW = m_waves(R);                 // wavefronts per workgroup
@@ -107,6 +246,11 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
     double *const gVa = p.V + (size_t)tile * N * KD;
     double *const gVb = p.V2 + (size_t)tile * N * KD;
     double *const gD = p.D + (size_t)tile * N * KD;
+    // FAM: rollout x | u (transient), cone / linear duals (persistent), linear-cost term (forward -> backward), same layout
+    double *const gXU = FAM ? p.scratch + (size_t)tile * N * KD : nullptr;
+    double *const gGC = FAM ? p.GC + (size_t)tile * N * KD : nullptr;
+    double *const gGL = FAM ? p.GL + (size_t)tile * N * KD : nullptr;
+    double *const gLX = FAM ? p.LX + (size_t)tile * N * KD : nullptr;
 
     // this wave's result entries of its row tile tw (t = wv + 8 tw): e = 0..3 <-> reg = e, row = 16 t + kq + 4 e. Rows and their
     // kind are recomputed from the tile index where they are needed (cheap integer work) instead of living in masks.
@@ -242,6 +386,7 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
                     if (active) {
                         gG[slot(tw, e)] = s - snew;
                         Vw[slot(tw, e)] = snew;
+                        if constexpr (FAM) gXU[slot(tw, e)] = x0;
                     }
                     w = x0;
                 } else if (kd == 2) {
@@ -301,11 +446,18 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
                         const unsigned o = (unsigned)((i + k_x(tw, e)) * (int)KD) + slot(tw, e);
                         gG[o] = gn[e];
                         Vw[o] = sn[e];
+                        if constexpr (FAM) gXU[o] = out[e];
                     }
                 }
             }
             buf ^= 1;
             lds_exchange_barrier();
+        }
+        // ================= the cone / linear families of this iterate (instances that entered the iteration active) =================
+        if constexpr (FAM) {
+            __syncthreads();  // the rollout's rows come from every wavefront of the tile (waits for the sweep's stores)
+            m_families<R, NW>(p, gXU, gGC, gGL, gLX, wv, lane, active);
+            __syncthreads();  // the backward sweep reads LX by row tile
         }
         if (active) it_done = it + 1;  // admm.cpp:143
 
@@ -350,9 +502,11 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
                 if (kd == 1) {
                     const unsigned o = (unsigned)((N - 1) * (int)KD) + slot(tw, e);
                     w = p.tables[(size_t)3 * TOFF + row_of(tw, e)] - rho * (Vn[o] - gG[o]);  // p_{N-1}, admm.cpp:81-82
+                    if constexpr (FAM) w += gLX[o];
                 } else if (kd == 2) {
                     const unsigned o = (unsigned)((N - 2) * (int)KD) + slot(tw, e);
                     w = tab(2, N - 2, tw, e) - rho * (Vn[o] - gG[o]);  // r_{N-2}, admm.cpp:77-78
+                    if constexpr (FAM) w += gLX[o];
                 }
                 if (has_tile(tw)) sX[buf][4 * tile_of(tw) + e][lane] = w;
             }
@@ -364,7 +518,7 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
 #pragma nounroll
             for (int tw = tw0; tw < TPW; ++tw) {
                 if (!has_tile(tw)) continue;
-                double lv[4], lg[4], start[4];
+                double lv[4], lg[4], start[4], lx[FAM ? 4 : 1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     start[e] = start_of(1, tw, e);
@@ -373,8 +527,10 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
                         const unsigned o = (unsigned)(kn * (int)KD) + slot(tw, e);
                         lv[e] = Vn[o];
                         lg[e] = gG[o];
+                        if constexpr (FAM) lx[e] = gLX[o];
                     } else {
                         lv[e] = lg[e] = 0.0;
+                        if constexpr (FAM) lx[e] = 0.0;
                     }
                 }
                 double out[4];
@@ -383,7 +539,8 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
                 for (int e = 0; e < 4; ++e) {
                     const int kn = (is_u(tw, e) && i >= 1) ? i - 1 : i;
                     const bool real = is_x(tw, e) || (is_u(tw, e) && i >= 1);
-                    const double lin = (real && TINY_EXP_M != 1) ? tab(2, kn, tw, e) - rho * (lv[e] - lg[e]) : 0.0;  // admm.cpp:77-80
+                    double lin = (real && TINY_EXP_M != 1) ? tab(2, kn, tw, e) - rho * (lv[e] - lg[e]) : 0.0;  // admm.cpp:77-80
+                    if constexpr (FAM) lin = real ? lin + lx[e] : 0.0;
                     sX[buf ^ 1][4 * tile_of(tw) + e][lane] = is_x(tw, e) ? lin + out[e] : lin;                             // p_i = q_i + ...
                 }
                 if (active && TINY_EXP_M != 1) {
@@ -479,7 +636,8 @@ hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream) {
     const int tiles = (p.batch + M_INST - 1) / M_INST;
 #define TINY_M_LAUNCH(R_)                                                                                                \
     case R_:                                                                                                              \
-        if (p.const_tables) hipLaunchKernelGGL((k_admm_solve_m<R_, true>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p); \
+        if (p.families) hipLaunchKernelGGL((k_admm_solve_m<R_, false, true>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p); \
+        else if (p.const_tables) hipLaunchKernelGGL((k_admm_solve_m<R_, true>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p); \
         else hipLaunchKernelGGL((k_admm_solve_m<R_, false>), dim3(tiles), dim3(64 * m_waves(R_)), 0, stream, p);              \
         break;
     switch (R) {
