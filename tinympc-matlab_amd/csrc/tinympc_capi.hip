@@ -766,7 +766,7 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acx, const int *q
                 used |= lanes;
             }
         };
-        if (s->nx + s->nu <= 64) {  // (larger systems have no families kernel at all: refused at launch)
+        if (s->nx + s->nu <= 64) {  // (larger systems: layout M walks the cone list in order, it has no rounds)
             walk(Acx, qcx, ncx, 0);
             walk(Acu, qcu, ncu, s->nx);
         }

@@ -132,7 +132,7 @@ __device__ __forceinline__ void m_families(const SolveParams &p, double *X, doub
         for (int sl = 0; sl < NS; ++sl) {
             const int r = row_at(sl);
             const unsigned o = (unsigned)(sl * 64 + lane);
-            const double xv = x[o], gcv = gc[o], glv = gl[o];
+            const double xv = x[o], gcv = nc > 0 ? gc[o] : 0.0, glv = nl > 0 ? gl[o] : 0.0;  // (uniform: a family nobody uses costs no traffic)
             if (active && cone_on(r)) {
                 const double sc = xv + gcv;
                 x[o] = sc;
@@ -201,7 +201,15 @@ __device__ __forceinline__ void m_families(const SolveParams &p, double *X, doub
         for (int sl = 0; sl < NS; ++sl) {
             const int r = row_at(sl);
             const unsigned o = (unsigned)(sl * 64 + lane);
-            const double sc = x[o], vc = gc[o], s0 = gl[o], vl = lx[o];
+            double sc = 0.0, vc = 0.0, s0 = 0.0, vl = 0.0;
+            if (nc > 0) {
+                sc = x[o];
+                vc = gc[o];
+            }
+            if (nl > 0) {
+                s0 = gl[o];
+                vl = lx[o];
+            }
             const bool real = r < nx || (r < nxu && has_u);
             double l = 0.0;
             if (cone_on(r)) {
