@@ -237,7 +237,11 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
         # k_admm_solve_fam<64, 64, false, false>: 14 registers in the variant that reads its tables from L2 (44 bytes per lane)
         ("tinympc_solve_fam.hip", "_ZN7tinympc16k_admm_solve_famILi64ELi64ELb0ELb0EEEvNS_11SolveParamsE"): 64,
         # k_admm_solve_m<13..15, false>: the per-knot-table variants at sixteen wavefronts per workgroup (128 registers): 14 registers
-        **{("tinympc_solve_m.hip", "_ZN7tinympc14k_admm_solve_mILi%dELb0EEEvNS_11SolveParamsE" % r): 64 for r in (13, 14, 15)},
+        **{("tinympc_solve_m.hip", "_ZN7tinympc14k_admm_solve_mILi%dELb0ELb0EEEvNS_11SolveParamsE" % r): 64 for r in (13, 14, 15)},
+        # k_admm_solve_m<R, false, true>: the families variants (HBM-bound: 2.4-3.4x the box path's bytes) keep a few values of the
+        # iteration's outer scope in scratch -- 2-6 registers up to R = 12, 20-32 at sixteen wavefronts per workgroup; none of the
+        # blocks that hold matrix instructions touches scratch (checked below)
+        **{("tinympc_solve_m.hip", "_ZN7tinympc14k_admm_solve_mILi%dELb0ELb1EEEvNS_11SolveParamsE" % r): 96 for r in range(5, 33)},
     }
     seen = refill = 0
     for source in ge.HIP_SOURCES + [e[0] for e in ge.HIP_BUILTINS]:
@@ -261,6 +265,10 @@ def test_compiled_in_kernels_do_not_live_in_scratch():
                 continue
             if m.group(1).endswith("_session"):
                 continue  # (rare paths may spill: test_compiled_in_specialisations_are_linted_and_do_not_spill checks its sweeps)
+            if source == "tinympc_solve_m.hip" and size > 0:
+                body = re.search(r"^%s:(.*?)^\.Lfunc_end" % re.escape(m.group(1)), text, re.S | re.M).group(1)
+                for b in re.split(r"^\.LBB\d+_\d+:", body, flags=re.M):
+                    assert not ("v_mfma" in b and "scratch_" in b), f"{m.group(1)}: a GEMM block uses scratch"
             assert size <= allowed.get((source, m.group(1)), 0), f"{source}: {m.group(1)} uses {size} bytes of scratch per lane"
     assert seen > 50 and refill >= 3
 
