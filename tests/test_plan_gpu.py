@@ -23,8 +23,14 @@ def _wide(P, nx, nu, N, seed=0):
 
 # (name, problem factory, batch, variant, env, expected layout, expected origin prefix(es), expected workgroups or None)
 CASES = [
-    ("quadrotor50 single", lambda P: P.quadrotor(50), 1, "box", {}, "C", ("compiled-in",), 1),
-    ("quadrotor50 x512", lambda P: P.quadrotor(50), 512, "box", {}, "C", ("compiled-in",), 512),
+    # the box path of small batches: layout F (round 4) -- BASELINE configs 2 and 3 compiled in, any other shape specialised because the
+    # test calls prepare() (test_box_path_of_small_batches_* below: without it such a shape stays on layout C)
+    ("quadrotor50 single", lambda P: P.quadrotor(50), 1, "box", {}, "F", ("compiled-in",), 1),
+    ("quadrotor50 x512", lambda P: P.quadrotor(50), 512, "box", {}, "F", ("compiled-in",), 512),
+    ("quadrotor50 single per-knot references", lambda P: P.quadrotor(50), 1, "varying", {}, "F", ("compiled-in",), 1),
+    ("cartpole20 single", lambda P: P.cartpole(20), 1, "box", {}, "F", ("compiled-in",), 1),
+    ("quadrotor50 single no specialiser", lambda P: P.quadrotor(50), 1, "box", {"TINYMPC_JIT": "0"}, "C", ("compiled-in",), 1),
+    ("quadrotor23 single", lambda P: P.quadrotor(23), 1, "box", {}, "F", ("compiled ", "disk-cache"), 1),
     ("quadrotor50 x2048", lambda P: P.quadrotor(50), 2048, "box", {}, "D", ("compiled-in",), 128),
     ("quadrotor40 x2048", lambda P: P.quadrotor(40), 2048, "box", {}, "D", ("compiled ", "disk-cache"), 128),
     ("quadrotor40 x2048 per-knot references", lambda P: P.quadrotor(40), 2048, "varying", {}, "D", ("compiled", "disk-cache"), None),
@@ -103,4 +109,46 @@ def test_plan_table(pkg, monkeypatch, case):
     st = s.get_stats_batch(b, 1)
     assert st["iter"][0] == orc.stats()["iter"], name
     assert rel_err(sol["controls"][:, :, 0], orc.solution()[1]) < 1e-9, name
+    s.reset()
+
+
+def test_box_path_of_small_batches_takes_layout_f_only_where_it_costs_nothing_or_was_asked_for(pkg, monkeypatch):
+    """decide_layout_f: the compiled-in configurations run on layout F from the first solve; another shape stays on the latency kernel
+    (no seconds of run-time compilation behind a setup call) until the caller asks for the specialised kernels with prepare(); results
+    agree either way, and the persistent state carries over from one kernel to the other."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    settings = dict(max_iter=40, abs_pri_tol=1e-4, abs_dua_tol=1e-4)
+
+    def fresh(prob):
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, **settings)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        s.set_x0(prob.x0)
+        return s
+
+    for prob in (P.quadrotor(50), P.cartpole(20)):
+        s = fresh(prob)
+        s.solve()
+        assert s.launch_info()["layout"] == "F" and s.jit_info().startswith("compiled-in"), (prob.name, s.launch_info(), s.jit_info())
+        s.reset()
+    prob = P.quadrotor(31)  # (no compiled-in kernel)
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    s = fresh(prob)
+    for rnd in range(4):
+        if rnd == 2:
+            s.prepare()
+        x0 = prob.x0 * (1.0 - 0.2 * rnd)
+        s.set_x0(x0)
+        s.solve()
+        assert s.launch_info()["layout"] == ("C" if rnd < 2 else "F"), (rnd, s.launch_info(), s.jit_info())
+        orc.set_x0(x0)
+        orc.solve()
+        assert s.get_stats()["iter"] == orc.stats()["iter"], rnd
+        assert rel_err(s.get_solution()["controls"], orc.solution()[1]) < 1e-9, rnd
+    s.reset()
+    monkeypatch.setenv("TINYMPC_BUILTIN", "0")  # the compiled-in code switched off: nothing is free any more
+    s = fresh(P.quadrotor(50))
+    s.solve()
+    assert s.launch_info()["layout"] == "C"
     s.reset()

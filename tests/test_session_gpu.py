@@ -37,6 +37,8 @@ def test_session_ticks_equal_launched_ticks(pkg, name):
     a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
     orc = O.OraclePort(prob).load_problem(prob, settings)
     a.session_begin()
+    # (BASELINE config 3 is compiled in on layout F, resident kernel included; the cartpole N=10 has no specialisation: layout C)
+    assert a.launch_info()["layout"] == b.launch_info()["layout"] == ("F" if name == "quadrotor" else "C")
     xa, xb = prob.x0.copy(), prob.x0.copy()
     for k in range(25):
         ua = a.session_step(xa)

@@ -287,6 +287,7 @@ void solve_jit_describe(int W, int nx, int nu, int N, bool const_tables, bool fa
 bool solve_f_plan(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, int *chunk_len, int *chunks, int *wpg, size_t *lds_bytes);
 bool solve_f_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
 hipError_t launch_solve_f(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
+bool solve_f_builtin(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, bool session);  // compiled in: costs nothing to ask for
 bool solve_f_session_supported(int nx, int nu, int N, bool families, const FamilyStructure &fs);  // the resident closed-loop variant (compiles)
 hipError_t launch_solve_f_session(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
 void solve_f_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);

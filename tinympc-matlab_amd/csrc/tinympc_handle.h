@@ -113,6 +113,7 @@ struct tinympc_solver {
     std::string f_sig;
     bool f_ok = false;
     tinympc::FamilyStructure f_fs;
+    bool specialise_asked = false;  // tinympc_prepare() was called: run-time specialisation is welcome wherever it is faster (decide_layout_f)
     int f_chunk_len = 0, f_chunks = 0, f_wpg = 0;
     size_t f_lds = 0;
     double *dctab_f = nullptr;   // Phi^(S..4S) | Psi^(S..4S) for layout F's chunk length

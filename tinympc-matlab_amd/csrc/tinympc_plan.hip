@@ -99,13 +99,20 @@ int decide_layout_f(tinympc_solver *s) {
     const bool fam = s->families_active();
     const bool possible = s->W == 16 && !s->layout_m && !s->st.adaptive_rho && (!s->session_active || s->session_on_f) && s->N >= 6;
     // Default: the families at small batches -- rocket landing N=100, one instance: 4.5 us per iteration against 6.55 on the
-    // round-1 latency kernel. The box path stays on layout C: with four wavefronts (plan_f) layout F is 4 % ahead there too
-    // (quadrotor N=50: 2.75 against 2.86 us), but layout C stages per-tick references from pinned memory inside the kernel, runs the
-    // resident session (bit-identical ticks) and needs no run-time specialisation for a new shape.
+    // round-1 latency kernel
     // (a configuration beyond what the generic kernels hold -- more than MAX_LIN_ROWS rows, MAX_CONES cones, MAX_ROUNDS rounds -- has
     // no other kernel at these batch sizes)
     bool want = possible && fam && !s->use_layout_d() && !s->use_layout_e() && s->batch < kLayoutEBatchMin &&
                 (s->fam_c || family_structure(s).beyond_generic());
+    // ... and (round 4) the box path wherever the latency kernel would run: layout F is ahead on every shape measured
+    // (tools/single_cf_probe.py, microseconds per iteration, one instance: quadrotor N=10 / 20 / 50 / 100 1.81 / 2.24 / 2.73 / 4.07
+    // against 2.45 / 2.63 / 2.90 / 4.33, cartpole N=20 1.60 against 2.13) and has had the resident session since this round. It is
+    // a specialisation, though: a first setup of a new shape must not cost seconds behind the caller's back, so it is taken where it
+    // costs nothing -- the configurations compiled into the library (BASELINE configs 2 and 3) -- or where the caller asked for the
+    // specialised kernels with tinympc_prepare() (the real-time workflow of INTEGRATION.md); otherwise layout C, which needs none.
+    const bool box_f = possible && !fam && s->layout_c && !s->use_layout_d() && !s->use_layout_e() && solve_jit_enabled() &&
+                       (s->specialise_asked || solve_f_builtin(s->nx, s->nu, s->N, s->tables_const(), false, FamilyStructure(), false));
+    want = want || box_f;
     if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
     if (!want) {
         s->f_ok = false;
@@ -413,6 +420,7 @@ int tinympc_prepare(tinympc_solver *s) {
     int rc = check_handle(s);
     if (rc) return rc;
     if ((rc = bind_device(s))) return rc;
+    s->specialise_asked = true;  // (the caller pays for specialised kernels now: layout F for the box path of small batches)
     if ((rc = resolve_plan(s))) return rc;
     (void)refill_applies(s, current_plan(s));  // (a run-time specialised shape builds its slot-refill variant here, not in the first solve)
     return TINYMPC_OK;

@@ -147,7 +147,16 @@ int tinympc_session_begin(tinympc_solver *s) {
     const bool c_ok = s->host_path() && (s->layout_c || (fam && s->fam_c)) && !(fam && s->chunk_len > 4) &&
                       !(fam && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()));
     s->session_on_f = false;
-    if (!c_ok) {
+    // (round 4) where the handle's launches already run on layout F -- the box path compiled in or asked for with tinympc_prepare() --
+    // its resident variant is the faster one too, if it is there for the asking (compiled in / prepare() again)
+    bool f_first = false;
+    if (c_ok && s->host_path() && !fam) {
+        if ((rc = resolve_plan(s))) return rc;
+        f_first = current_plan(s).kernel == KernelId::F && (s->specialise_asked || solve_f_builtin(s->nx, s->nu, s->N, false, false, FamilyStructure(), true)) &&
+                  solve_f_session_supported(s->nx, s->nu, s->N, false, s->f_fs);
+    }
+    if (f_first) s->session_on_f = true;
+    else if (!c_ok) {
         if (!s->host_path()) return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles only (batch 1, nx+nu <= 16)");
         if ((rc = resolve_plan(s))) return rc;
         if (current_plan(s).kernel != KernelId::F || !solve_f_session_supported(s->nx, s->nu, s->N, fam, s->f_fs))

@@ -1,0 +1,27 @@
+"""Single-instance box path: the latency kernel (layout C) against the structure-specialised one (layout F), microseconds per ADMM
+iteration over 200 forced iterations (kernel time, HIP events).   python tools/single_cf_probe.py   (on the GPU box)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package(); P = pkg.problems
+    for name, prob in (("quadrotor N=10", P.quadrotor(10)), ("quadrotor N=20", P.quadrotor(20)), ("quadrotor N=50", P.quadrotor(50)),
+                       ("quadrotor N=100", P.quadrotor(100)), ("cartpole N=20", P.cartpole(20))):
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, max_iter=200, abs_pri_tol=0.0, abs_dua_tol=0.0)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if prob.x_ref is not None: s.set_x_ref(prob.x_ref); s.set_u_ref(prob.u_ref)
+        s.set_x0(prob.x0); s.prepare()
+        ms = []
+        for _ in range(8):
+            s.reset_workspace(); ms.append(s.solve_timed())
+        t = float(np.median(ms[2:]))
+        print(f"{name:16s} layout {s.launch_info()['layout']} {5 * t:7.3f} us/iter   {s.jit_info()[:80]}", flush=True)
+        s.reset()
+    sys.exit(0)
+for lay, extra in (("C", {}), ("F", {}), ("F", {"TINYMPC_F_CHUNKS": "32"})):
+    env = dict(os.environ, TINYMPC_LAYOUT=lay, **extra)
+    print("---- TINYMPC_LAYOUT=%s %s" % (lay, extra), flush=True)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env)
