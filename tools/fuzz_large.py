@@ -1,7 +1,9 @@
 """Randomised LARGE systems (65 <= nx+nu <= 512: layout M, every row-tile count R = 5..32 can occur, both the register-resident and the
 streamed form; the multi-launch Riccati precompute) against the oracle: caches, iteration counts, statuses, trajectories, over a cold
 and a warm start, constant and per-knot bounds / references, ragged last tile.
-  python tools/fuzz_large.py [count] [seed] > gpurun_out/fuzz_large.txt"""
+  python tools/fuzz_large.py [count] [seed] [families] > gpurun_out/fuzz_large.txt
+With a third argument every case also gets random cones (anywhere in the state / input vector: inside a row tile, across tiles,
+overlapping) and linear rows on either side (round 4: layout M's families phase)."""
 import os
 import sys
 import time
@@ -37,6 +39,24 @@ for case in range(count):
         prob.x_min, prob.x_max = np.full(nx, -2.0), np.full(nx, 2.0)
         prob.u_min, prob.u_max = np.full(nu, -0.3), np.full(nu, 0.3)
     prob.fdyn = 0.01 * rng.standard_normal(nx) if rng.integers(0, 2) else None
+    fam_note = ""
+    if len(sys.argv) > 3:
+        def cones(dim, n):
+            starts, dims, mus = [], [], []
+            for _ in range(n):
+                q = int(rng.integers(2, min(dim, 40) + 1))
+                starts.append(int(rng.integers(0, dim - q + 1))); dims.append(q); mus.append(float(rng.uniform(0.3, 1.5)))
+            return starts, dims, mus
+        ncx, ncu = int(rng.integers(0, 5)), int(rng.integers(0, 3))
+        ax, qx, cx = cones(nx, ncx)
+        au, qu, cu = cones(nu, ncu)
+        nlx, nlu = int(rng.integers(0, 5)), int(rng.integers(0, 3))
+        if ncx + ncu + nlx + nlu == 0:
+            ncx, (ax, qx, cx) = 1, ([0], [3], [0.8])
+        prob.cones = dict(Acx=ax, qcx=qx, cx=cx, Acu=au, qcu=qu, cu=cu)
+        prob.linear = dict(Alin_x=rng.standard_normal((nlx, nx)) / np.sqrt(nx), blin_x=rng.uniform(0.05, 0.5, nlx),
+                           Alin_u=rng.standard_normal((nlu, nu)) / np.sqrt(nu), blin_u=rng.uniform(0.05, 0.3, nlu))
+        fam_note = f" cones {ncx}+{ncu} rows {nlx}+{nlu}"
     settings = dict(max_iter=int(rng.integers(15, 60)), abs_pri_tol=1e-3, abs_dua_tol=1e-3, check_termination=int(rng.choice([1, 1, 3])))
     x0s = rng.standard_normal((nx, batch)) * np.linspace(0.05, 1.0, batch)[None, :]
     t0 = time.time()
@@ -46,6 +66,9 @@ for case in range(count):
     if prob.x_ref is not None:
         s.set_x_ref(prob.x_ref)
         s.set_u_ref(prob.u_ref)
+    if prob.cones:
+        s.set_cone_constraints(**prob.cones)
+        s.set_linear_constraints(**prob.linear)
     sample = sorted(set(b for b in (0, batch // 2, batch - 1)))
     orcs = {b: O.OraclePort(prob).load_problem(prob, settings) for b in sample}
     c = s.get_cache()
@@ -67,7 +90,7 @@ for case in range(count):
     worst = max(worst, e, ce)
     bad = (not ok) or e > 1e-6 or ce > 1e-6 or layout != "M"
     fails += bad
-    print(f"case {case:3d}: nx={nx:3d} nu={nu:2d} (R={(nxu + 15) // 16:2d}) N={N:2d} batch={batch:2d} per-knot tables={int(varying)} fdyn={int(prob.fdyn is not None)} "
+    print(f"case {case:3d}: nx={nx:3d} nu={nu:2d} (R={(nxu + 15) // 16:2d}) N={N:2d} batch={batch:2d} per-knot tables={int(varying)} fdyn={int(prob.fdyn is not None)}{fam_note} "
           f"check every {settings['check_termination']} -> layout {layout} | caches {ce:.1e} trajectories {e:.1e} iterations {'equal' if ok else 'DIFFER'} | "
           f"{time.time() - t0:5.1f} s{'   <-- FAIL' if bad else ''}", flush=True)
     s.reset()
