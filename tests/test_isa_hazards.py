@@ -48,7 +48,7 @@ def test_every_solve_source_is_linted_by_the_build():
     assert run_time_only == {"tinympc_solve_e.hip", "tinympc_solve_f.hip"}
     assert [e[0] for e in ge.HIP_BUILTINS][:3] == ["k_builtin_e_rocket100", "k_builtin_f_rocket100", "k_builtin_f_rocket100_session"]
     assert {e[0] for e in ge.HIP_BUILTINS[3:]} == {"k_builtin_f_%s%s" % (n, v) for n in ("cartpole20", "quadrotor50") for v in ("", "_var", "_session")}
-    assert ge.HIP_BUILTIN_GUARDED <= {e[0] for e in ge.HIP_BUILTINS}
+    assert ge.builtin_guarded() <= {e[0] for e in ge.HIP_BUILTINS}
     assert on_disk - no_dpp_chain - run_time_only == set(SOURCES), "new solve kernel source: add it to SOURCES here and to HIP_LINTED in __graft_entry__.py"
     for f in no_dpp_chain:
         assert "_dpp" not in open(os.path.join(CSRC, f)).read()
@@ -121,7 +121,7 @@ def test_family_specialisations_of_layout_d_have_no_dpp_hazard(nx, nu, N, vreg, 
 
 def test_compiled_in_specialisations_are_linted_and_do_not_spill():
     """BASELINE config 4's kernels (layout E for batches, layout F for one instance) and layout F for configs 2 and 3 are compiled in with
-    the BARE chain blocks: the build's ISA lint is what stands between them and the DPP hazard (HIP_BUILTIN_GUARDED: the ones it refused
+    the BARE chain blocks: the build's ISA lint is what stands between them and the DPP hazard (builtin_guarded(): the ones it refused
     bare), and their descriptors must show no scratch."""
     import __graft_entry__ as ge
     for name, source, defs in ge.HIP_BUILTINS:
@@ -146,7 +146,7 @@ def test_compiled_in_specialisations_are_linted_and_do_not_spill():
         # blocks proper start without one (the run-time builds put one in front of every chain)
         chains = len(re.findall(r"v_fmac_f64_dpp [^\n]* row_newbcast:0 ", text))
         with_nop = len(re.findall(r"s_nop 1\n\t\.p2align 3\n\tv_fmac_f64_dpp", text))
-        if name in ge.HIP_BUILTIN_GUARDED:  # (the lint found a hazard in its bare form: it keeps the guard in front of every chain)
+        if name in ge.builtin_guarded():  # (the lint found a hazard in its bare form: it keeps the guard in front of every chain)
             assert with_nop >= chains // 2, (name, chains, with_nop)  # (the backward chains start behind their own v_mov)
         else:
             assert chains > with_nop + 10, (name, chains, with_nop)

@@ -7,8 +7,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     pkg = g.load_package(); P = pkg.problems
-    for name, prob in (("quadrotor N=10", P.quadrotor(10)), ("quadrotor N=20", P.quadrotor(20)), ("quadrotor N=50", P.quadrotor(50)),
-                       ("quadrotor N=100", P.quadrotor(100)), ("cartpole N=20", P.cartpole(20))):
+    probs = (("quadrotor N=10", P.quadrotor(10)), ("quadrotor N=20", P.quadrotor(20)), ("quadrotor N=50", P.quadrotor(50)),
+             ("quadrotor N=100", P.quadrotor(100)), ("cartpole N=20", P.cartpole(20)))
+    if os.environ.get("TINYMPC_F_S"):
+        probs = tuple(("quadrotor N=%d" % n, P.quadrotor(n)) for n in (10, 15, 20, 30, 40, 50, 65, 80, 100, 130)) + (("cartpole N=20", P.cartpole(20)), ("cartpole N=40", P.cartpole(40)))
+    for name, prob in probs:
         s = pkg.TinyMPC()
         s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, max_iter=200, abs_pri_tol=0.0, abs_dua_tol=0.0)
         s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -21,7 +24,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         print(f"{name:16s} layout {s.launch_info()['layout']} {5 * t:7.3f} us/iter   {s.jit_info()[:80]}", flush=True)
         s.reset()
     sys.exit(0)
-for lay, extra in (("C", {}), ("F", {}), ("F", {"TINYMPC_F_CHUNKS": "32"})):
+CONFIGS = (("C", {}), ("F", {}), ("F", {"TINYMPC_F_CHUNKS": "32"}))
+if len(sys.argv) > 1 and sys.argv[1] == "--chunks":  # python tools/single_cf_probe.py --chunks 12,20,24
+    CONFIGS = tuple(("F", {"TINYMPC_F_CHUNKS": c, "TINYMPC_BUILTIN": "0"}) for c in sys.argv[2].split(","))
+if len(sys.argv) > 1 and sys.argv[1] == "--slots":  # python tools/single_cf_probe.py --slots 2,3,4,5: chunk length S directly
+    CONFIGS = tuple(("F", {"TINYMPC_F_S": c, "TINYMPC_BUILTIN": "0"}) for c in sys.argv[2].split(","))
+for lay, extra in CONFIGS:
     env = dict(os.environ, TINYMPC_LAYOUT=lay, **extra)
     print("---- TINYMPC_LAYOUT=%s %s" % (lay, extra), flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env)
