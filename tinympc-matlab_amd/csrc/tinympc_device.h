@@ -191,12 +191,21 @@ struct AdaptTableParams {
     double *out;
 };
 
+// The knot-per-lane form of the families (KFamilies, tinympc_solve_e_common.h; layouts E and F): ONE exchange buffer per wavefront --
+// entry (j, t) = nx+nu doubles at (j (S+1) + t) ES, ES odd (conflict-free for the lanes that walk t), padded so that
+// the lanes beyond the last entry read inside the buffer
+__host__ __device__ constexpr int kfam_es(int nxu) { return nxu | 1; }  // (a stride of 17 -- no EXEC mask on the sweep's stores -- measured no faster: 2.604 against 2.614 ms, 30 KB more LDS)
+__host__ __device__ constexpr int kfam_passes(int S) { return (S + 1 + 15) / 16; }
+__host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S + 1) + 16 * kfam_passes(S)) * kfam_es(nxu) + nxu + 1) & ~1; }
+
 // ---- layout F (tinympc_solve_f.hip): one instance per workgroup, up to 4 * wpg chunks of S slots on the DPP rows of `wpg`
 // wavefronts. LDS per workgroup, in doubles: operators | tables (!ct) | linear rows (fam) | carry matrices [2][4][16][16] |
 // wavefront totals [2][wpg][16] | flags [16] | residual partials [4 wpg][4] | per wavefront d[S * 4 nu]
-__host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg, int S, bool fam, int nl) {
-    return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + 2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg + 64 +
-                             (size_t)wpg * ((S * 4 * nu + 1) & ~1));  // (+ 64: the session's mailbox copy)
+// (kf_nxu > 0: the families one knot per lane -- the cones' slopes [2][ncone] and one exchange buffer per wavefront on top)
+__host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int kf_nxu = 0, int ncone = 0) {
+    return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + (kf_nxu > 0 ? ((2 * ncone + 1) & ~1) : 0) +
+                             2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg + 64 + (size_t)wpg * ((S * 4 * nu + 1) & ~1) +  // (+ 64: the session's mailbox copy)
+                             (kf_nxu > 0 ? (size_t)wpg * kfam_doubles(kf_nxu, S) : 0));
 }
 
 // Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
@@ -252,12 +261,6 @@ __host__ __device__ constexpr int e_shared_doubles(int N, bool ct, int wpg, bool
     // (... | linear rows | the cones' slopes and their reciprocals [2][ncone] | carry matrices | per group: carries, flags, partials, knot 0)
     return 512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 + ((2 * ncone + 1) & ~1) : 0) + 512 + gpw * (2 * wpg * 64 + 16 + wpg * 16 + 6 * 64);
 }
-// ... or, with the families evaluated one KNOT per lane (KFamilies, tinympc_solve_e_common.h; `lds_arrays` = -1), ONE exchange buffer
-// per wavefront: entry (j, t) = nx+nu doubles at (j (S+1) + t) ES, ES odd (conflict-free for the lanes that walk t), padded so that
-// the lanes beyond the last entry read inside the buffer
-__host__ __device__ constexpr int kfam_es(int nxu) { return nxu | 1; }  // (a stride of 17 -- no EXEC mask on the sweep's stores -- measured no faster: 2.604 against 2.614 ms, 30 KB more LDS)
-__host__ __device__ constexpr int kfam_passes(int S) { return (S + 1 + 15) / 16; }
-__host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S + 1) + 16 * kfam_passes(S)) * kfam_es(nxu) + nxu + 1) & ~1; }
 __host__ __device__ constexpr int e_wave_doubles(int nxu, int nu, int S, int lds_arrays) {
     return (lds_arrays < 0 ? kfam_doubles(nxu, S) : lds_arrays * S * e_fam_row(nxu)) + e_d_doubles(nu, S);
 }

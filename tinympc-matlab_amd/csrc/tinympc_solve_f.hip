@@ -44,6 +44,9 @@
 #define TINY_JIT_E_NLX 1
 #define TINY_JIT_E_NLU 0
 #endif
+#ifndef TINY_JIT_F_KFAM
+#define TINY_JIT_F_KFAM 0  // 1: the families one KNOT per lane (KFamilies, tinympc_solve_e_common.h) instead of one element per lane
+#endif
 #ifndef TINY_JIT_F_SESSION
 #define TINY_JIT_F_SESSION 0
 #endif
@@ -59,7 +62,12 @@ struct DStep;  // tinympc_solve_d_chain.h
 
 namespace tinympc {
 
-template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool SESSION>
+// KFAM (round 4): layout E's knot-per-lane families here. The four DPP rows of a wavefront are four CHUNKS of the one instance; lane
+// (row j, entry t) takes knot t of chunk 4 wv + j: after the forward sweep has left the wavefront's slots in an LDS exchange buffer it
+// picks up all rows of its knot, evaluates every cone and linear row once per iteration, keeps the knot's duals gc | gl in its
+// registers for the whole solve, and hands the linear-cost term back through the buffer -- the S evaluations of ~70 dependent FP64
+// instructions per iteration that sat in every wavefront's sweep become one.
+template <int NX, int NU, int N, bool CT, int WPG, int S, bool FAM, bool SESSION, bool KFAM = false>
 __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double *smem) {
     static_assert(!SESSION || !CT, "layout F: the session kernel keeps its references in the LDS copy of the per-knot tables");
     constexpr int W = 16, NXU = NX + NU, NS = N - 1, DS = 4 * NU;
@@ -70,6 +78,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     constexpr int S_LAST = NS - (NCH - 1) * S;               // slots of the last chunk in use, 1 .. S
     static_assert(S >= 2 && NCH >= 2 && NCH <= 4 * WPG && NCH > 4 * (WPG - 1), "layout F: chunk plan");
     using Step = DStep<NX, NU>;
+    constexpr bool KF = FAM && KFAM;
+    constexpr int ES = kfam_es(NXU);
+    static_assert(!KF || S + 1 <= 16, "layout F, knot-per-lane families: one pass of 16 entries per chunk");
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -88,12 +99,18 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     double *sOps = smem;                                    // [2][16 k][16 r]
     double *sT = sOps + 512;                                // tables (!CT)
     double *sLin = sT + (CT ? 0 : 3 * (N + 2) * 16 + 16);   // [E_NL][3][16] (FAM)
-    double *sPow = sLin + (FAM ? 3 * E_NL * 16 : 0);        // [2 Phi|Psi][4 levels: powers S, 2S, 3S, 4S][16 k][16 r]
+    double *sMu = sLin + (FAM ? 3 * E_NL * 16 : 0);         // (KF) [2][E_NCONE] the cones' slopes | their reciprocals
+    double *sPow = sMu + (KF ? ((2 * E_NCONE + 1) & ~1) : 0);  // [2 Phi|Psi][4 levels: powers S, 2S, 3S, 4S][16 k][16 r]
     double *sY = sPow + 2 * 4 * 256;                        // [2][WPG][16] the wavefronts' totals of a scan, double-buffered
     int *sFlag = reinterpret_cast<int *>(sY + 2 * WPG * 16);  // [2][WPG] "every lane below tolerance" per wavefront (16 doubles)
     double *sRes = sY + 2 * WPG * 16 + 16;                  // [4 WPG][4] residual maxima per chunk
     double *sMail = sRes + 4 * WPG * 4;                     // [64] the session's mailbox as last polled (+ the poller's verdict)
     double *sD = sMail + 64 + (size_t)wv * ((S * DS + 1) & ~1);  // per wavefront: d[S][4 rows x nu]
+    double *sKX = sMail + 64 + (size_t)WPG * ((S * DS + 1) & ~1) + (size_t)wv * kfam_doubles(NXU, S);  // (KF) per wavefront: the exchange buffer
+    // (KF) this lane's two roles in the exchange buffer: as row r of chunk-row j (slot q = entry q+1: kxRow + (q+1) ES) and as entry
+    // t = r of chunk-row j (kxT .. + nx+nu)
+    const int kxRow = j * (S + 1) * ES + (r < NXU ? r : NXU - 1);
+    const int kxT = (j * (S + 1) + r) * ES;
 
     for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
         const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
@@ -106,6 +123,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     if constexpr (!CT)
         for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
     if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, 64 * WPG);
+    if constexpr (KF) {
+        KFamilies<NX, NU>::stage_cone_slopes(p.fam, KT, sMu, (int)threadIdx.x);
+        for (int i = lane; i < kfam_doubles(NXU, S); i += 64) sKX[i] = 0.0;
+    }
 
     // canonical HBM layout shared with the other kernels (instance = lane group inst % 4 of wave group inst / 4)
     const long wg = inst >> 2;
@@ -117,7 +138,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     const int dIdx = j * NU + (is_u ? r - NX : 0);
 
     // ---- this lane's elements, in registers for the whole solve: slot i <-> step s0 + i
-    double G[S], V[S], Vp[S], GC[FAM ? S : 1], GL[FAM ? S : 1], LX[FAM ? S : 1];
+    double G[S], V[S], Vp[S], GC[(FAM && !KF) ? S : 1], GL[(FAM && !KF) ? S : 1], LX[(FAM && !KF) ? S : 1];
     e_static_for<0, S>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const bool on = (i < nsl) && row_ok;
@@ -125,7 +146,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         G[i] = on ? gG[kn * 64] : 0.0;
         V[i] = on ? gV[kn * 64] : 0.0;
         Vp[i] = V[i];
-        if constexpr (FAM) {
+        if constexpr (FAM && !KF) {
             GC[i] = on ? (p.GC + vbase)[kn * 64] : 0.0;
             GL[i] = on ? (p.GL + vbase)[kn * 64] : 0.0;
             LX[i] = 0.0;
@@ -135,13 +156,32 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     // knot 0 of the state rows: chunk 0, state lanes
     const bool k0 = bottomc && is_x;
     double G0 = k0 ? gG[0] : 0.0, V0 = k0 ? gV[0] : 0.0, V0p = V0;
-    double GC0 = (FAM && k0) ? (p.GC + vbase)[0] : 0.0, GL0 = (FAM && k0) ? (p.GL + vbase)[0] : 0.0;
+    double GC0 = (FAM && !KF && k0) ? (p.GC + vbase)[0] : 0.0, GL0 = (FAM && !KF && k0) ? (p.GL + vbase)[0] : 0.0;
     double x0v = k0 ? p.x0[inst * NX + r] : 0.0;
     if (p.x0_mirror && k0) p.x0_mirror[inst * NX + r] = x0v;  // x0 came from pinned host memory: keep the device copy current
+    // (KF) the duals of this lane's knot -- entry t = r of chunk-row j: state rows of knot s0 + t, input rows of knot s0 + t - 1; entry
+    // 0 exists in chunk 0 only (knot 0 of the state rows) -- from the canonical HBM layout every kernel shares
+    KFamilies<NX, NU> kf;
+    const bool kent = KF && ((r >= 1 && r <= nsl) || (r == 0 && bottomc));  // this lane holds an entry
+    const unsigned long long kmask = __ballot(KF && r >= 1 && r <= nsl);     // ... that is a slot: it hands a linear-cost term back
+    if constexpr (KF) {
+        const double *const bGC = p.GC + (vbase - r), *const bGL = p.GL + (vbase - r);
+        e_static_for<0, NXU>([&](auto R) {
+            constexpr int rr = decltype(R)::value;
+            const int kn = rr < NX ? s0 + r : s0 + r - 1;
+            const bool ok = kent && (rr < NX || r >= 1);
+            kf.gc[rr] = ok ? bGC[(size_t)kn * 64 + rr] : 0.0;
+            kf.gl[rr] = ok ? bGL[(size_t)kn * 64 + rr] : 0.0;
+        });
+    }
     __syncthreads();  // (the only barrier that also waits for global loads)
+    if constexpr (KF) {
+        kf.init(p.fam, KT, sLin, sMu, p.rho);
+        if (bottomc && row_ok) sKX[kxRow] = is_x ? x0v : 0.0;  // entry 0 of chunk 0: x_0
+    }
 
     EFamilies<NX, NU> fam_eval;
-    if constexpr (FAM) fam_eval.init(p.fam, KT, sLin, r, p.rho);
+    if constexpr (FAM && !KF) fam_eval.init(p.fam, KT, sLin, r, p.rho);
 
     const double cf = p.ops[(size_t)2 * W * KT + r];
     const double cb = p.ops[(size_t)2 * W * KT + W + r];
@@ -151,7 +191,6 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     const double lo_c = p.tables[W + r], hi_c = p.tables[(size_t)TOFF + W + r], lr_c = p.tables[(size_t)2 * TOFF + W + r];
     const double *const sTl = sT + (size_t)(s0 + koff) * W + r;  // (!CT) row of local slot i: sTl[(i + 1) * W]  (idle rows: never read)
     const double *const sMf = sOps + r, *const sMb = sOps + 256 + r;
-    const unsigned aD = e_lds_addr(sD + dIdx);
     const int ct = p.check_termination;
 
     auto load_ops = [&](const double *src, double (&m)[16]) {
@@ -164,7 +203,8 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         double base;
         if constexpr (CT) base = lr_c;
         else base = (decltype(I)::value < nsl) ? sTl[2 * TOFF + (I.value + 1) * W] : 0.0;
-        if constexpr (FAM) base += LX[I.value];
+        if constexpr (KF) base += (decltype(I)::value < nsl) ? sKX[(I.value + 1) * ES + kxRow] : 0.0;
+        else if constexpr (FAM) base += LX[I.value];
         return base;
     };
 
@@ -236,7 +276,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 const size_t k = (size_t)(s0 + i), kn = k + koff;
                 gG[kn * 64] = G[i];
                 gV[kn * 64] = conv ? Vp[i] : V[i];
-                if constexpr (FAM) {
+                if constexpr (FAM && !KF) {
                     (p.GC + vbase)[kn * 64] = GC[i];
                     (p.GL + vbase)[kn * 64] = GL[i];
                 }
@@ -246,9 +286,22 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         if (k0) {
             gG[0] = G0;
             gV[0] = conv ? V0p : V0;
-            if constexpr (FAM) {
+            if constexpr (FAM && !KF) {
                 (p.GC + vbase)[0] = GC0;
                 (p.GL + vbase)[0] = GL0;
+            }
+        }
+        if constexpr (KF) {  // the families' duals leave from the knot-per-lane layout
+            if (kent) {
+                double *const wGC = p.GC + (vbase - r), *const wGL = p.GL + (vbase - r);
+                e_static_for<0, NXU>([&](auto R) {
+                    constexpr int rr = decltype(R)::value;
+                    if (rr < NX || r >= 1) {
+                        const size_t kn = (size_t)(rr < NX ? s0 + r : s0 + r - 1);
+                        wGC[kn * 64 + rr] = kf.gc[rr];
+                        wGL[kn * 64 + rr] = kf.gl[rr];
+                    }
+                });
             }
         }
     };
@@ -289,6 +342,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         if (k0) {
             x0v = payload(1 + r);
             if (p.x0_mirror) p.x0_mirror[inst * NX + r] = x0v;
+        }
+        if constexpr (KF) {
+            if (bottomc && row_ok) sKX[kxRow] = is_x ? x0v : 0.0;  // entry 0 of chunk 0: this tick's x_0
         }
         double *const tab = const_cast<double *>(p.tables);  // (mirror: the table rows the other kernels read)
         if (flags & 2) {
@@ -389,7 +445,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 dua = fabs(V0 - snew);
                 V0 = snew;
             }
-            if constexpr (FAM) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
+            if constexpr (FAM && !KF) {  // (its lx only reaches p_0, which nothing reads; the duals persist)
                 double gcn, gln;
                 (void)fam_eval.eval(x0v, GC0, GL0, gcn, gln);
                 if (k0) {
@@ -410,7 +466,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 }
                 Vp[q] = V[q];
                 xcur = Step::fwd_reg(xcur, dq, m, cf, loq, hiq, G[q], V[q], pri, dua);
-                if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                if constexpr (KF) {  // this slot's element goes up to its knot's lane
+                    if (row_ok) sKX[(q + 1) * ES + kxRow] = xcur;
+                } else if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                     double gcn, gln;
                     LX[q] = fam_eval.eval(xcur, GC[q], GL[q], gcn, gln);
                     GC[q] = gcn;
@@ -419,6 +477,17 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             }
         });
         it_done = it0 + 1;  // admm.cpp:143
+        // ---- (KF) the families of all slots of this wavefront at once, one knot per lane: rows in, projections, duals, the linear-cost
+        // term out through the same entry (read again by both backward passes; entry 0 keeps x_0). Same wavefront on both sides of the
+        // buffer: LDS executes a wavefront's accesses in order, the fences keep the compiler from moving them.
+        if constexpr (KF) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            double val[NXU], lxo[NXU];
+            e_static_for<0, NXU>([&](auto R) { val[R.value] = sKX[kxT + R.value]; });
+            kf.eval(val, lxo);
+            e_static_for<0, NXU>([&](auto R) { e_lds_write_masked<R.value * 8>(e_lds_addr(sKX + kxT), lxo[R.value], kmask); });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
 
         // ---- R1 (admm.cpp:93-101): one ballot per wavefront; the flags cross with the backward scan's barrier
         if (check) {
@@ -445,7 +514,8 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 double lrT = lr1;
                 if (terminal) {  // the last chunk: p_{N-1} (admm.cpp:81-82)
                     double pT = pnref;
-                    if constexpr (FAM) pT += LX[tt];
+                    if constexpr (KF) pT += sKX[(tt + 1) * ES + kxRow];
+                    else if constexpr (FAM) pT += LX[tt];
                     lrT = is_x ? pT : lr1;
                 }
                 px = nrho * (V[tt] - G[tt]) + lrT;
@@ -597,9 +667,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
 extern "C" __global__ void __launch_bounds__(64 * TINY_JIT_F_WPG) __attribute__((amdgpu_waves_per_eu(1, (TINY_JIT_F_WPG + 3) / 4 > 2 ? (TINY_JIT_F_WPG + 3) / 4 : 2)))
 TINY_KERNEL_NAME(const tinympc::SolveParams p) {
     constexpr bool CTJ = TINY_JIT_CT != 0, FAMJ = TINY_JIT_FAM != 0;
-    constexpr bool SESJ = TINY_JIT_F_SESSION != 0;
-    constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL);
+    constexpr bool SESJ = TINY_JIT_F_SESSION != 0, KFJ = FAMJ && TINY_JIT_F_KFAM != 0;
+    constexpr size_t bytes = tinympc::f_lds_bytes(TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, tinympc::E_NL,
+                                                  KFJ ? TINY_JIT_NX + TINY_JIT_NU : 0, tinympc::E_NCONE);
     static_assert(bytes <= 160 * 1024, "layout F: the workgroup's LDS plan exceeds a CU");
     __shared__ __attribute__((aligned(16))) double smem_f[bytes / sizeof(double)];
-    tinympc::k_admm_solve_f_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, SESJ>(p, smem_f);
+    tinympc::k_admm_solve_f_body<TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, TINY_JIT_F_WPG, TINY_JIT_F_S, FAMJ, SESJ, KFJ>(p, smem_f);
 }
