@@ -268,9 +268,9 @@ int launch(tinympc_solver *s, bool timed) {
     if ((rc = resolve_plan(s))) return rc;
     const LaunchPlan pl = current_plan(s);
     const bool fam = pl.families, adaptive = pl.adaptive;
-    // k_build_adapt reads the device copy of the references before the solve kernel starts; layout F has no in-kernel staging of
-    // references left in pinned host memory (layout C does): bring the device copies and the tables up to date the ordinary way
-    if (s->refs_on_host && (adaptive || pl.kernel == KernelId::F)) {
+    // k_build_adapt reads the device copy of the references before the solve kernel starts: bring the device copies and the tables up
+    // to date the ordinary way (every other kernel of a single-instance handle stages references left in pinned host memory itself)
+    if (s->refs_on_host && adaptive) {
         if ((rc = flush_host_refs(s))) return rc;
     }
     if ((rc = refresh_derived(s))) return rc;

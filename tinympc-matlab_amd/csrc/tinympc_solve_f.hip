@@ -112,6 +112,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     const int kxRow = j * (S + 1) * ES + (r < NXU ? r : NXU - 1);
     const int kxT = (j * (S + 1) + r) * ES;
 
+    // references left in pinned host memory by set_x_ref / set_u_ref (single-instance handles; the closed loop with per-tick references,
+    // rocket_landing_constraints.m:86-121): this workgroup rebuilds the table rows they determine before anything reads them -- the tick
+    // stays ONE launch, as on layout C. (The resident kernel has its own path: flags 2 / 4 / 8 of a command.)
+    if constexpr (!SESSION) refresh_reference_tables(p, W, KT);
     for (int i = threadIdx.x; i < 512; i += 64 * WPG) {
         const int which = i >> 8, k = (i >> 4) & 15, rr = i & 15;
         sOps[i] = (k < KT) ? p.ops[(size_t)which * W * KT + (size_t)rr * KT + k] : 0.0;
