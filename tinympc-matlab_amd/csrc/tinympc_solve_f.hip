@@ -47,6 +47,19 @@
 #ifndef TINY_JIT_F_KFAM
 #define TINY_JIT_F_KFAM 0  // 1: the families one KNOT per lane (KFamilies, tinympc_solve_e_common.h) instead of one element per lane
 #endif
+// Timing experiment (tools/f_breakdown.py, through TINYMPC_JIT_DEFS=-DTINY_F_STAMP=1; the states of the solution are overwritten):
+// the shader clock at the phase boundaries of iteration 10, per wavefront
+#ifndef TINY_F_STAMP
+#define TINY_F_STAMP 0
+#endif
+#if TINY_F_STAMP
+#define F_STAMP(k) do { if (it0 == 10) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define F_STAMP(k) do { } while (0)
+#endif
+#ifndef TINY_F_OPS_RESIDENT
+#define TINY_F_OPS_RESIDENT 1  // 0 (experiments): the sweep operators' rows are read from LDS at the top of every sweep
+#endif
 #ifndef TINY_JIT_F_SESSION
 #define TINY_JIT_F_SESSION 0
 #endif
@@ -61,6 +74,13 @@ struct DStep;  // tinympc_solve_d_chain.h
 #include "tinympc_solve_e_common.h"
 
 namespace tinympc {
+
+// (a reference to the 16-entry one of two arrays, whichever it is)
+template <int A, int B>
+__device__ __forceinline__ double (&ops_pick(double (&a)[A], double (&b)[B]))[16] {
+    if constexpr (A == 16) return a;
+    else return b;
+}
 
 // KFAM (round 4): layout E's knot-per-lane families here. The four DPP rows of a wavefront are four CHUNKS of the one instance; lane
 // (row j, entry t) takes knot t of chunk 4 wv + j: after the forward sweep has left the wavefront's slots in an LDS exchange buffer it
@@ -79,6 +99,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     static_assert(S >= 2 && NCH >= 2 && NCH <= 4 * WPG && NCH > 4 * (WPG - 1), "layout F: chunk plan");
     using Step = DStep<NX, NU>;
     constexpr bool KF = FAM && KFAM;
+    constexpr bool OPSR = TINY_F_OPS_RESIDENT != 0 && WPG <= 8 && S <= 8;
     constexpr int ES = kfam_es(NXU);
     static_assert(!KF || S + 1 <= 16, "layout F, knot-per-lane families: one pass of 16 entries per chunk");
 
@@ -310,6 +331,17 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         }
     };
 
+#if TINY_F_STAMP
+    unsigned long long stamp[8] = {};
+#endif
+    // The two sweep operators' rows: in registers for the whole solve where the plan leaves room (one or two wavefronts per SIMD, chunks
+    // of up to eight slots: 32 VGPRs on top of <= 210) -- quadrotor N=50 2.73 -> 2.65 us per iteration, N=20 2.12 -> 2.01 --, else
+    // re-read from LDS at the top of every sweep.
+    double mF[OPSR ? 16 : 1], mB[OPSR ? 16 : 1];
+    if constexpr (OPSR) {
+        load_ops(sMf, mF);
+        load_ops(sMb, mB);
+    }
     const int max_iter = p.max_iter;
     const int tid = (int)threadIdx.x;
     double expect = p.session_expect;
@@ -424,8 +456,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     for (int it = 0; it < max_iter; ++it) {  // admm.cpp:129
         const int it0 = __builtin_amdgcn_readfirstlane(it);
         const bool check = __builtin_amdgcn_readfirstlane((int)((ct > 0) && (((it0 + 1) % ct) == 0))) != 0;  // admm.cpp:91
-        double m[16];
-        load_ops(sMf, m);
+        F_STAMP(0);
+        double mloc[OPSR ? 1 : 16];  // (OPSR: both operators' rows live in registers)
+        double (&m)[16] = ops_pick(mF, mloc);
+        if constexpr (!OPSR) load_ops(sMf, m);
         // ================= forward, pass 1: the chunk's end state from a zero incoming state (chunk 0: from x_0) =================
         double xt = bottomc ? x0v : 0.0;
         e_static_for<0, S>([&](auto I) {
@@ -435,7 +469,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 xt = Step::fwd_plain(xt, di, m, cf);
             }
         });
+        F_STAMP(1);
         const double xin = carry_scan(-1, sPow, (is_x && c < NCH) ? xt : 0.0);
+        F_STAMP(2);
         // ================= forward, pass 2: the real sweep (F1) with S1 + D1 + R1 fused in =================
         double pri = 0.0, dua = 0.0;
         if (wv == 0) {  // knot 0, state lanes of chunk 0: x_0 is given (tiny_set_x0), no mat-vec
@@ -493,6 +529,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
 
+        F_STAMP(3);
         // ---- R1 (admm.cpp:93-101): one ballot per wavefront; the flags cross with the backward scan's barrier
         if (check) {
             snap_pri = pri;
@@ -507,7 +544,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         // chain of a chunk of n slots: P <- q~_(n-1) [+ c_in];  for i = n-1 .. 0:  a = [q_(i-1) (i >= 1) + cb | cb] + Mb [P; r_i];
         // d_i = a (input lanes);  P = a (state lanes).  What comes out (state lanes) is p of the chunk's first knot MINUS its q,
         // which the chunk below owns.
-        load_ops(sMb, m);
+        F_STAMP(4);
+        double (&mb_)[16] = ops_pick(mB, mloc);
+        if constexpr (!OPSR) load_ops(sMb, mb_);
         auto bwd_chain = [&](double cin, auto STORE) -> double {
             constexpr bool store = decltype(STORE)::value;
             double px = 0.0, rcur = 0.0, rnext = 0.0, acc = cb;
@@ -541,7 +580,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 const double lrmc2 = (s >= 2) ? (is_x ? lr2 + cb : cb) : cb;
                 const double rh = (s >= 2) ? rhom : 0.0;
                 double a = acc, an, rn;
-                Step::bwd(a, px, rcur, m, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
+                Step::bwd(a, px, rcur, mb_, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
                 if constexpr (store)
                     if (is_u) sD[s * DS + dIdx] = a;  // d_s
                 px = a;
@@ -563,7 +602,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             if (nsl > 0) {
                 e_static_for<0, S_LAST - 1>([&](auto I) { block(std::integral_constant<int, S_LAST - 1 - I.value>{}); });  // S_LAST-1 .. 1
                 a = acc;
-                Step::bwd_last(a, px, rcur, m);
+                Step::bwd_last(a, px, rcur, mb_);
                 if constexpr (store)
                     if (is_u) sD[dIdx] = a;  // d of the chunk's first slot
             }
@@ -571,7 +610,9 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         };
         // pass 1: from q~ alone (speculative: runs before the termination verdict, writes nothing)
         const double e2 = bwd_chain(0.0, std::false_type{});
+        F_STAMP(5);
         const double pin = carry_scan(+1, sPow + 4 * 256, (is_x && c < NCH) ? e2 : 0.0);
+        F_STAMP(6);
         if (check) {  // (behind the scan's barrier)
             int all = 1;
 #pragma unroll
@@ -584,6 +625,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         }
         // pass 2: the real sweep, from the true p entering the chunk; only d is kept
         (void)bwd_chain(is_x ? pin : 0.0, std::true_type{});
+        F_STAMP(7);
     }
 
     // ---- the four residual norms of the last check: rows, then chunks through LDS
@@ -615,31 +657,32 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         }
         if constexpr (!SESSION) write_state(converged);
     }
-    if (threadIdx.x == 0) {
-        double res[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q < NCH; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) res[k] = fmax(res[k], sRes[q * 4 + k]);
-        p.istats[inst * 2 + 0] = it_done;
-        p.istats[inst * 2 + 1] = status;
-        if (res_valid) {
-            p.dstats[inst * 4 + 0] = res[0];
-            p.dstats[inst * 4 + 1] = res[1] * p.rho;
-            p.dstats[inst * 4 + 2] = res[2];
-            p.dstats[inst * 4 + 3] = res[3] * p.rho;
+    if (threadIdx.x < 4) {  // lane k: the k-th residual norm over the chunks (one thread walking all four cost a closed-loop tick ~0.1 us)
+        const int k = (int)threadIdx.x;
+        double res = 0.0;
+        for (int q = 0; q < NCH; ++q) res = fmax(res, sRes[q * 4 + k]);
+        const double out = (k & 1) ? res * p.rho : res;  // pri_x, dua_x (scaled by rho), pri_u, dua_u
+        if (k == 0) {
+            p.istats[inst * 2 + 0] = it_done;
+            p.istats[inst * 2 + 1] = status;
         }
+        if (res_valid) p.dstats[inst * 4 + k] = out;
         if (p.host_sol) {
             double *hs = p.host_sol + (size_t)N * NX + (size_t)NS * NU;
-            hs[4] = (double)it_done;
-            hs[5] = (double)status;
-            if (res_valid) {
-                hs[0] = res[0];
-                hs[1] = res[1] * p.rho;
-                hs[2] = res[2];
-                hs[3] = res[3] * p.rho;
+            if (k == 0) {
+                hs[4] = (double)it_done;
+                hs[5] = (double)status;
             }
+            if (res_valid) hs[k] = out;
         }
     }
+#if TINY_F_STAMP
+    e_barrier();
+    if (lane < 8) {
+        p.sol_x[(size_t)inst * N * NX + wv * 8 + lane] = (double)(stamp[lane] - stamp[0]);
+        if (p.host_sol) p.host_sol[wv * 8 + lane] = (double)(stamp[lane] - stamp[0]);
+    }
+#endif
     if (p.host_sol && (SESSION || p.host_seq != 0.0)) {  // (uniform) everything above is in pinned memory: raise the completion stamp
         __threadfence_system();
         __syncthreads();

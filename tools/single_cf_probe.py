@@ -29,6 +29,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--chunks":  # python tools/single_cf_pr
     CONFIGS = tuple(("F", {"TINYMPC_F_CHUNKS": c, "TINYMPC_BUILTIN": "0"}) for c in sys.argv[2].split(","))
 if len(sys.argv) > 1 and sys.argv[1] == "--slots":  # python tools/single_cf_probe.py --slots 2,3,4,5: chunk length S directly
     CONFIGS = tuple(("F", {"TINYMPC_F_S": c, "TINYMPC_BUILTIN": "0"}) for c in sys.argv[2].split(","))
+if len(sys.argv) > 1 and sys.argv[1] == "--defs":  # python tools/single_cf_probe.py --defs "-DX=0" "-DX=1": experiment builds of layout F
+    CONFIGS = tuple(("F", {"TINYMPC_JIT_DEFS": d}) for d in sys.argv[2:])
 for lay, extra in CONFIGS:
     env = dict(os.environ, TINYMPC_LAYOUT=lay, **extra)
     print("---- TINYMPC_LAYOUT=%s %s" % (lay, extra), flush=True)
