@@ -826,6 +826,19 @@ def main() -> int:
                                                "this run's rate; hbm_model_gbs: SURVEY.md section 8d's streaming model (9-11 accesses per element), of which "
                                                "the kernel moves about 2/3",
                                    "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)", **lmeas}
+            # ... and the same system with a state cone, an input cone and two linear rows per side (round 4: the families' phase of
+            # layout M between the sweeps, one knot per wavefront; HBM-bound at a multiple of the box path's bytes)
+            frng = np.random.default_rng(5)
+            big.set_cone_constraints(Acx=[0, 40], qcx=[3, 6], cx=[0.8, 0.6], Acu=[0], qcu=[3], cu=[0.7])
+            big.set_linear_constraints(Alin_x=frng.standard_normal((2, lnx)) / np.sqrt(lnx), blin_x=np.array([0.3, 0.4]),
+                                       Alin_u=frng.standard_normal((2, lnu)) / np.sqrt(lnu), blin_u=np.array([0.2, 0.25]))
+            fms = []
+            for k in range(4):
+                big.reset_workspace()
+                fms.append(big.solve_timed())
+            fmed = sorted(fms[1:])[1]
+            out["large_system"]["with_families"] = {"workload": "+ 2 state cones, 1 input cone, 2 linear rows per side", "iters_per_s": lB * lit / (fmed * 1e-3),
+                                                    "kernel_ms": fmed, "layout": big.launch_info()["layout"], "fraction_of_box_rate": med / fmed}
             big.reset()
             # ... and beyond 256 rows (round 3): four row tiles per wavefront, the operator tiles streamed from a tile-major copy in L2;
             # with nxu / 20 flop per byte of state this one is priced on the matrix pipe
@@ -980,7 +993,7 @@ def main() -> int:
                 "rocket_batch_N10_iters_per_s": leg("rocket_batch/N=10/iters_per_s"),
                 "adaptive_rho_batch_iters_per_s": leg("adaptive_rho_batch/iters_per_s"), "adaptive_rho_batch_fp64_frac_box_part": leg("adaptive_rho_batch/fp64_frac_box_part"),
                 "wide_system_fp64_frac": leg("wide_system/fp64_frac"), "long_horizon_fp64_frac": leg("long_horizon/fp64_frac"),
-                "large_system_fp64_frac": leg("large_system/fp64_frac"), "large_system_hbm_measured_frac": leg("large_system/hbm_measured_frac"),
+                "large_system_fp64_frac": leg("large_system/fp64_frac"), "large_system_with_families_iters_per_s": leg("large_system/with_families/iters_per_s"), "large_system_hbm_measured_frac": leg("large_system/hbm_measured_frac"),
                 "very_large_system_fp64_frac": leg("very_large_system/fp64_frac"),
                 "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),
                 "cartpole_batch_8192_iters_per_s": leg("cartpole/batch_8192/iters_per_s"), "cartpole_batch_8192_fp64_frac": leg("cartpole/batch_8192/fp64_frac"),
