@@ -113,14 +113,20 @@ def test_systems_beyond_128_rows(pkg, nx, nu, N, varying):
     assert ei.value.code == pkg._lib.ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("nx,nu,N,batch", [(96, 32, 12, 21), (70, 10, 8, 5), (160, 32, 8, 19), (300, 20, 5, 17)])
-def test_families_on_large_systems(pkg, nx, nu, N, batch):
+@pytest.mark.parametrize("nx,nu,N,batch,form", [(96, 32, 12, 21, "one-pass"), (70, 10, 8, 5, "one-pass"), (160, 32, 8, 19, "one-pass"), (300, 20, 5, 17, "one-pass"),
+                                                 (96, 32, 12, 21, "general"), (160, 32, 8, 19, "general"), (70, 10, 8, 5, "ten rows"), (300, 20, 5, 17, "ten rows")])
+def test_families_on_large_systems(pkg, monkeypatch, nx, nu, N, batch, form):
     """Cones and linear rows beyond 64 rows (bindings.cpp:408-478 take any nx, nu): layout M's families phase (wavefront w evaluates
     knots w, w + NW, ... between the sweeps, tinympc_solve_m.hip). A cone inside one 16-row tile, one across a tile boundary, two
     that share rows (projected one after another), one over three tiles, an input cone that starts in the tile the state rows end
     in; three dense state rows, two input rows; fdyn. R = 8, 5, 12 (streamed operators) and 20 (two row tiles per wavefront).
     Against the restatement: iteration counts, 1e-9 on the trajectories, cold start + two warm starts; then the families switched
-    off again (the box path of the same handle)."""
+    off again (the box path of the same handle).
+    Two forms of the phase: up to eight linear rows per side ONE pass computes every row's dot product and the sequence of projections is
+    a scalar recurrence over the rows' Gram matrix ("one-pass"); beyond that, or with TINYMPC_M_FAM_FAST=0, a pass per row ("general",
+    "ten rows")."""
+    if form == "general":
+        monkeypatch.setenv("TINYMPC_M_FAM_FAST", "0")
     P = pkg.problems
     rng = np.random.default_rng(nx * 10 + nu)
     A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
@@ -132,7 +138,8 @@ def test_families_on_large_systems(pkg, nx, nu, N, batch):
     prob.u_min, prob.u_max = np.full(nu, -1.0), np.full(nu, 1.0)
     prob.fdyn = 0.01 * rng.standard_normal(nx)
     prob.cones = dict(Acx=[0, 13, 15, 20], qcx=[3, 6, 3, 41], cx=[0.8, 0.6, 1.1, 0.9], Acu=[0, 5], qcu=[3, 4], cu=[0.7, 1.3])
-    prob.linear = dict(Alin_x=rng.standard_normal((3, nx)) / np.sqrt(nx), blin_x=rng.uniform(0.1, 0.4, 3),
+    nlx = 10 if form == "ten rows" else 3
+    prob.linear = dict(Alin_x=rng.standard_normal((nlx, nx)) / np.sqrt(nx), blin_x=rng.uniform(0.1, 0.4, nlx),
                        Alin_u=rng.standard_normal((2, nu)) / np.sqrt(nu), blin_u=rng.uniform(0.1, 0.3, 2))
     settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
     s = pkg.TinyMPC()

@@ -371,6 +371,7 @@ size_t solve_m_state_doubles(int nx, int nu, int N, int tiles);
 size_t solve_m_fam_doubles(int nx, int nu, int nl);
 size_t solve_m_fam_cone_offset();
 size_t solve_m_fam_lin_offset();
+int solve_m_fam_fast_rows();  // up to this many linear rows per side the description carries the rows' Gram matrices (behind the rows)
 hipError_t launch_solve_m(const SolveParams &p, hipStream_t stream);
 // Run-time specialisation of layout D (tinympc_jit.hip): any (nx, nu, N) that fits the register / LDS plan, compiled with
 // hiprtc from the very sources of the compiled-in instantiations on first use and cached (memory + disk).

@@ -234,6 +234,20 @@ static int refresh_families_m(tinympc_solver *s) {
             ak[GW + 3] = 1.0 / nrm_u;
         }
     }
+    if (nl <= solve_m_fam_fast_rows()) {  // the rows' Gram matrices (the one-pass form of the phase): [side][k][j] = a_k' a_j
+        f[4] = 1.0;
+        double *Gx = f.data() + solve_m_fam_lin_offset() + (size_t)nl * (GW + 4), *Gu = Gx + (size_t)nl * nl;
+        for (int k = 0; k < nl; ++k)
+            for (int j = 0; j < nl; ++j) {
+                const double *ak = f.data() + solve_m_fam_lin_offset() + (size_t)k * (GW + 4), *aj = f.data() + solve_m_fam_lin_offset() + (size_t)j * (GW + 4);
+                double gx = 0.0, gu = 0.0;
+                for (int c = 0; c < nx; ++c) gx += ak[c] * aj[c];
+                for (int c = nx; c < nx + nu; ++c) gu += ak[c] * aj[c];
+                Gx[(size_t)k * nl + j] = gx;
+                Gu[(size_t)k * nl + j] = gu;
+            }
+    }
+    if (const char *env = getenv("TINYMPC_M_FAM_FAST")) f[4] = (env[0] == '0') ? 0.0 : f[4];  // (A/B: the general form of the phase)
     if ((rc = upload(s, s->dfam, f.data(), f.size()))) return rc;
     s->fam_dirty = false;
     return TINYMPC_OK;

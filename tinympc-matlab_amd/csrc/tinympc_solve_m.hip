@@ -94,7 +94,13 @@ int solve_m_geometry(int nx, int nu) { return m_geometry((nx + nu + 15) / 16); }
 __host__ __device__ constexpr size_t m_fam_cone_offset() { return 8; }                                   // [c][first, last, mu]
 __host__ __device__ constexpr size_t m_fam_lin_offset() { return 8 + (size_t)3 * HARD_MAX_CONES; }      // [k][GW coefficients | b_x, b_u, 1/|a_x|^2, 1/|a_u|^2]
 __host__ __device__ constexpr size_t m_fam_lin_stride(int GW) { return (size_t)GW + 4; }
-size_t solve_m_fam_doubles(int nx, int nu, int nl) { return m_fam_lin_offset() + (size_t)nl * m_fam_lin_stride(solve_m_geometry(nx, nu)); }
+// Up to M_FAM_FAST_ROWS linear rows per side (header entry 4 says so) the description also carries the rows' Gram matrices, state side
+// then input side, [k][j] = a_k' a_j, behind the rows: the phase then needs ONE pass for all dot products (m_families_fast).
+constexpr int M_FAM_FAST_ROWS = 8;
+size_t solve_m_fam_doubles(int nx, int nu, int nl) {
+    return m_fam_lin_offset() + (size_t)nl * m_fam_lin_stride(solve_m_geometry(nx, nu)) + (nl <= M_FAM_FAST_ROWS ? (size_t)2 * nl * nl : 0);
+}
+int solve_m_fam_fast_rows() { return M_FAM_FAST_ROWS; }
 size_t solve_m_fam_cone_offset() { return m_fam_cone_offset(); }
 size_t solve_m_fam_lin_offset() { return m_fam_lin_offset(); }
 
@@ -223,6 +229,166 @@ __device__ __forceinline__ void m_families(const SolveParams &p, double *X, doub
                 if (active) gl[o] = gln;
             }
             if (active && real) lx[o] = l;
+        }
+    }
+}
+
+// The same phase with fewer bytes (the sweeps and this phase are HBM-bound: what counts is how often an array is walked). Cones touch
+// few rows: only the slots that hold a cone row (`cmask`, wave-uniform) get a temporary (in LX) -- every other row's projected value IS
+// its x + gc. Linear rows (up to M_FAM_FAST_ROWS per side): the dot products of ALL rows with the unprojected s = x + gl in one pass;
+// what the earlier projections of the sequence change in row k's product follows from the rows' Gram matrix,
+//     a_k' (s - sum_{j<k} dist_j a_j) = a_k' s - sum_{j<k} dist_j (a_k' a_j),
+// a scalar recurrence per instance; the projected vector is rebuilt in the last pass, s -> s - dist_k a_k in the order of the rows
+// (the reference's own sequence of updates). Per knot: x, gl once (dots), x, gc, gl once more and gc, gl, LX out -- 5 reads + 3 writes
+// against 9-13 + 7 of m_families. Same results up to the rounding of the products (parity tests: 1e-9, iteration counts exact).
+template <int R, int NW>
+__device__ __forceinline__ void m_families_fast(const SolveParams &p, double *X, double *GCa, double *GLa, double *LXa, int wv, int lane, bool active,
+                                                unsigned long long cm_lo, unsigned long long cm_hi) {
+    constexpr int GW = m_geometry(R), NS = 4 * R, KM = M_FAM_FAST_ROWS;
+    const size_t KD = m_knot_doubles(R);
+    const double *F = p.fam;
+    const int nx = p.nx, nxu = p.nx + p.nu, N = p.N;
+    const int ncx = __builtin_amdgcn_readfirstlane((int)F[0]), ncu = __builtin_amdgcn_readfirstlane((int)F[1]);
+    const int nlx = __builtin_amdgcn_readfirstlane((int)F[2]), nlu = __builtin_amdgcn_readfirstlane((int)F[3]);
+    const int nc = ncx + ncu, nl = nlx > nlu ? nlx : nlu;
+    const int kq = lane >> 4;
+    const double rho = p.rho;
+    const double *const rows = F + m_fam_lin_offset();
+    const double *const Gx = rows + (size_t)nl * m_fam_lin_stride(GW), *const Gu = Gx + (size_t)nl * nl;
+    auto sum4 = [](double v) -> double {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    };
+    for (int kn = wv; kn < N; kn += NW) {
+        double *x = X + (size_t)kn * KD, *gc = GCa + (size_t)kn * KD, *gl = GLa + (size_t)kn * KD, *lx = LXa + (size_t)kn * KD;
+        const bool has_u = kn < N - 1;
+        auto row_at = [&](int sl) -> int { return 16 * (sl >> 2) + kq + 4 * (sl & 3); };
+        auto cone_on = [&](int r) -> bool { return r < nx ? ncx > 0 : (r < nxu && has_u && ncu > 0); };
+        auto lin_on = [&](int r) -> bool { return r < nx ? nlx > 0 : (r < nxu && has_u && nlu > 0); };
+        auto cone_slot = [&](int sl) -> bool { return (((sl < 64) ? (cm_lo >> sl) : (cm_hi >> (sl - 64))) & 1ull) != 0ull; };  // (uniform)
+        // ---- 1: the rows' dot products with s = x + gl; the cone slots' temporaries
+        double dx[KM], du[KM];  // a_k' s per side; from the recurrence on: dist_k
+#pragma unroll
+        for (int k = 0; k < KM; ++k) dx[k] = du[k] = 0.0;
+        constexpr int U = 4;  // slots whose loads are in flight together (see pass 4)
+        static_assert(NS % U == 0, "slots come in fours");
+        for (int s0 = 0; s0 < NS; s0 += U) {
+            bool any = nl > 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) any = any || (nc > 0 && cone_slot(s0 + u));
+            if (!any) continue;  // (uniform)
+            double xv[U], gcv[U], glv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned o = (unsigned)((s0 + u) * 64 + lane);
+                const bool cs = nc > 0 && cone_slot(s0 + u);
+                xv[u] = (nl > 0 || cs) ? x[o] : 0.0;
+                gcv[u] = cs ? gc[o] : 0.0;
+                glv[u] = nl > 0 ? gl[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sl = s0 + u, r = row_at(sl);
+                const unsigned o = (unsigned)(sl * 64 + lane);
+                const bool cs = nc > 0 && cone_slot(sl);
+                if (cs && active && cone_on(r)) lx[o] = xv[u] + gcv[u];
+                if (nl > 0) {
+                    const double sv0 = lin_on(r) ? xv[u] + glv[u] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        if (k < nl) {  // (uniform)
+                            const double prod = rows[(size_t)k * m_fam_lin_stride(GW) + r] * sv0;
+                            dx[k] += (r < nx) ? prod : 0.0;
+                            du[k] += (r < nx) ? 0.0 : prod;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- 2: the sequence of half-spaces as a scalar recurrence (project_halfspaces: row k sees what rows 0 .. k-1 moved)
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            if (k < nl) {
+                const double *rk = rows + (size_t)k * m_fam_lin_stride(GW);
+                double dotx = sum4(dx[k]), dotu = sum4(du[k]);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) {
+                    if (j < k) {
+                        dotx = fma(-dx[j], Gx[(size_t)k * nl + j], dotx);
+                        dotu = fma(-du[j], Gu[(size_t)k * nl + j], dotu);
+                    }
+                }
+                dx[k] = dotx > rk[GW] ? (dotx - rk[GW]) * rk[GW + 2] : 0.0;      // dist_k, state side (0: not violated, nothing moves)
+                du[k] = dotu > rk[GW + 1] ? (dotu - rk[GW + 1]) * rk[GW + 3] : 0.0;
+            }
+        }
+        // ---- 3: cones one after another on the temporaries
+        for (int c = 0; c < nc; ++c) {
+            const double *cd = F + m_fam_cone_offset() + 3 * c;
+            const int first = __builtin_amdgcn_readfirstlane((int)cd[0]), last = __builtin_amdgcn_readfirstlane((int)cd[1]);
+            const double mu = cd[2];
+            if (first >= nx && !has_u) continue;
+            const double inv_mu = (mu != 0.0) ? 1.0 / mu : 0.0;
+            const int s_first = 4 * (first >> 4) + ((first & 15) >> 2), s_last = 4 * (last >> 4) + ((last & 15) >> 2);
+            double a2 = 0.0, t = 0.0;
+            for (int sl = s_first; sl <= s_last; ++sl) {
+                const int r = row_at(sl);
+                const double v = lx[(unsigned)(sl * 64 + lane)];
+                a2 += (r >= first && r < last) ? v * v : 0.0;
+                t += (r == last) ? v : 0.0;
+            }
+            a2 = sum4(a2);
+            t = sum4(t);
+            for (int sl = s_first; sl <= s_last; ++sl) {
+                const int r = row_at(sl);
+                const unsigned o = (unsigned)(sl * 64 + lane);
+                const double v = lx[o];
+                if (active && r >= first && r <= last) lx[o] = soc_project_element(v, a2, t, mu, inv_mu, r == last ? 2 : 1);
+            }
+        }
+        // ---- 4: duals and the linear-cost term. U slots' loads in flight before the first of their stores: the arrays may alias as far
+        // as the compiler knows (a load behind a store waits for it), and with one slot in flight per wavefront the phase ran at a
+        // third of the sweeps' bandwidth.
+        for (int s0 = 0; s0 < NS; s0 += U) {
+            double xv[U], gcv[U], glv[U], tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned o = (unsigned)((s0 + u) * 64 + lane);
+                const bool cs = nc > 0 && cone_slot(s0 + u);
+                xv[u] = x[o];
+                gcv[u] = nc > 0 ? gc[o] : 0.0;
+                glv[u] = nl > 0 ? gl[o] : 0.0;
+                tv[u] = cs ? lx[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sl = s0 + u;
+                const bool cs = nc > 0 && cone_slot(sl);
+                const int r = row_at(sl);
+                const unsigned o = (unsigned)(sl * 64 + lane);
+                const bool real = r < nx || (r < nxu && has_u);
+                double l = 0.0;
+                if (cone_on(r)) {
+                    const double sc = xv[u] + gcv[u];
+                    const double vc = cs ? tv[u] : sc;  // (a row outside every cone: its projected value is s itself)
+                    const double gcn = sc - vc;
+                    l -= rho * (vc - gcn);
+                    if (active) gc[o] = gcn;
+                }
+                if (lin_on(r)) {
+                    const double sv0 = xv[u] + glv[u];
+                    double vl = sv0;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        if (k < nl) vl = fma(-((r < nx) ? dx[k] : du[k]), rows[(size_t)k * m_fam_lin_stride(GW) + r], vl);
+                    }
+                    const double gln = sv0 - vl;
+                    l -= rho * (vl - gln);
+                    if (active) gl[o] = gln;
+                }
+                if (active && real) lx[o] = l;
+            }
         }
     }
 }
@@ -368,6 +534,21 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
     int par = 0;                // the slack buffer this iteration READS: 0 = V, 1 = V2
     int buf = 0;
 
+    // FAM: few enough linear rows for the one-pass form (m_families_fast)? and which slots of a knot hold a cone row (uniform)
+    bool fam_fast = false;
+    unsigned long long cmask_lo = 0ull, cmask_hi = 0ull;
+    if constexpr (FAM) {
+        fam_fast = __builtin_amdgcn_readfirstlane((int)p.fam[4]) != 0;
+        const int ncones = __builtin_amdgcn_readfirstlane((int)p.fam[0]) + __builtin_amdgcn_readfirstlane((int)p.fam[1]);
+        for (int c = 0; c < ncones; ++c) {
+            const int first = __builtin_amdgcn_readfirstlane((int)p.fam[m_fam_cone_offset() + 3 * c]);
+            const int last = __builtin_amdgcn_readfirstlane((int)p.fam[m_fam_cone_offset() + 3 * c + 1]);
+            for (int sl = 4 * (first >> 4) + ((first & 15) >> 2); sl <= 4 * (last >> 4) + ((last & 15) >> 2); ++sl) {
+                if (sl < 64) cmask_lo |= 1ull << sl;
+                else cmask_hi |= 1ull << (sl - 64);
+            }
+        }
+    }
     for (int it = 0; it < p.max_iter; ++it) {  // admm.cpp:129
         if (__syncthreads_or(active ? 1 : 0) == 0) break;
         const bool check = (ct > 0) && (((it + 1) % ct) == 0);
@@ -464,7 +645,8 @@ __global__ void __launch_bounds__(64 * m_waves(R)) k_admm_solve_m(const SolvePar
         // ================= the cone / linear families of this iterate (instances that entered the iteration active) =================
         if constexpr (FAM) {
             __syncthreads();  // the rollout's rows come from every wavefront of the tile (waits for the sweep's stores)
-            m_families<R, NW>(p, gXU, gGC, gGL, gLX, wv, lane, active);
+            if (fam_fast) m_families_fast<R, NW>(p, gXU, gGC, gGL, gLX, wv, lane, active, cmask_lo, cmask_hi);
+            else m_families<R, NW>(p, gXU, gGC, gGL, gLX, wv, lane, active);
             __syncthreads();  // the backward sweep reads LX by row tile
         }
         if (active) it_done = it + 1;  // admm.cpp:143
