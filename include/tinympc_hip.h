@@ -331,7 +331,10 @@ int tinympc_get_jit_info(tinympc_solver *s, char *buf, int len);
 /* Decide (and, where needed, specialise -- seconds the first time) the solve kernel for the handle's CURRENT configuration:
  * bounds / references that vary over the horizon, cone / linear families, adaptive rho and slot refill select variants that are
  * otherwise built at the first launch that needs them. Call it once after the constraints and settings are in place to keep that
- * one-off cost out of the first real-time tick. No reference counterpart (the reference has one code path). */
+ * one-off cost out of the first real-time tick. It also tells the library that run-time specialisation is welcome on this handle:
+ * a single instance / small batch of a shape that is not compiled in then runs on the structure-specialised latency kernel (layout
+ * F: 5-25 % fewer microseconds per iteration than the generic latency kernel, resident session included) instead of staying on the
+ * generic one, which needs no compiler. No reference counterpart (the reference has one code path). */
 int tinympc_prepare(tinympc_solver *s);
 
 /* The HIP stream of the handle as an opaque pointer (hipStream_t). */
