@@ -113,6 +113,8 @@ struct tinympc_solver {
     std::string f_sig;
     bool f_ok = false;
     tinympc::FamilyStructure f_fs;
+    signed char f_box_builtin[2] = {-1, -1};  // is the box path's layout F kernel compiled in? [tables constant?]; -1: not asked yet
+    unsigned f_box_key = 0;  // decide_layout_f, box path: what the current f_sig was decided for (0: nothing)
     bool specialise_asked = false;  // tinympc_prepare() was called: run-time specialisation is welcome wherever it is faster (decide_layout_f)
     int f_chunk_len = 0, f_chunks = 0, f_wpg = 0;
     size_t f_lds = 0;

@@ -110,15 +110,24 @@ int decide_layout_f(tinympc_solver *s) {
     // a specialisation, though: a first setup of a new shape must not cost seconds behind the caller's back, so it is taken where it
     // costs nothing -- the configurations compiled into the library (BASELINE configs 2 and 3) -- or where the caller asked for the
     // specialised kernels with tinympc_prepare() (the real-time workflow of INTEGRATION.md); otherwise layout C, which needs none.
-    const bool box_f = possible && !fam && s->layout_c && !s->use_layout_d() && !s->use_layout_e() && solve_jit_enabled() &&
-                       (s->specialise_asked || solve_f_builtin(s->nx, s->nu, s->N, s->tables_const(), false, FamilyStructure(), false));
+    bool box_f = possible && !fam && s->layout_c && !s->use_layout_d() && !s->use_layout_e() && solve_jit_enabled();
+    if (box_f && !s->specialise_asked) {  // (asked once per handle and kind of tables: this runs in front of every launch)
+        signed char &known = s->f_box_builtin[s->tables_const() ? 1 : 0];
+        if (known < 0) known = solve_f_builtin(s->nx, s->nu, s->N, s->tables_const(), false, FamilyStructure(), false) ? 1 : 0;
+        box_f = known == 1;
+    }
     want = want || box_f;
     if (const char *env = getenv("TINYMPC_LAYOUT")) want = (env[0] == 'F' || env[0] == 'f') && possible;
     if (!want) {
         s->f_ok = false;
         s->f_sig.clear();
+        s->f_box_key = 0;
         return TINYMPC_OK;
     }
+    // (the box path decides in front of every closed-loop tick: a small integer instead of the signature string below)
+    const unsigned box_key = fam ? 0u : (8u | (s->tables_const() ? 1u : 0u) | (solve_jit_enabled() ? 2u : 0u));
+    if (!fam && box_key == s->f_box_key && !s->f_sig.empty()) return TINYMPC_OK;
+    s->f_box_key = box_key;
     const FamilyStructure fs = fam ? family_structure(s) : FamilyStructure();
     std::string sig = s->tables_const() ? "ct|" : "var|";
     for (int c = 0; c < fs.ncone; ++c) sig += std::to_string(fs.cone[c][0]) + "," + std::to_string(fs.cone[c][1]) + "," + std::to_string(fs.cone[c][2]) + ";";
