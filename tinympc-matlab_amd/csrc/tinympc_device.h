@@ -291,8 +291,8 @@ bool solve_f_plan(int nx, int nu, int N, bool const_tables, bool families, const
 bool solve_f_supported(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs);  // plans AND compiles
 hipError_t launch_solve_f(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
 bool solve_f_builtin(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, bool session);  // compiled in: costs nothing to ask for
-bool solve_f_session_supported(int nx, int nu, int N, bool families, const FamilyStructure &fs);  // the resident closed-loop variant (compiles)
-hipError_t launch_solve_f_session(const SolveParams &p, const FamilyStructure &fs, hipStream_t stream);
+bool solve_f_session_supported(int nx, int nu, int N, bool launch_const_tables, bool families, const FamilyStructure &fs);  // the resident closed-loop variant, in the form of the handle's launch kernel (compiles)
+hipError_t launch_solve_f_session(const SolveParams &p, const FamilyStructure &fs, bool launch_const_tables, hipStream_t stream);
 void solve_f_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);

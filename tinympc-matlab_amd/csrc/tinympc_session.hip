@@ -83,7 +83,7 @@ int launch_session_kernel(tinympc_solver *s) {
     if (s->session_on_f) {
         p.const_tables = 0;  // (the session kernel always carries per-knot tables: references may change from tick to tick)
         p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
-        HIP_TRY(launch_solve_f_session(p, s->f_fs, s->stream));
+        HIP_TRY(launch_solve_f_session(p, s->f_fs, s->tables_const(), s->stream));
         return TINYMPC_OK;
     }
     HIP_TRY(launch_solve_c(p, s->W, s->KT, s->lds_bytes_c, s->stream));
@@ -147,19 +147,21 @@ int tinympc_session_begin(tinympc_solver *s) {
     const bool c_ok = s->host_path() && (s->layout_c || (fam && s->fam_c)) && !(fam && s->chunk_len > 4) &&
                       !(fam && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()));
     s->session_on_f = false;
-    // (round 4) where the handle's launches already run on layout F -- the box path compiled in or asked for with tinympc_prepare() --
-    // its resident variant is the faster one too, if it is there for the asking (compiled in / prepare() again)
+    // (round 4) where the handle's launches already run on layout F -- the families by default, the box path compiled in or asked for
+    // with tinympc_prepare() -- its resident variant is the one whose ticks are bit-identical to those launches (and the faster one):
+    // taken if it is there for the asking (the families specialise at run time anyway; the box path: compiled in / prepare())
     bool f_first = false;
-    if (c_ok && s->host_path() && !fam) {
+    if (c_ok && s->host_path()) {
         if ((rc = resolve_plan(s))) return rc;
-        f_first = current_plan(s).kernel == KernelId::F && (s->specialise_asked || solve_f_builtin(s->nx, s->nu, s->N, false, false, FamilyStructure(), true)) &&
-                  solve_f_session_supported(s->nx, s->nu, s->N, false, s->f_fs);
+        f_first = current_plan(s).kernel == KernelId::F &&
+                  (fam || s->specialise_asked || solve_f_builtin(s->nx, s->nu, s->N, false, false, FamilyStructure(), true)) &&
+                  solve_f_session_supported(s->nx, s->nu, s->N, s->tables_const(), fam, s->f_fs);
     }
     if (f_first) s->session_on_f = true;
     else if (!c_ok) {
         if (!s->host_path()) return fail(TINYMPC_ERR_UNSUPPORTED, "session: single-instance handles only (batch 1, nx+nu <= 16)");
         if ((rc = resolve_plan(s))) return rc;
-        if (current_plan(s).kernel != KernelId::F || !solve_f_session_supported(s->nx, s->nu, s->N, fam, s->f_fs))
+        if (current_plan(s).kernel != KernelId::F || !solve_f_session_supported(s->nx, s->nu, s->N, s->tables_const(), fam, s->f_fs))
             return fail(TINYMPC_ERR_UNSUPPORTED, "session: neither the latency kernel (box path; families up to N = 65, disjoint cones) nor layout F "
                         "(run-time specialised; TINYMPC_JIT not 0) has a resident kernel for this configuration (N = %d)", s->N);
         s->session_on_f = true;
