@@ -30,6 +30,18 @@ def test_lint_catches_a_planted_hazard():
     assert len(bad) == 1  # one wait state is not enough
     n, bad = _lint(".LBB0_1:\n v_fmac_f64_dpp v[2:3], v[4:5], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
     assert len(bad) == 1
+    # a branch target inside the window is followed to the branches that jump to it (round 4): safe on both paths ...
+    dpp = " v_fmac_f64_dpp v[2:3], v[4:5], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+    both = "v_mov_b32_e32 v4, v9\n s_nop 0\n s_cbranch_execz .LBB0_2\n v_add_u32_e32 v1, v1, v1\n v_add_u32_e32 v1, v1, v1\n.LBB0_2:\n" + dpp
+    assert _lint(both) == (1, [])
+    # ... a write one wait state in front of the branch is not (the branch itself is the only wait state on that path) ...
+    n, bad = _lint("v_mov_b32_e32 v4, v9\n s_cbranch_execz .LBB0_2\n v_add_u32_e32 v1, v1, v1\n v_add_u32_e32 v1, v1, v1\n.LBB0_2:\n" + dpp)
+    assert len(bad) == 1 and "branch at line" in bad[0][2]
+    # ... nor is a write on the fall-through path right above the label
+    n, bad = _lint("s_cbranch_execz .LBB0_2\n s_nop 1\n v_mov_b32_e32 v5, v9\n.LBB0_2:\n" + dpp)
+    assert len(bad) == 1
+    # (nothing falls through an unconditional branch)
+    assert _lint("s_nop 1\n s_cbranch_execz .LBB0_2\n v_mov_b32_e32 v5, v9\n s_branch .LBB0_3\n.LBB0_2:\n" + dpp + ".LBB0_3:\n s_endpgm\n") == (1, [])
     assert _lint("v_mov_b32_e32 v4, v9\n v_add_u32_e32 v1, v1, v1\n v_add_u32_e32 v1, v1, v1\n" + good.split("\n")[1] + "\n")[1] == []
     # the 64-bit DPP move (layout E's masked gathers) reads its source through the crossbar too
     n, bad = _lint("v_mul_f64 v[4:5], v[8:9], v[8:9]\n v_mov_b64_dpp v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n")
@@ -149,7 +161,7 @@ def test_compiled_in_specialisations_are_linted_and_do_not_spill():
         if name in ge.builtin_guarded():  # (the lint found a hazard in its bare form: it keeps the guard in front of every chain)
             assert with_nop >= chains // 2, (name, chains, with_nop)  # (the backward chains start behind their own v_mov)
         else:
-            assert chains > with_nop + 10, (name, chains, with_nop)
+            assert chains >= 2 * with_nop, (name, chains, with_nop)
 
 
 E_ROCKET = dict(nround=1, ncone=2, cones="{0,0,2},{0,6,8}", nlx=1, nlu=0)

@@ -170,6 +170,8 @@ struct SolveParams {
     // next instance index from this counter (instance = 4 x launched wavefronts + old value; zeroed by the host before the launch),
     // so that a wavefront does not idle three rows while its slowest instance iterates. NULL: one instance per row and launch.
     int *refill_next;
+    // Layout F (round 4): T_s = Phi^(S-1-s) (-B) as [s][k][16 rows] | aff[16], for the chunk length of the launch (k_build_f_input_tables)
+    const double *ftab;
 };
 
 struct ChunkTableParams {
@@ -205,7 +207,7 @@ __host__ __device__ constexpr int kfam_doubles(int nxu, int S) { return ((3 * (S
 __host__ __device__ constexpr size_t f_lds_bytes(int nu, int N, bool ct, int wpg, int S, bool fam, int nl, int kf_nxu = 0, int ncone = 0) {
     return sizeof(double) * ((size_t)512 + (ct ? 0 : 3 * (N + 2) * 16 + 16) + (fam ? 3 * nl * 16 : 0) + (kf_nxu > 0 ? ((2 * ncone + 1) & ~1) : 0) +
                              2 * 4 * 256 + 2 * wpg * 16 + 16 + 16 * wpg + 64 + (size_t)wpg * ((S * 4 * nu + 1) & ~1) +  // (+ 64: the session's mailbox copy)
-                             (kf_nxu > 0 ? (size_t)wpg * kfam_doubles(kf_nxu, S) : 0));
+                             (kf_nxu > 0 ? (size_t)wpg * kfam_doubles(kf_nxu, S) : 0) + (size_t)S * nu * 16 + 16);       // (+ the chunks' input tables T_s | aff)
 }
 
 // Family description built on the host by the C-ABI layer (masks and coefficients only), doubles:
@@ -340,6 +342,9 @@ hipError_t launch_solve_fam(const SolveParams &p, int W, int KT, size_t lds_byte
 // for small batches). W = 16, N <= 129.
 hipError_t launch_solve_c(const SolveParams &p, int W, int KT, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_build_chunk_tables(const ChunkTableParams &p, hipStream_t stream);
+// layout F: T_s = Phi^(S-1-s) (-B) [s][k][16] | aff[16] (tinympc_solve_c.hip: k_build_f_input_tables); p.Lc unused
+size_t f_input_table_doubles(int nu, int S);
+hipError_t launch_build_f_input_tables(const ChunkTableParams &p, hipStream_t stream);
 void chunk_plan(int N, int *S, int *C, int *Lc);
 size_t solve_c_lds_bytes(int nx, int Lc);
 size_t solve_c_lds_bytes_refs(int nx, int nu, int N, int Lc);

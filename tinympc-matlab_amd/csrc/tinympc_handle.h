@@ -120,6 +120,8 @@ struct tinympc_solver {
     size_t f_lds = 0;
     double *dctab_f = nullptr;   // Phi^(S..4S) | Psi^(S..4S) for layout F's chunk length
     int dctab_f_len = 0;
+    double *dftab = nullptr;     // layout F: the chunks' input tables T_s | aff for f_chunk_len (k_build_f_input_tables)
+    int dftab_cap = 0;           // (slots it was allocated for)
     double *dclock = nullptr;    // (diagnostic build TINY_CLOCK_STAMP only) per-wavefront clock stamps of the last launch
     double *dctab_e = nullptr;   // Phi^S | Psi^S for layout E's chunk length
     int dctab_e_len = 0;         // ... the chunk length it was built for (0: not built)

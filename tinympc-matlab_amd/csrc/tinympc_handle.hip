@@ -136,6 +136,13 @@ int refresh_derived(tinympc_solver *s) {
         c.nx = s->nx; c.nu = s->nu; c.KT = s->KT; c.S = s->f_chunk_len; c.Lc = 4;
         c.ops = s->dops; c.out = s->dctab_f;
         HIP_TRY(launch_build_chunk_tables(c, s->stream));
+        if (!s->dftab || s->dftab_cap < s->f_chunk_len) {  // (a longer chunk than before: a new block, the old one stays on the free list)
+            int rc = dalloc(s, &s->dftab, f_input_table_doubles(s->nu, s->f_chunk_len));
+            if (rc) return rc;
+            s->dftab_cap = s->f_chunk_len;
+        }
+        c.out = s->dftab;
+        HIP_TRY(launch_build_f_input_tables(c, s->stream));
         s->dctab_f_len = s->f_chunk_len;
     }
     if (s->tables_dirty) {

@@ -376,7 +376,7 @@ int launch(tinympc_solver *s, bool timed) {
             HIP_TRY(launch_solve_e(p, s->fs, s->stream));
             break;
         case KernelId::F:
-            p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
+            p.ctab = s->dctab_f; p.ftab = s->dftab; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
             arm_completion_flag(s, p);
             HIP_TRY(launch_solve_f(p, s->f_fs, s->stream));
             break;

@@ -82,7 +82,7 @@ int launch_session_kernel(tinympc_solver *s) {
     p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
     if (s->session_on_f) {
         p.const_tables = 0;  // (the session kernel always carries per-knot tables: references may change from tick to tick)
-        p.ctab = s->dctab_f; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
+        p.ctab = s->dctab_f; p.ftab = s->dftab; p.chunk_len = s->f_chunk_len; p.chunk_count = s->f_chunks; p.chunk_levels = 4;
         HIP_TRY(launch_solve_f_session(p, s->f_fs, s->tables_const(), s->stream));
         return TINYMPC_OK;
     }

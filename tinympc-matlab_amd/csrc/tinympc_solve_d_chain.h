@@ -162,6 +162,88 @@
 #define D_C15 ""
 #endif
 
+// the input columns only (layout F, round 4: e += T d, see DStep::acc_inputs)
+#if 0 >= D_NX && 0 < D_NX + D_NU
+#define D_I0 D_FM_("%[d]", 0)
+#else
+#define D_I0 ""
+#endif
+#if 1 >= D_NX && 1 < D_NX + D_NU
+#define D_I1 D_FM_("%[d]", 1)
+#else
+#define D_I1 ""
+#endif
+#if 2 >= D_NX && 2 < D_NX + D_NU
+#define D_I2 D_FM_("%[d]", 2)
+#else
+#define D_I2 ""
+#endif
+#if 3 >= D_NX && 3 < D_NX + D_NU
+#define D_I3 D_FM_("%[d]", 3)
+#else
+#define D_I3 ""
+#endif
+#if 4 >= D_NX && 4 < D_NX + D_NU
+#define D_I4 D_FM_("%[d]", 4)
+#else
+#define D_I4 ""
+#endif
+#if 5 >= D_NX && 5 < D_NX + D_NU
+#define D_I5 D_FM_("%[d]", 5)
+#else
+#define D_I5 ""
+#endif
+#if 6 >= D_NX && 6 < D_NX + D_NU
+#define D_I6 D_FM_("%[d]", 6)
+#else
+#define D_I6 ""
+#endif
+#if 7 >= D_NX && 7 < D_NX + D_NU
+#define D_I7 D_FM_("%[d]", 7)
+#else
+#define D_I7 ""
+#endif
+#if 8 >= D_NX && 8 < D_NX + D_NU
+#define D_I8 D_FM_("%[d]", 8)
+#else
+#define D_I8 ""
+#endif
+#if 9 >= D_NX && 9 < D_NX + D_NU
+#define D_I9 D_FM_("%[d]", 9)
+#else
+#define D_I9 ""
+#endif
+#if 10 >= D_NX && 10 < D_NX + D_NU
+#define D_I10 D_FM_("%[d]", 10)
+#else
+#define D_I10 ""
+#endif
+#if 11 >= D_NX && 11 < D_NX + D_NU
+#define D_I11 D_FM_("%[d]", 11)
+#else
+#define D_I11 ""
+#endif
+#if 12 >= D_NX && 12 < D_NX + D_NU
+#define D_I12 D_FM_("%[d]", 12)
+#else
+#define D_I12 ""
+#endif
+#if 13 >= D_NX && 13 < D_NX + D_NU
+#define D_I13 D_FM_("%[d]", 13)
+#else
+#define D_I13 ""
+#endif
+#if 14 >= D_NX && 14 < D_NX + D_NU
+#define D_I14 D_FM_("%[d]", 14)
+#else
+#define D_I14 ""
+#endif
+#if 15 >= D_NX && 15 < D_NX + D_NU
+#define D_I15 D_FM_("%[d]", 15)
+#else
+#define D_I15 ""
+#endif
+#define D_CHAIN_IN D_I0 D_I1 D_I2 D_I3 D_I4 D_I5 D_I6 D_I7 D_I8 D_I9 D_I10 D_I11 D_I12 D_I13 D_I14 D_I15
 #define D_CHAIN D_C0 D_C1 D_C2 D_C3 D_C4 D_C5 D_C6 D_C7 D_C8 D_C9 D_C10 D_C11 D_C12 D_C13 D_C14 D_C15
 #define D_MOPS                                                                                                      \
     [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]), [m6] "v"(m[6]), \
@@ -288,6 +370,14 @@ struct DStep<D_NX, D_NU> {
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "v"(nrho), [lr] "v"(lr), D_MOPS);
     }
+    // a += T * d over the INPUT columns only (T_k in m[NX + k]; the other entries of m are not read): layout F accumulates a chunk's end
+    // state from a zero incoming state, sum_s Phi^(S-1-s) (-B) d_s, while the backward sweep produces the d_s (tinympc_solve_f.hip).
+    static __device__ __forceinline__ double acc_inputs(double a, double d, const double (&m)[16]) {
+        // (its operand d is ALWAYS the result of the chain right in front of it: the two wait states of the DPP hazard are spelled out
+        // here in every build, so that a compiled-in kernel's other chain blocks can stay bare)
+        asm volatile("s_nop 1\n\t" D_AL D_CHAIN_IN D_WAIT : [a] "+v"(a) : [d] "v"(d), D_MOPS);
+        return a;
+    }
     // Last backward step (slot 0): nothing left to prepare.
     static __device__ __forceinline__ void bwd_last(double &a, double x, double d, const double (&m)[16]) {
         asm volatile(D_HAZ D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
@@ -317,6 +407,23 @@ struct DStep<D_NX, D_NU> {
 #undef D_C14
 #undef D_C15
 #undef D_CHAIN
+#undef D_I0
+#undef D_I1
+#undef D_I2
+#undef D_I3
+#undef D_I4
+#undef D_I5
+#undef D_I6
+#undef D_I7
+#undef D_I8
+#undef D_I9
+#undef D_I10
+#undef D_I11
+#undef D_I12
+#undef D_I13
+#undef D_I14
+#undef D_I15
+#undef D_CHAIN_IN
 #undef D_MOPS
 #undef D_PROJECT
 #undef D_P1

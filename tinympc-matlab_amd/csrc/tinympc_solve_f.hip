@@ -60,6 +60,9 @@
 #ifndef TINY_F_OPS_RESIDENT
 #define TINY_F_OPS_RESIDENT 1  // 0 (experiments): the sweep operators' rows are read from LDS at the top of every sweep
 #endif
+#ifndef TINY_F_TSUM
+#define TINY_F_TSUM 1  // 0 (experiments): the first forward pass sweeps every chunk from a zero incoming state, as in rounds 3-4a
+#endif
 #ifndef TINY_JIT_F_SESSION
 #define TINY_JIT_F_SESSION 0
 #endif
@@ -100,6 +103,13 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     using Step = DStep<NX, NU>;
     constexpr bool KF = FAM && KFAM;
     constexpr bool OPSR = TINY_F_OPS_RESIDENT != 0 && WPG <= 8 && S <= 8;
+    // TSUM (round 4): no first forward pass. A chunk's end state from a zero incoming state is linear in its inputs,
+    //     e = sum_s Phi^(S-1-s) (-B d_s + cf) = sum_s T_s d_s + aff   (+ Phi^S x_0 for chunk 0),
+    // and the d_s are what the backward sweep's second pass has just produced: it accumulates T_s d_s on the way (NU FMAs per slot
+    // instead of a whole sweep step), the matrices T_s and aff come from k_build_f_input_tables (p.ftab).
+    // Measured (one instance, microseconds per iteration): quadrotor N=50 2.65 -> 2.58, cartpole N=20 1.54 -> 1.49, rocket N=44 / 20 (element
+    // form) 2.97 -> 2.86 / 2.45 -> 2.35; with the knot-per-lane families' long chunks (rocket N=100, S=7) 3.99 -> 4.07: not there.
+    constexpr bool TSUM = TINY_F_TSUM != 0 && !KF;
     constexpr int ES = kfam_es(NXU);
     static_assert(!KF || S + 1 <= 16, "layout F, knot-per-lane families: one pass of 16 entries per chunk");
 
@@ -128,6 +138,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     double *sMail = sRes + 4 * WPG * 4;                     // [64] the session's mailbox as last polled (+ the poller's verdict)
     double *sD = sMail + 64 + (size_t)wv * ((S * DS + 1) & ~1);  // per wavefront: d[S][4 rows x nu]
     double *sKX = sMail + 64 + (size_t)WPG * ((S * DS + 1) & ~1) + (size_t)wv * kfam_doubles(NXU, S);  // (KF) per wavefront: the exchange buffer
+    double *sTd = sMail + 64 + (size_t)WPG * ((S * DS + 1) & ~1) + (KF ? (size_t)WPG * kfam_doubles(NXU, S) : 0);  // [S][NU][16] T_s | aff[16]
     // (KF) this lane's two roles in the exchange buffer: as row r of chunk-row j (slot q = entry q+1: kxRow + (q+1) ES) and as entry
     // t = r of chunk-row j (kxT .. + nx+nu)
     const int kxRow = j * (S + 1) * ES + (r < NXU ? r : NXU - 1);
@@ -147,6 +158,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     }
     if constexpr (!CT)
         for (int i = threadIdx.x; i < 3 * (N + 2) * 16 + 16; i += 64 * WPG) sT[i] = p.tables[i];
+    for (int i = threadIdx.x; i < S * NU * 16 + 16; i += 64 * WPG) sTd[i] = p.ftab[i];
     if constexpr (FAM) EFamilies<NX, NU>::stage_linear_rows(p.fam, KT, sLin, (int)threadIdx.x, 64 * WPG);
     if constexpr (KF) {
         KFamilies<NX, NU>::stage_cone_slopes(p.fam, KT, sMu, (int)threadIdx.x);
@@ -288,6 +300,35 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         return is_x ? (jr == 0 ? cin : far) : 0.0;
     };
 
+    // TSUM: e += T_s d_s (d_s on the input lanes of this row, T_s's row r from LDS)
+    double eacc = 0.0;
+    const double aff_r = (TSUM && is_x) ? sTd[S * NU * 16 + r] : 0.0;
+    double c0 = 0.0;  // Phi^S x_0 (chunk 0; set where x_0 is known: below, and per tick in a session)
+    auto acc_T = [&](auto Sl, double dval) {
+        constexpr int sl = decltype(Sl)::value;
+        double tm[16];
+        e_static_for<0, 16>([&](auto K) {
+            constexpr int kk = decltype(K)::value;
+            tm[kk] = (kk >= NX && kk < NXU) ? sTd[(sl * NU + (kk - NX)) * 16 + r] : 0.0;
+        });
+        eacc = Step::acc_inputs(eacc, dval, tm);
+    };
+    auto set_c0 = [&]() {
+        if constexpr (TSUM) {
+            double mp[KS];
+            load_pow(sPow, mp);  // Phi^S (the forward scan's first level)
+            const double v = group_matvec<W, KS>(mp, k0 ? x0v : 0.0, 0.0);
+            c0 = (bottomc && is_x) ? v : 0.0;
+        }
+    };
+    if constexpr (TSUM) {  // the inputs this solve (or session) starts from: once, from the d it loaded -- in the backward sweep's own
+        // order, last slot first, so that a launched tick starts from the very bits a resident kernel carries over from its last sweep
+        e_static_for<0, S>([&](auto I) {
+            constexpr int i = S - 1 - decltype(I)::value;
+            if (i < nsl) acc_T(std::integral_constant<int, i>{}, sD[i * DS + dIdx]);
+        });
+        set_c0();
+    }
     int it_done = 0, status = 11;  // TINY_UNSOLVED (admm.cpp:114)
     bool res_valid = false, converged = false;
     double snap_pri = 0.0, snap_dua = 0.0;
@@ -382,6 +423,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         if constexpr (KF) {
             if (bottomc && row_ok) sKX[kxRow] = is_x ? x0v : 0.0;  // entry 0 of chunk 0: this tick's x_0
         }
+        set_c0();
         double *const tab = const_cast<double *>(p.tables);  // (mirror: the table rows the other kernels read)
         if (flags & 2) {
             // the references changed: fetch them again from the pinned copies (tinympc_set_x_ref / _u_ref filled them), derive the
@@ -461,14 +503,19 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         double (&m)[16] = ops_pick(mF, mloc);
         if constexpr (!OPSR) load_ops(sMf, m);
         // ================= forward, pass 1: the chunk's end state from a zero incoming state (chunk 0: from x_0) =================
-        double xt = bottomc ? x0v : 0.0;
-        e_static_for<0, S>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            if (i < nsl) {
-                const double di = sD[i * DS + dIdx];
-                xt = Step::fwd_plain(xt, di, m, cf);
-            }
-        });
+        double xt;
+        if constexpr (TSUM) {
+            xt = (eacc + aff_r) + c0;  // (rows that are not a full chunk: never used, see carry_scan)
+        } else {
+            xt = bottomc ? x0v : 0.0;
+            e_static_for<0, S>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (i < nsl) {
+                    const double di = sD[i * DS + dIdx];
+                    xt = Step::fwd_plain(xt, di, m, cf);
+                }
+            });
+        }
         F_STAMP(1);
         const double xin = carry_scan(-1, sPow, (is_x && c < NCH) ? xt : 0.0);
         F_STAMP(2);
@@ -581,8 +628,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 const double rh = (s >= 2) ? rhom : 0.0;
                 double a = acc, an, rn;
                 Step::bwd(a, px, rcur, mb_, V[s2], G[s2], rh, lrmc2, nrho, lr2, an, rn);
-                if constexpr (store)
+                if constexpr (store) {
                     if (is_u) sD[s * DS + dIdx] = a;  // d_s
+                    if constexpr (TSUM) acc_T(std::integral_constant<int, s>{}, a);
+                }
                 px = a;
                 rcur = rnext;
                 rnext = rn;
@@ -603,8 +652,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 e_static_for<0, S_LAST - 1>([&](auto I) { block(std::integral_constant<int, S_LAST - 1 - I.value>{}); });  // S_LAST-1 .. 1
                 a = acc;
                 Step::bwd_last(a, px, rcur, mb_);
-                if constexpr (store)
+                if constexpr (store) {
                     if (is_u) sD[dIdx] = a;  // d of the chunk's first slot
+                    if constexpr (TSUM) acc_T(std::integral_constant<int, 0>{}, a);
+                }
             }
             return a;
         };
@@ -623,7 +674,8 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 break;
             }
         }
-        // pass 2: the real sweep, from the true p entering the chunk; only d is kept
+        // pass 2: the real sweep, from the true p entering the chunk; only d is kept (TSUM: ... and what the next forward scan needs of it)
+        if constexpr (TSUM) eacc = 0.0;
         (void)bwd_chain(is_x ? pin : 0.0, std::true_type{});
         F_STAMP(7);
     }
