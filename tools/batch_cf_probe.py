@@ -1,0 +1,26 @@
+import os, subprocess, sys
+ROOT='/root/repo' if os.path.exists('/root/repo/__graft_entry__.py') else os.getcwd()
+if len(sys.argv)>1 and sys.argv[1]=='--child':
+    import numpy as np
+    sys.path.insert(0,ROOT)
+    import __graft_entry__ as g
+    pkg=g.load_package(); P=pkg.problems
+    for name,prob in (("quadrotor N=50",P.quadrotor(50)),("cartpole N=20",P.cartpole(20))):
+        for batch in (1,64,256,512,768):
+            s=pkg.TinyMPC()
+            s.setup(prob.A,prob.B,prob.Q,prob.R,prob.N,batch=batch,rho=prob.rho,max_iter=200,abs_pri_tol=0.0,abs_dua_tol=0.0)
+            s.set_bound_constraints(prob.x_min,prob.x_max,prob.u_min,prob.u_max)
+            x0s=np.asfortranarray(prob.x0[:,None]*np.linspace(0.5,1.0,batch)[None,:])
+            s.set_x0_batch(x0s) if batch>1 else s.set_x0(prob.x0)
+            ms=[]
+            for _ in range(6):
+                s.reset_workspace(); ms.append(s.solve_timed())
+            t=float(np.median(ms[2:]))
+            print(f"{name:15s} batch {batch:4d} layout {s.launch_info()['layout']} {t:7.3f} ms  {batch*200/t/1e3:8.2f} M iters/s",flush=True)
+            s.reset()
+    sys.exit(0)
+for lay in ("C",None):
+    env=dict(os.environ); env.pop("TINYMPC_LAYOUT",None)
+    if lay: env["TINYMPC_LAYOUT"]=lay
+    print("---- TINYMPC_LAYOUT=%s"%lay,flush=True)
+    subprocess.run([sys.executable,os.path.abspath(__file__),"--child"],env=env)
