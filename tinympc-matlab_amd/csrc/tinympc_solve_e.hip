@@ -464,21 +464,20 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             // ================= forward, pass 1: the chunk's end state from a zero incoming state =================
             if constexpr (CUT) {
                 double xt = bottom ? sK0[4 * 64 + lane] : 0.0;
-                double dcur = 0.0;
+                // (values of e_lds_read_async are only ever handed to the chain blocks, never copied: a two-entry ring indexed by the
+                // slot's parity instead of `cur = next` -- the compiler may place such a copy in front of the block's s_waitcnt)
+                double dring[2] = {0.0, 0.0};
                 if constexpr (!DREG) {
-                    dcur = e_lds_read_async<0>(aD);
+                    dring[0] = e_lds_read_async<0>(aD);
                     e_lds_wait();
                 }
 #if TINY_E_EXP != 3 && TINY_E_EXP != 5
                 e_static_for<0, S>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    double dn = 0.0;
-                    if constexpr (DREG) dcur = DR[i];
-                    else if constexpr (i + 1 < S) dn = e_lds_read_async<(i + 1) * DS * 8>(aD);
+                    if constexpr (!DREG && i + 1 < S) dring[(i + 1) & 1] = e_lds_read_async<(i + 1) * DS * 8>(aD);
                     prio_tick();
-                    if constexpr (i < S_LAST) xt = Step::fwd_plain(xt, dcur, m, cf);
-                    else if (!top) xt = Step::fwd_plain(xt, dcur, m, cf);
-                    if constexpr (!DREG) dcur = dn;
+                    if constexpr (i < S_LAST) xt = Step::fwd_plain(xt, DREG ? DR[i] : dring[i & 1], m, cf);
+                    else if (!top) xt = Step::fwd_plain(xt, DREG ? DR[i] : dring[i & 1], m, cf);
                 });
 #endif
                 sE[wv * 64 + lane] = xt;
@@ -524,47 +523,47 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
             E_STAMP(3);
             double xcur = xin;
             {
-                double dcur = 0.0;
-                if constexpr (!DREG) dcur = e_lds_read_async<0>(aD);
-                double locur = lo_c, hicur = hi_c, glcur = 0.0, gccur = 0.0;
-                double loprev = lo_c, hiprev = hi_c, xprev = 0.0;  // (woven steps: the previous slot's bounds and element)
+                // (rings instead of cur / next / prev variables: what e_lds_read_async returns goes into the chain blocks as it is -- no
+                // register copy that the compiler could place in front of a block's s_waitcnt. Bounds: slot q's live in entry q % 3 --
+                // the woven step also needs slot q-1's while slot q+1's are on their way --, d and the element form's duals in q % 2)
+                double dring[2] = {0.0, 0.0}, gcring[2] = {0.0, 0.0}, glring[2] = {0.0, 0.0};
+                double loring[3] = {lo_c, lo_c, lo_c}, hiring[3] = {hi_c, hi_c, hi_c};
+                double xprev = 0.0;  // (woven steps: the previous slot's element)
+                if constexpr (!DREG) dring[0] = e_lds_read_async<0>(aD);
                 if constexpr (!CT) {
-                    locur = e_lds_read_async<W * 8>(aT);
-                    hicur = e_lds_read_async<(TOFF + W) * 8>(aT);
+                    loring[0] = e_lds_read_async<W * 8>(aT);
+                    hiring[0] = e_lds_read_async<(TOFF + W) * 8>(aT);
                 }
-                if constexpr (GCL) gccur = e_lds_read_async<0>(aGC);
-                if constexpr (GLL) glcur = e_lds_read_async<0>(aGL);
+                if constexpr (GCL) gcring[0] = e_lds_read_async<0>(aGC);
+                if constexpr (GLL) glring[0] = e_lds_read_async<0>(aGL);
                 e_lds_wait();
                 auto fstep = [&](auto Q) {
                     constexpr int q = decltype(Q)::value;
-                    double dn = 0.0, lon = lo_c, hin = hi_c, gln_next = 0.0, gcn_next = 0.0;
-                    if constexpr (DREG) dcur = DR[q];
-                    else if constexpr (q + 1 < S) dn = e_lds_read_async<(q + 1) * DS * 8>(aD);
+                    constexpr int c3 = q % 3, n3 = (q + 1) % 3, p3 = (q + 2) % 3, c2 = q & 1, n2 = (q + 1) & 1;
+                    if constexpr (!DREG && q + 1 < S) dring[n2] = e_lds_read_async<(q + 1) * DS * 8>(aD);
                     if constexpr (!CT && q + 1 < S) {
-                        lon = e_lds_read_async<(q + 2) * W * 8>(aT);
-                        hin = e_lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
+                        loring[n3] = e_lds_read_async<(q + 2) * W * 8>(aT);
+                        hiring[n3] = e_lds_read_async<(TOFF + (q + 2) * W) * 8>(aT);
                     }
-                    if constexpr (GCL && q + 1 < S) gcn_next = e_lds_read_async<(q + 1) * RS * 8>(aGC);
-                    if constexpr (GLL && q + 1 < S) gln_next = e_lds_read_async<(q + 1) * RS * 8>(aGL);
+                    if constexpr (GCL && q + 1 < S) gcring[n2] = e_lds_read_async<(q + 1) * RS * 8>(aGC);
+                    if constexpr (GLL && q + 1 < S) glring[n2] = e_lds_read_async<(q + 1) * RS * 8>(aGL);
                     prio_tick();
                     if constexpr (!TINY_E_WOVEN || q == 0) {
-                        xcur = Step::fwd_reg(xcur, dcur, m, cf, locur, hicur, G[q], V[q], pri, dua);  // (slot 0 complete: the first "can it still converge" test reads it)
+                        xcur = Step::fwd_reg(xcur, DREG ? DR[q] : dring[c2], m, cf, loring[c3], hiring[c3], G[q], V[q], pri, dua);  // (slot 0 complete: the first "can it still converge" test reads it)
                     } else if constexpr (q == 1) {
-                        xprev = xcur = Step::fwd_plain(xcur, dcur, m, cf);  // its row-local block rides on step 2
+                        xprev = xcur = Step::fwd_plain(xcur, DREG ? DR[q] : dring[c2], m, cf);  // its row-local block rides on step 2
                     } else {
                         const double xp = xprev;  // slot q-1's element = this step's state operand on state lanes, u_(q-1) on input lanes
-                        xprev = xcur = Step::fwd_reg_woven(xcur, dcur, m, cf, xp, loprev, hiprev, G[q - 1], V[q - 1], pri, dua);
+                        xprev = xcur = Step::fwd_reg_woven(xcur, DREG ? DR[q] : dring[c2], m, cf, xp, loring[p3], hiring[p3], G[q - 1], V[q - 1], pri, dua);
                     }
-                    loprev = locur;
-                    hiprev = hicur;
                     // (KF) this slot's element -- x_{q+1} on state lanes, u_q on input lanes -- goes up to its knot's lane
                     if constexpr (KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) e_lds_write_masked<(q + 1) * ES * 8>(aKX, xcur, mask_real);
                     if constexpr (FAM && !KF && TINY_E_EXP != 2 && TINY_E_EXP != 5) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
                         double gcn, gln;
                         double gl_old, gc_old;
-                        if constexpr (GC_LDS) gc_old = gccur;
+                        if constexpr (GC_LDS) gc_old = gcring[c2];
                         else gc_old = GC[q];
-                        if constexpr (GL_LDS) gl_old = glcur;
+                        if constexpr (GL_LDS) gl_old = glring[c2];
                         else gl_old = GLr[q];
                         const double l = families(xcur, gc_old, gl_old, gcn, gln);
                         if constexpr (GC_LDS) e_lds_write_masked<q * RS * 8>(aGC, gcn, mask_real);
@@ -573,13 +572,6 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                         else GLr[q] = gln;
                         if constexpr (LX_LDS) e_lds_write_masked<q * RS * 8>(aLX, l, mask_real);
                         else LX[q] = l;
-                    }
-                    if constexpr (!DREG) dcur = dn;
-                    glcur = gln_next;
-                    gccur = gcn_next;
-                    if constexpr (!CT) {
-                        locur = lon;
-                        hicur = hin;
                     }
                 };
                 constexpr int EF = E_FIRST < S ? E_FIRST : S;
@@ -611,10 +603,10 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                 });
                 if constexpr (TINY_E_WOVEN != 0) {  // the row-local block of the sweep's last slot (every chunk has >= 3 slots)
                     if constexpr (S_LAST == S) {
-                        Step::project_prev(xprev, loprev, hiprev, G[S - 1], V[S - 1], pri, dua);
+                        Step::project_prev(xprev, loring[(S - 1) % 3], hiring[(S - 1) % 3], G[S - 1], V[S - 1], pri, dua);
                     } else {
-                        if (top) Step::project_prev(xprev, loprev, hiprev, G[S_LAST - 1], V[S_LAST - 1], pri, dua);
-                        else Step::project_prev(xprev, loprev, hiprev, G[S - 1], V[S - 1], pri, dua);
+                        if (top) Step::project_prev(xprev, loring[(S_LAST - 1) % 3], hiring[(S_LAST - 1) % 3], G[S_LAST - 1], V[S_LAST - 1], pri, dua);
+                        else Step::project_prev(xprev, loring[(S - 1) % 3], hiring[(S - 1) % 3], G[S - 1], V[S - 1], pri, dua);
                     }
                 }
             }
@@ -630,7 +622,7 @@ __device__ __forceinline__ void k_admm_solve_e_body(const SolveParams &p, double
                     constexpr int pp = decltype(Pp)::value;
                     double val[NXU], lxo[NXU];
                     e_static_for<0, NXU>([&](auto R) { val[R.value] = e_lds_read_async<(16 * pp * ES + R.value) * 8>(aKT); });
-                    e_lds_wait();
+                    e_lds_wait_for(val);  // (the values are consumed by plain arithmetic: see e_lds_wait_for)
 #if TINY_E_EXP == 1
                     e_static_for<0, NXU>([&](auto R) { lxo[R.value] = val[R.value]; });
 #else

@@ -61,6 +61,25 @@ __device__ __forceinline__ void e_reg_write_masked(double &dst, double v, unsign
                  : "scc");
 }
 __device__ __forceinline__ void e_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// ... the same wait, with the values of e_lds_read_async that ordinary C++ arithmetic consumes next passed THROUGH it: the compiler sees
+// no dependence between a `ds_read` in one asm statement and an s_waitcnt in another, and is free to schedule register arithmetic on the
+// read's result in front of the wait (round 4: a change that only removed four loads in front of layout E's families phase did exactly
+// that -- two thirds of a batch's iteration counts went wrong). Consumers that are asm statements themselves (the chain blocks) are
+// ordered behind the wait as volatile asm; everything else goes through here.
+// (a point in the order of the volatile asm statements that the named values cannot be copied or used in front of: behind a chain
+// block's own s_waitcnt, for the values its successor will take from e_lds_read_async)
+__device__ __forceinline__ void e_lds_arrived() {}
+template <class... T>
+__device__ __forceinline__ void e_lds_arrived(double &v, T &...rest) {
+    asm volatile("" : "+v"(v));
+    e_lds_arrived(rest...);
+}
+template <int NV>
+__device__ __forceinline__ void e_lds_wait_for(double (&v)[NV]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+}
 // workgroup barrier that waits for this wavefront's LDS traffic only (not for its global stores, as __syncthreads() would)
 #if defined(TINY_E_EXP) && (TINY_E_EXP == 4 || TINY_E_EXP == 5)  // (timing experiment: no barrier)
 __device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -274,6 +293,16 @@ struct KFamilies {
     double gc[NXU], gl[NXU];  // the families' duals of this lane's knot
     double rho;
     bool cone_x, cone_u, lin_x, lin_u;  // (uniform) the family is enabled for the side
+    // ... which the structure also says at compile time (it lists the ACTIVE cones and rows only: a side is enabled exactly when it has
+    // one). Small structures use that -- a disabled side's rows drop out of the loops below (rocket N=100 x 4,096 on layout E: 2.62 ->
+    // 2.52 ms) --; large ones keep the run-time flags (20 cones + 120 rows: the folded form needed 50-80 registers more and spilled).
+    static constexpr bool has_cone(bool input_side) {
+        for (int c = 0; c < E_NCONE; ++c)
+            if ((E_CONES[c].first >= NX) == input_side) return true;
+        return false;
+    }
+    static constexpr bool FOLD = E_NCONE <= 4 && E_NL <= 4;
+    static constexpr bool CX = has_cone(false), CU = has_cone(true), LX_ = E_NLX > 0, LU_ = E_NLU > 0;
     const double *sMu;        // LDS: [2][E_NCONE] slope of cone c of the list | its reciprocal (uniform reads: no registers for up to 64 cones)
     const double *sLin;       // LDS: [E_NL][3][16]  a_k | b_k | 1/||a_k||^2, per ROW-layout lane (state lanes: the state side's row k)
 
@@ -336,7 +365,7 @@ struct KFamilies {
             });
             e_static_for<0, NXU>([&](auto R) {
                 constexpr int r = R.value;
-                const bool on = r < NX ? cone_x : cone_u;
+                const bool on = FOLD ? (r < NX ? bool(CX) : bool(CU)) : (r < NX ? cone_x : cone_u);
                 const double gcn = (val[r] + gc[r]) - sv[r];
                 if (on) {
                     gc[r] = gcn;
@@ -372,7 +401,7 @@ struct KFamilies {
             }
             e_static_for<0, NXU>([&](auto R) {
                 constexpr int r = R.value;
-                const bool on = r < NX ? lin_x : lin_u;
+                const bool on = FOLD ? (r < NX ? bool(LX_) : bool(LU_)) : (r < NX ? lin_x : lin_u);
                 const double gln = (val[r] + gl[r]) - sv[r];
                 if (on) {
                     gl[r] = gln;
