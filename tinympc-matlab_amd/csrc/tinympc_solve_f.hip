@@ -278,6 +278,12 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             const double t = end_val + group_matvec<W, KS>(m1, rows_shift1(dir, end_val), 0.0);
             L = t + group_matvec<W, KS>(m2, rows_shift2(dir, t), 0.0);
         }
+        if constexpr (WPG == 1) {
+            // ONE wavefront (up to four chunks: short horizons, round 4): what enters a row is the prefix of the rows before it -- no
+            // totals to exchange, no barrier in the whole iteration
+            const double Lprev1 = rows_shift1(dir, L);
+            return is_x ? (jr == 0 ? 0.0 : Lprev1) : 0.0;
+        }
         double m4[KS], mj[KS];
         load_pow(Pm + 3 * 256, m4);
         load_pow(Pm + (size_t)(jr >= 1 ? jr - 1 : 0) * 256, mj);
@@ -285,7 +291,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         const double Lprev = rows_shift1(dir, L);
         e_barrier();
         // totals of the wavefronts the carry comes from, nearest last: cin = T_far; cin = T_next + P4 cin; ...
-        double tv[WPG - 1];
+        double tv[WPG > 1 ? WPG - 1 : 1];
         e_static_for<0, WPG - 1>([&](auto Q) {
             const int v = dir < 0 ? Q.value : WPG - 1 - Q.value;  // forward: 0, 1, ..; backward: WPG-1, WPG-2, ..
             tv[Q.value] = is_x ? sY[(cur * WPG + v) * 16 + r] : 0.0;

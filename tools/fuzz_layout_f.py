@@ -25,7 +25,7 @@ for case in range(count):
     nxu = int(rng.integers(3, 17))
     nu = int(rng.integers(1, max(2, nxu // 3 + 1)))
     nx = nxu - nu
-    N = int(rng.choice([rng.integers(10, 30), rng.integers(30, 70), rng.integers(70, 130)]))
+    N = int(rng.choice([rng.integers(6, 14), rng.integers(10, 30), rng.integers(30, 70), rng.integers(70, 130)]))  # (6 .. 13: the one-wavefront plans)
     batch = int(rng.choice([1, 1, 1, 3, 40]))
     fam = bool(rng.integers(0, 2))
     varying = bool(rng.integers(0, 2))

@@ -9,7 +9,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     pkg = g.load_package(); P = pkg.problems
     probs = (("quadrotor N=10", P.quadrotor(10)), ("quadrotor N=20", P.quadrotor(20)), ("quadrotor N=50", P.quadrotor(50)),
              ("quadrotor N=100", P.quadrotor(100)), ("cartpole N=20", P.cartpole(20)))
-    if os.environ.get("TINYMPC_F_S"):
+    if os.environ.get("TINYMPC_F_SHORT"):
+        probs = tuple(("quadrotor N=%d" % n, P.quadrotor(n)) for n in (8, 10, 13, 17, 20, 25)) + tuple(("cartpole N=%d" % n, P.cartpole(n)) for n in (10, 20, 25))
+    elif os.environ.get("TINYMPC_F_S"):
         probs = tuple(("quadrotor N=%d" % n, P.quadrotor(n)) for n in (10, 15, 20, 30, 40, 50, 65, 80, 100, 130)) + (("cartpole N=20", P.cartpole(20)), ("cartpole N=40", P.cartpole(40)))
     for name, prob in probs:
         s = pkg.TinyMPC()
@@ -31,6 +33,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--slots":  # python tools/single_cf_pro
     CONFIGS = tuple(("F", {"TINYMPC_F_S": c, "TINYMPC_BUILTIN": "0"}) for c in sys.argv[2].split(","))
 if len(sys.argv) > 1 and sys.argv[1] == "--defs":  # python tools/single_cf_probe.py --defs "-DX=0" "-DX=1": experiment builds of layout F
     CONFIGS = tuple(("F", {"TINYMPC_JIT_DEFS": d}) for d in sys.argv[2:])
+if len(sys.argv) > 1 and sys.argv[1] == "--short":  # short horizons: chunk lengths that leave one wavefront (<= 4 chunks) against the default plan
+    CONFIGS = (("C", {"TINYMPC_F_SHORT": "1"}), ("F", {"TINYMPC_F_SHORT": "1", "TINYMPC_BUILTIN": "0"})) + tuple(("F", {"TINYMPC_F_S": c, "TINYMPC_F_SHORT": "1", "TINYMPC_BUILTIN": "0"}) for c in ("3", "4", "5", "6", "7"))
 for lay, extra in CONFIGS:
     env = dict(os.environ, TINYMPC_LAYOUT=lay, **extra)
     print("---- TINYMPC_LAYOUT=%s %s" % (lay, extra), flush=True)
