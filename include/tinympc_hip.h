@@ -256,9 +256,11 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
  * This library's own such calls (tinympc_setup / tinympc_reset of ANOTHER handle on the device: hipMalloc / hipFree) first
  * send the resident kernels of the device home; their sessions stay open and the next tinympc_session_step starts the
  * kernel again (a few milliseconds, once). Calls from outside the library (hipDeviceSynchronize, torch.cuda.synchronize,
- * somebody else's hipMalloc) cannot be seen coming: end the session before them. The resident kernel is layout C's: its results are identical, bit for bit, to the same
- * ticks issued as tinympc_mpc_step_batch calls on that kernel (with the cone / linear families a launched tick runs on
- * layout F by default, whose results differ in the last bits: the carries of its chunks round differently). */
+ * somebody else's hipMalloc) cannot be seen coming: end the session before them. The resident kernel is the variant of the
+ * kernel the handle's launches run on (layout F where that is compiled in, was asked for with tinympc_prepare, or carries the cone /
+ * linear families; layout C otherwise): its results are identical, bit for bit, to the same ticks issued as tinympc_mpc_step_batch
+ * calls. (Only where layout F has no resident kernel for a configuration its launches run on does the session fall back to layout
+ * C's, whose results differ from layout F's in the last bits: the carries of its chunks round differently.) */
 int tinympc_session_begin(tinympc_solver *s);
 int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out);
 int tinympc_session_end(tinympc_solver *s);

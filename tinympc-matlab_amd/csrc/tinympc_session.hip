@@ -140,9 +140,8 @@ int tinympc_session_begin(tinympc_solver *s) {
     if ((rc = bind_device(s))) return rc;  // (ends a session that is still open)
     if (s->st.adaptive_rho) return fail(TINYMPC_ERR_UNSUPPORTED, "session: adaptive_rho is not supported");
     if (s->st.max_iter < 1) return fail(TINYMPC_ERR_INVALID_INPUT, "session: max_iter must be >= 1");
-    // Which resident kernel: the latency kernel's SESSION variant (layout C) wherever it holds the configuration -- box path, families up
-    // to N = 65 with disjoint cones --, else layout F's (round 4: the structure-specialised latency kernel; families at any horizon it
-    // plans, overlapping cones, constraint lists beyond the generic kernels' capacities), where the handle's launches run on layout F.
+    // Which resident kernel: layout F's (round 4) where the handle's launches run on layout F -- then the session's ticks are bit-identical
+    // to launched ticks --, else the latency kernel's SESSION variant (layout C: box path, families up to N = 65 with disjoint cones).
     const bool fam = s->families_active();
     const bool c_ok = s->host_path() && (s->layout_c || (fam && s->fam_c)) && !(fam && s->chunk_len > 4) &&
                       !(fam && (family_structure(s).nround > 1 || family_structure(s).beyond_generic()));
