@@ -152,3 +152,49 @@ def test_box_path_of_small_batches_takes_layout_f_only_where_it_costs_nothing_or
     s.solve()
     assert s.launch_info()["layout"] == "C"
     s.reset()
+
+
+@pytest.mark.parametrize("name,N", [("quadrotor", 8), ("quadrotor", 10), ("quadrotor", 13), ("cartpole", 10), ("quadrotor", 14)])
+def test_short_horizons_run_on_one_wavefront_of_layout_f(pkg, monkeypatch, name, N):
+    """plan_f (round 4): up to four chunks of at most three slots fit the DPP rows of ONE wavefront -- the carry scan stays inside it, the
+    iteration has no barrier (N <= 13); from four slots per chunk on it is two wavefronts again (N = 14). Launched solves against the
+    oracle (cold + warm), then a resident session against launched ticks of a twin handle, bit for bit."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    prob = P.quadrotor(N) if name == "quadrotor" else P.cartpole(N, True)
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+
+    def handle():
+        s = pkg.TinyMPC()
+        s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, **settings)
+        s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        s.set_x0(prob.x0)
+        s.prepare()
+        return s
+
+    a, b = handle(), handle()
+    info = a.jit_info()
+    assert a.launch_info()["layout"] == "F" and ("wpg=1 " in info) == (N <= 13), info
+    orc = O.OraclePort(prob).load_problem(prob, settings)
+    for rnd in range(3):
+        x0 = prob.x0 * (1.0 - 0.25 * rnd)
+        a.set_x0(x0)
+        a.solve()
+        orc.set_x0(x0)
+        orc.solve()
+        assert a.get_stats()["iter"] == orc.stats()["iter"] and a.get_stats()["status"] == orc.stats()["status"], rnd
+        assert rel_err(a.get_solution()["states"], orc.solution()[0]) < 1e-9 and rel_err(a.get_solution()["controls"], orc.solution()[1]) < 1e-9, rnd
+    a.reset_workspace()
+    b.reset_workspace()
+    a.session_begin()
+    assert a.launch_info()["layout"] == "F"
+    x = prob.x0.copy()
+    for k in range(15):
+        ua = a.session_step(x)
+        ub = b.mpc_step(x)[:, 0]
+        np.testing.assert_array_equal(ua, ub)
+        assert a.get_stats()["iter"] == b.get_stats()["iter"], k
+        x = prob.A @ x + prob.B @ ua
+    a.session_end()
+    a.reset()
+    b.reset()
