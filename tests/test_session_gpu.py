@@ -61,16 +61,22 @@ def test_session_ticks_equal_launched_ticks(pkg, name):
     b.reset()
 
 
-def test_session_with_per_tick_references_and_families(pkg, monkeypatch):
+@pytest.mark.parametrize("layout,N", [("C", 20), ("F", 10), ("F", 20), ("F", 44)])
+def test_session_with_per_tick_references_and_families(pkg, monkeypatch, layout, N):
     """rocket_landing_constraints.m:86-121 inside a session: references re-sent every tick, cones + linear row + fdyn. The session
-    is the resident variant of the latency kernel of layout C, so its ticks are bit-identical to LAUNCHED ticks of that kernel
-    (TINYMPC_LAYOUT=C here: by default small family batches launch layout F, whose carries round differently -- 1e-15)."""
-    monkeypatch.setenv("TINYMPC_LAYOUT", "C")
+    is the resident variant of the kernel the handle's launches run on, so its ticks are bit-identical to LAUNCHED ticks: layout F by
+    default (round 4; N = 10: one wavefront, 20 / 44: the element form of the families on three / four wavefronts), the latency kernel of
+    layout C with TINYMPC_LAYOUT=C."""
+    if layout == "C":
+        monkeypatch.setenv("TINYMPC_LAYOUT", "C")
+    else:
+        monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
     P = pkg.problems
-    prob = P.rocket(20)
+    prob = P.rocket(N)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
     a, b = _solver(pkg, prob, settings, True), _solver(pkg, prob, settings, True)
     a.session_begin()
+    assert a.launch_info()["layout"] == layout
     x = prob.x0.copy()
     goal = np.zeros(prob.nx)
     for k in range(12):
@@ -83,6 +89,7 @@ def test_session_with_per_tick_references_and_families(pkg, monkeypatch):
         np.testing.assert_array_equal(ua, ub)
         assert a.get_stats()["iter"] == b.get_stats()["iter"], k
         x = prob.A @ x + prob.B @ ua + prob.fdyn
+    assert b.launch_info()["layout"] == layout
     a.session_end()
     a.reset()
     b.reset()
