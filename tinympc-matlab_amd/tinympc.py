@@ -50,6 +50,7 @@ class TinyMPC:
                              adaptive_rho_min=0.1, adaptive_rho_max=10.0, adaptive_rho_enable_clipping=True)
         self.x_min = self.x_max = self.u_min = self.u_max = None
         self._h = _lib.Handle()
+        self._tick = None  # persistent buffers of mpc_step / session_step
         self._L = None
 
     # ------------------------------------------------------------------ setup
@@ -313,15 +314,27 @@ class TinyMPC:
         assert a.shape[0] == self.nx
         _lib.check(self._L.tinympc_set_x0_batch(self._h, _p(a), first, a.shape[1]))
 
+    def _tick_buffers(self):
+        """Persistent buffers of the per-tick verbs (addresses cached: see _lib.fast_tick_functions)."""
+        if self._tick is None or self._tick[0].shape != (self.nx, self.batch):
+            xb = np.zeros((self.nx, self.batch), order="F")
+            ub = np.zeros((self.nu, self.batch), order="F")
+            f_session, f_step = _lib.fast_tick_functions()
+            self._tick = (xb, ub, xb.ctypes.data, ub.ctypes.data, f_session, f_step)
+        return self._tick
+
     def mpc_step(self, x0s) -> np.ndarray:
         """One closed-loop tick for every instance: measured states in (nx x batch, or an nx-vector for
         batch 1), warm-started solve, first controls out (nu x batch). One call, one synchronisation."""
         self._check_setup()
-        a = _f(np.asarray(x0s, dtype=np.float64).reshape(self.nx, -1))
-        assert a.shape == (self.nx, self.batch), f"x0s must be {self.nx} x {self.batch}"
-        u0 = np.zeros((self.nu, self.batch), order="F")
-        _lib.check(self._L.tinympc_mpc_step_batch(self._h, _p(a), _p(u0)))
-        return u0
+        xb, ub, xa, ua, _, f_step = self._tick_buffers()
+        a = np.asarray(x0s, dtype=np.float64)
+        assert a.size == self.nx * self.batch, f"x0s must be {self.nx} x {self.batch}"
+        xb[...] = a.reshape(self.nx, self.batch)
+        rc = f_step(self._h.value, xa, ua)
+        if rc:
+            _lib.check(rc)
+        return ub.copy(order="F")
 
     # ------------------------------------------------------------------ closed-loop session (resident kernel)
     def session_begin(self):
@@ -333,11 +346,14 @@ class TinyMPC:
     def session_step(self, x0) -> np.ndarray:
         """One tick inside a session: measured state in, warm-started solve, first controls out."""
         self._check_setup()
-        a = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1))
+        xb, ub, xa, ua, f_session, _ = self._tick_buffers()
+        a = np.asarray(x0, dtype=np.float64)
         assert a.size == self.nx
-        u0 = np.zeros(self.nu)
-        _lib.check(self._L.tinympc_session_step(self._h, _p(a), _p(u0)))
-        return u0
+        xb[:, 0] = a.reshape(-1)
+        rc = f_session(self._h.value, xa, ua)
+        if rc:
+            _lib.check(rc)
+        return ub[:, 0].copy()
 
     def bench_closed_loop(self, A, B, x0, ticks: int, skip: int = 0, session: bool = False, fdyn=None) -> dict:
         """`ticks` closed-loop ticks driven from C (tinympc_bench_closed_loop): what a caller written in C pays per tick -- no
