@@ -625,6 +625,12 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 }
                 rcur = px;                  // (input lanes: r_T)
                 px = is_x ? px + cin : px;  // (state lanes: + the carry entering from above)
+#if defined(TINY_BUILTIN) && !defined(TINY_CHAIN_NOP)
+                // (compiled in, bare chain blocks: this select is the one place where the compiler puts a VALU write of a chain's DPP
+                // operand right in front of the chain -- the build's lint refused two of the six compiled-in kernels for it, and guarding
+                // EVERY chain of a kernel costs a lone wavefront ~7 cycles apiece, 4 % of the iteration; the two wait states, here only)
+                asm volatile("s_nop 1" : "+v"(px));
+#endif
             };
             auto block = [&](auto Sl) {
                 constexpr int s = decltype(Sl)::value;
