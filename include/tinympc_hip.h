@@ -296,12 +296,6 @@ int tinympc_collect_kernel_ms(tinympc_solver *s, float *kernel_ms, int capacity,
  * (Single-instance handles get the same treatment for the plain verbs: tinympc_set_x0 only fills a pinned
  * buffer the next launch reads, and tinympc_get_solution / tinympc_get_stats after a solve are host copies.) */
 int tinympc_mpc_step_batch(tinympc_solver *s, const double *x0s, double *u0_out);
-/* Measurement helper, not a MEX verb: `ticks` closed-loop ticks of a single-instance handle driven from C (x0 in, warm-started
- * solve, first controls out, plant step x+ = A x + B u0 + f; f may be NULL) through tinympc_mpc_step_batch (session == 0) or the
- * session the caller has opened (session != 0). Only the tick verb is timed, the first `skip` ticks are not counted; *seconds and
- * *iterations are sums over the counted ticks, tick_us (may be NULL) receives every tick's duration. x is advanced in place. */
-int tinympc_bench_closed_loop(tinympc_solver *s, const double *A, const double *B, const double *f, double *x, int ticks, int skip, int session,
-                              double *seconds, long *iterations, double *tick_us);
 
 /* Launch geometry of the solve kernel, for reports: lanes per instance, instances per wavefront,
  * workgroups in the grid, dynamic LDS bytes per workgroup, and whether the per-knot bound/reference

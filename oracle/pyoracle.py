@@ -314,6 +314,9 @@ class OracleRef(_Base):
         if hasattr(L, "ref_bench_closed_loop"):
             L.ref_bench_closed_loop.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
             L.ref_bench_closed_loop.restype = C.c_long
+        if hasattr(L, "ref_bench_closed_loop_samples"):
+            L.ref_bench_closed_loop_samples.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp]
+            L.ref_bench_closed_loop_samples.restype = C.c_long
         if hasattr(L, "ref_codegen"):
             L.ref_codegen.argtypes = [C.c_void_p, C.c_char_p]
             L.ref_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -417,3 +420,26 @@ class OracleRef(_Base):
         sec = C.c_double(0.0)
         its = int(self.L.ref_bench_closed_loop(self.h, _p(a), int(ticks), int(skip), C.byref(sec)))
         return its, float(sec.value), a.ravel()
+
+    def bench_closed_loop_samples(self, x0, ticks: int, skip: int = 0):
+        """As bench_closed_loop, plus the per-tick durations (us) of the counted ticks: (iterations, seconds, x, tick_us)."""
+        a = _f(np.asarray(x0, dtype=np.float64).reshape(-1, 1).copy())
+        sec = C.c_double(0.0)
+        per = np.zeros(int(ticks))
+        its = int(self.L.ref_bench_closed_loop_samples(self.h, _p(a), int(ticks), int(skip), C.byref(sec), _p(per)))
+        return its, float(sec.value), a.ravel(), per[int(skip):].copy()
+
+    @staticmethod
+    def bench_setup(prob, reps: int = 20):
+        """The reference's tiny_setup (tiny_api.cpp:21-122, precompute included) `reps` times on one thread: per-call microseconds."""
+        L = C.CDLL(REF_LIB)
+        L.ref_bench_setup.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp]
+        nx, nu, N = prob.nx, prob.nu, prob.N
+        A, B, Q, R = _f(prob.A), _f(prob.B), _f(prob.Q), _f(prob.R)
+        big = 1e17
+        xmn, xmx = _f(np.full((nx, N), -big)), _f(np.full((nx, N), big))
+        umn, umx = _f(np.full((nu, N - 1), -big)), _f(np.full((nu, N - 1), big))
+        us = np.zeros(int(reps))
+        ok = L.ref_bench_setup(_p(A), _p(B), _p(Q), _p(R), float(prob.rho), nx, nu, N, _p(xmn), _p(xmx), _p(umn), _p(umx), int(reps), _p(us))
+        assert ok == reps
+        return us

@@ -285,7 +285,9 @@ long ref_bench_solves(void *h, const double *x0s, int count, int reps) {
 // the first `skip` of them untimed. Only the three core calls of a tick are inside the timed region (what the MEX verbs
 // set_x0 / solve / get_solution reach, bindings.cpp:107-131, 212-261); the plant step is outside it. Returns the total
 // ADMM iterations of the timed ticks; *seconds receives the timed seconds, x0 is overwritten with the final state.
-long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *seconds) {
+// ... tick_us (may be NULL) receives every tick's duration in microseconds, counted or not (the same samples the GPU side's
+// tinympc_bench_closed_loop returns: bench.py quotes the same statistic on both sides).
+long ref_bench_closed_loop_samples(void *h, double *x0, int ticks, int skip, double *seconds, double *tick_us) {
     TinySolver *s = static_cast<TinySolver *>(h);
     CoutSilencer quiet(true);
     int nx = s->work->nx;
@@ -299,6 +301,7 @@ long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *sec
         tiny_solve(s);
         tinyVector u0 = s->solution->u.col(0);
         clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (tick_us) tick_us[k] = 1e6 * (double)(t1.tv_sec - t0.tv_sec) + 1e-3 * (double)(t1.tv_nsec - t0.tv_nsec);
         if (k >= skip) {
             acc += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
             iters += s->work->iter;
@@ -308,6 +311,28 @@ long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *sec
     Eigen::Map<Eigen::VectorXd>(x0, nx) = x;
     if (seconds) *seconds = acc;
     return iters;
+}
+
+long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *seconds) {
+    return ref_bench_closed_loop_samples(h, x0, ticks, skip, seconds, nullptr);
+}
+
+// CPU-baseline helper for bench.py's `setup` leg: tiny_setup (tiny_api.cpp:21-122, precompute included) + the teardown the MEX's
+// reset does, `reps` times on one thread; us_out[r] receives the microseconds of the r-th tiny_setup alone. Returns the number of
+// successful setups.
+int ref_bench_setup(const double *A, const double *B, const double *Q, const double *R, double rho, int nx, int nu, int N,
+                    const double *x_min, const double *x_max, const double *u_min, const double *u_max, int reps, double *us_out) {
+    int ok = 0;
+    for (int r = 0; r < reps; ++r) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        void *h = ref_setup(A, B, Q, R, rho, nx, nu, N, x_min, x_max, u_min, u_max, 0);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (us_out) us_out[r] = 1e6 * (double)(t1.tv_sec - t0.tv_sec) + 1e-3 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (h) ok += 1;
+        ref_free(h);
+    }
+    return ok;
 }
 
 }  // extern "C"

@@ -13,10 +13,11 @@ import pytest
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "tinympc_hip.h")
+BENCH_HEADER = os.path.join(ROOT, "include", "tinympc_hip_bench.h")
 
 
-def _declared_symbols():
-    text = open(HEADER).read()
+def _declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tinympc_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,6 +30,26 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in tinympc_hip.h but not exported"
     assert sorted(pkg._lib.SIGNATURES) == declared, "ctypes table and header disagree"
     assert pkg.abi_version() == 1
+
+
+def test_measurement_helpers_live_outside_the_boundary(pkg):
+    """include/tinympc_hip_bench.h: the closed-loop measurement loop is a separate library calling public verbs; the two diagnostics
+    are exported by the product library; none of them is declared in the drop-in header."""
+    L = pkg._lib
+    declared = _declared_symbols(BENCH_HEADER)
+    assert declared == sorted(list(L.BENCH_SIGNATURES) + list(L.DEBUG_SIGNATURES))
+    assert not set(declared) & set(_declared_symbols())
+    lib, bench = pkg.load_library(), L.load_bench_library()
+    for name in L.DEBUG_SIGNATURES:
+        assert hasattr(lib, name)
+    for name in L.BENCH_SIGNATURES:
+        assert hasattr(bench, name) and not hasattr(lib, name), name
+    # argument validation of the loop needs no GPU: skip >= ticks is refused (it used to return seconds = 0)
+    x = np.zeros(4)
+    p = x.ctypes.data_as(L.c_double_p)
+    h = C.c_void_p(1)  # (never dereferenced: validation comes first)
+    assert bench.tinympc_bench_closed_loop(h, 2, 1, p, p, None, p, 5, 5, 0, None, None, None) == L.ERR_INVALID_INPUT
+    assert bench.tinympc_bench_closed_loop(None, 2, 1, p, p, None, p, 5, 1, 0, None, None, None) == L.ERR_INVALID_INPUT
 
 
 def test_seventeen_mex_verbs_have_entry_points(pkg):

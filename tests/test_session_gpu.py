@@ -121,6 +121,44 @@ def test_session_is_ended_by_other_verbs_and_survives_idling(pkg):
     b.reset()
 
 
+@pytest.mark.parametrize("how", ["parked", "idle"])
+def test_reference_jump_after_the_resident_kernel_left(pkg, how):
+    """A layout-F session (quadrotor N=50: compiled in) whose resident kernel has gone home -- parked by another handle's setup, or
+    after its 2 s idle time-out -- and then receives a NEW reference (a jump, no shift before it): the restart must hand the pending
+    full re-read to the new kernel. Layout F's session kernel stages nothing itself; round 4 re-issued the command without the
+    reference flag and ran the tick on the old tables (advisor finding, tinympc_session.hip)."""
+    P = pkg.problems
+    prob = P.quadrotor(50)
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
+    a, b = _solver(pkg, prob, settings), _solver(pkg, prob, settings)
+    a.session_begin()
+    assert a.launch_info()["layout"] == "F"
+    x = prob.x0.copy()
+    for _ in range(2):
+        ua, ub = a.session_step(x), b.mpc_step(x)[:, 0]
+        np.testing.assert_array_equal(ua, ub)
+        x = prob.A @ x + prob.B @ ua
+    if how == "parked":
+        other = _solver(pkg, prob, settings)  # its setup sends the device's resident kernels home
+        other.reset()
+    else:
+        time.sleep(2.6)
+    goal = np.array([0.8, -0.6, 0.5, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    x_ref = np.repeat(goal[:, None], prob.N, axis=1)
+    x_ref[:, ::2] *= 0.9  # (varies over the horizon: not a constant-table case)
+    for h in (a, b):
+        h.set_x_ref(x_ref)
+    for k in range(3):
+        ua, ub = a.session_step(x), b.mpc_step(x)[:, 0]
+        np.testing.assert_array_equal(ua, ub, err_msg=f"{how}: tick {k} after the jump")
+        assert a.get_stats()["iter"] == b.get_stats()["iter"]
+        x = prob.A @ x + prob.B @ ua
+    a.session_end()
+    np.testing.assert_array_equal(a.mpc_step(x)[:, 0], b.mpc_step(x)[:, 0])
+    a.reset()
+    b.reset()
+
+
 def test_receding_horizon_references_travel_as_one_column(pkg):
     """rocket_landing_constraints.m:96-101: the reference re-sent at tick k+1 is the one of tick k moved up by one knot.
     Inside a session the library detects that (bit for bit) and ships only the new last column with the command; the

@@ -74,8 +74,6 @@ SIGNATURES = {
     "tinympc_compute_sensitivity": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     "tinympc_setup_batch": (C.c_int, [C.POINTER(Handle), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                       C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "tinympc_bench_closed_loop": (C.c_int, [Handle, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
-                                            c_double_p, C.POINTER(C.c_long), c_double_p]),
     "tinympc_set_x0_batch": (C.c_int, [Handle, c_double_p, C.c_int, C.c_int]),
     "tinympc_set_x0_batch_device": (C.c_int, [Handle, C.c_void_p, C.c_int, C.c_int]),
     "tinympc_reset_workspace": (C.c_int, [Handle]),
@@ -100,7 +98,19 @@ SIGNATURES = {
     "tinympc_get_stream": (C.c_void_p, [Handle]),
 }
 
+# include/tinympc_hip_bench.h: measurement helpers / diagnostics, not part of the drop-in boundary
+BENCH_LIB_PATH = os.path.join(_HERE, "libtinympc_bench.so")
+BENCH_SIGNATURES = {
+    "tinympc_bench_closed_loop": (C.c_int, [Handle, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
+                                            c_double_p, C.POINTER(C.c_long), c_double_p]),
+}
+DEBUG_SIGNATURES = {  # (exported by the product library itself: they read the handle's diagnostic counters)
+    "tinympc_debug_tick_timing": (C.c_int, [Handle, c_double_p]),
+    "tinympc_debug_setup_timing": (C.c_int, [Handle, c_double_p]),
+}
+
 _lib = None
+_bench_lib = None
 
 
 class TinyMPCError(RuntimeError):
@@ -127,11 +137,28 @@ def load_library() -> C.CDLL:
     missing = [n for n in SIGNATURES if not hasattr(lib, n)]
     if missing:
         raise ImportError(f"{LIB_PATH} does not export: {missing}")
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_bench_library() -> C.CDLL:
+    """libtinympc_bench.so (csrc/bench/): the closed-loop measurement loop, a caller of the product library's public verbs."""
+    global _bench_lib
+    if _bench_lib is not None:
+        return _bench_lib
+    load_library()  # (the product library first: the bench library resolves its verbs against the SAME loaded copy)
+    if not os.path.exists(BENCH_LIB_PATH):
+        raise FileNotFoundError(f"{BENCH_LIB_PATH} not found: build it with `python __graft_entry__.py`")
+    lib = C.CDLL(BENCH_LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in BENCH_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _bench_lib = lib
     return lib
 
 

@@ -298,9 +298,13 @@ hipError_t launch_solve_f_session(const SolveParams &p, const FamilyStructure &f
 void solve_f_describe(int nx, int nu, int N, bool const_tables, bool families, const FamilyStructure &fs, char *buf, size_t len);
 // Launchers (defined in tinympc_kernels.hip). All are asynchronous on `stream`.
 hipError_t launch_precompute(const PrecomputeParams &p, hipStream_t stream);
+// nx <= 12, nu <= 4: the Riccati fixed point in the registers of one wavefront (tinympc_precompute_rows.hip)
+bool precompute_rows_supported(int nx, int nu);
+hipError_t launch_precompute_rows(const PrecomputeParams &p, hipStream_t stream);
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream);  // asynchronous constant fill
+hipError_t launch_fill_bounds(double *xmin, double *xmax, size_t X, double *umin, double *umax, size_t U, double inf, hipStream_t stream);
 hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int batch, double rho, hipStream_t stream);
 size_t lqr_scratch_doubles(int nx, int nu);
 // The same precompute for large systems (nx+nu > 64; tinympc_precompute_large.hip): every matrix product of an iteration its own

@@ -5,6 +5,7 @@
 // Host-side bookkeeping only: every number the solver produces is computed by the kernels; there is no CPU fallback anywhere.
 #pragma once
 #include "tinympc_hip.h"
+#include "tinympc_hip_bench.h"  // (the diagnostics the product library itself exports)
 
 #include <cstdio>
 #include <cstdlib>
@@ -189,7 +190,12 @@ struct tinympc_solver {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
     }
-    std::vector<void *> allocs;
+    void *arena_dev = nullptr, *arena_pin = nullptr;  // the setup arenas (ArenaPlan below; pooled per device, tinympc_handle.hip)
+    size_t arena_dev_bytes = 0, arena_pin_bytes = 0;
+    std::vector<void *> allocs;       // hipMalloc blocks dalloc() added after setup
+    std::vector<void *> host_allocs;  // hipHostMalloc blocks added after setup (staging of mpc_step_batch on batched handles)
+    double *h_stage = nullptr;        // pinned staging of the problem data (setup's one upload); layout = the device arena's upload block
+    double setup_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tinympc_debug_setup_timing: host microseconds of setup's phases
 
     size_t X() const { return (size_t)nx * N; }
     size_t U() const { return (size_t)nu * (N - 1); }
@@ -201,8 +207,36 @@ struct tinympc_solver {
 namespace tinympc {
 namespace host {
 
+void park_sessions_on_device(int device, const tinympc_solver *except);  // (tinympc_session.hip; described below)
+
+// One block of device memory and one block of pinned host memory per handle (round 5): every array whose size is known at setup is
+// carved out of them -- tinympc_setup_batch used to make ~45 hipMalloc and 5 hipHostMalloc calls (5.9 ms for a quadrotor, twelve
+// times the reference's whole tiny_setup). ArenaPlan collects (slot, offset) pairs in a first pass, the block is allocated once,
+// bind() writes the pointers. 256-byte alignment: every array starts on its own pair of 128-byte lines.
+struct ArenaPlan {
+    struct Item { void **slot; size_t offset; };
+    std::vector<Item> items;
+    size_t total = 0;
+    size_t mark() { total = (total + 255) & ~(size_t)255; return total; }
+    template <typename T>
+    void add(T **slot, size_t count) {
+        mark();
+        items.push_back({reinterpret_cast<void **>(slot), total});
+        total += sizeof(T) * (count ? count : 1);
+    }
+    void bind(void *base) const {
+        for (const Item &it : items) *it.slot = static_cast<char *>(base) + it.offset;
+    }
+};
+
+// Arrays whose size depends on what the verbs receive AFTER setup (the families' description and duals, a longer layout-F chunk,
+// the HBM working copy of a long horizon on layout M): their own hipMalloc, at the launch that first needs them. hipMalloc
+// synchronises the device, so resident session kernels of OTHER handles are sent home first (as setup and destroy do) -- it would
+// otherwise stall until their 2 s idle time-out. Not from inside this handle's own session tick (session_mu is held there and the
+// registry lock comes first in the lock order): a session's kernel was launched once by session_begin, everything it needs exists.
 template <typename T>
 int dalloc(tinympc_solver *s, T **p, size_t count) {
+    if (!s->session_active) park_sessions_on_device(s->device, s);
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
     if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", sizeof(T) * count, hipGetErrorString(e));
@@ -212,6 +246,8 @@ int dalloc(tinympc_solver *s, T **p, size_t count) {
 }
 
 // ---- tinympc_handle.hip
+int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes);  // -> s->arena_dev / arena_pin (from the device's pool when one fits)
+int acquire_stream_kit(tinympc_solver *s);  // stream + event pair from the device's pool (created when the pool is empty)
 int bind_device(tinympc_solver *s);   // every verb that touches the device passes through here first (ends an open session)
 bool rows_constant(const double *m, int rows, int cols);
 int upload(tinympc_solver *s, double *dst, const double *src, size_t count);

@@ -25,6 +25,97 @@ int fail(int code, const char *fmt, ...) {
 
 namespace host {
 
+// Streams and events are kept for the life of the process: hipStreamCreateWithFlags takes 1.4 ms on MI355X / ROCm 7.2 and
+// hipStreamDestroy 1.3 ms (profiles/r05_setup_time.txt) -- more than the rest of tinympc_setup_batch and twenty times the
+// reference's whole tiny_setup. A handle takes a stream + its event pair from the device's pool and puts them back when it is
+// destroyed (idle: destroy() has waited for the stream); the MEX usage -- one global solver, `setup` replacing it again and again
+// (bindings.cpp:17, 92) -- then pays for one stream once.
+namespace {
+struct StreamKit { hipStream_t stream; hipEvent_t ev0, ev1; };
+std::mutex g_kits_mu;
+std::vector<StreamKit> g_kits[64];  // [device]
+constexpr size_t kKitsKept = 16;    // per device; beyond that a returned stream is destroyed
+}  // namespace
+
+// ... and so are the memory blocks of small handles: hipFree + hipHostFree of a single-instance handle's two arenas take 0.2 ms
+// (three times the reference's whole tiny_setup), and a MEX user's `setup` destroys the previous solver first (bindings.cpp:92).
+// Arenas of up to kArenaKeepBytes go back to a per-device pool when their handle is destroyed and serve the next setup that fits.
+namespace {
+struct ArenaKit { void *dev; size_t dev_bytes; void *pin; size_t pin_bytes; };
+std::vector<ArenaKit> g_arenas[64];             // [device]; under g_kits_mu
+constexpr size_t kArenaKeepBytes = 4u << 20;    // device bytes of an arena worth keeping (a quadrotor N=50 instance: 0.1 MB)
+constexpr size_t kArenasKept = 8;
+}  // namespace
+
+int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes) {
+    if (s->device >= 0 && s->device < 64) {
+        std::lock_guard<std::mutex> lock(g_kits_mu);
+        auto &pool = g_arenas[s->device];
+        for (size_t i = 0; i < pool.size(); ++i) {
+            if (pool[i].dev_bytes >= dev_bytes && pool[i].pin_bytes >= pin_bytes) {
+                s->arena_dev = pool[i].dev; s->arena_dev_bytes = pool[i].dev_bytes;
+                s->arena_pin = pool[i].pin; s->arena_pin_bytes = pool[i].pin_bytes;
+                pool.erase(pool.begin() + (long)i);
+                return TINYMPC_OK;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(&s->arena_dev, dev_bytes);
+    if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", dev_bytes, hipGetErrorString(e));
+    s->arena_dev_bytes = dev_bytes;
+    e = hipHostMalloc(&s->arena_pin, pin_bytes, hipHostMallocCoherent);
+    if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipHostMalloc(%zu bytes) failed: %s", pin_bytes, hipGetErrorString(e));
+    s->arena_pin_bytes = pin_bytes;
+    return TINYMPC_OK;
+}
+
+static void release_arenas(tinympc_solver *s) {
+    if (s->arena_dev && s->arena_pin && s->arena_dev_bytes <= kArenaKeepBytes && s->device >= 0 && s->device < 64) {
+        std::lock_guard<std::mutex> lock(g_kits_mu);
+        auto &pool = g_arenas[s->device];
+        if (pool.size() < kArenasKept) {
+            pool.push_back({s->arena_dev, s->arena_dev_bytes, s->arena_pin, s->arena_pin_bytes});
+            s->arena_dev = s->arena_pin = nullptr;
+            return;
+        }
+    }
+    if (s->arena_dev) (void)hipFree(s->arena_dev);
+    if (s->arena_pin) (void)hipHostFree(s->arena_pin);
+    s->arena_dev = s->arena_pin = nullptr;
+}
+
+int acquire_stream_kit(tinympc_solver *s) {
+    if (s->device >= 0 && s->device < 64) {
+        std::lock_guard<std::mutex> lock(g_kits_mu);
+        auto &pool = g_kits[s->device];
+        if (!pool.empty()) {
+            s->stream = pool.back().stream; s->ev0 = pool.back().ev0; s->ev1 = pool.back().ev1;
+            pool.pop_back();
+            return TINYMPC_OK;
+        }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    return TINYMPC_OK;
+}
+
+static void release_stream_kit(tinympc_solver *s) {
+    if (s->stream && s->ev0 && s->ev1 && s->device >= 0 && s->device < 64 && hipStreamQuery(s->stream) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_kits_mu);
+        auto &pool = g_kits[s->device];
+        if (pool.size() < kKitsKept) {
+            pool.push_back({s->stream, s->ev0, s->ev1});
+            s->stream = nullptr; s->ev0 = s->ev1 = nullptr;
+            return;
+        }
+    }
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = nullptr; s->ev0 = s->ev1 = nullptr;
+}
+
 // Every verb that touches the device passes through here first: a resident session kernel would make it wait forever
 // on the handle's stream, so the session is ended (its state is in HBM after every tick) before anything else happens.
 int bind_device(tinympc_solver *s) {
@@ -87,7 +178,11 @@ int run_precompute(tinympc_solver *s) {
     p.Kinf = s->dKinf; p.Pinf = s->dPinf; p.Quu_inv = s->dQuu; p.AmBKt = s->dAmBKt; p.APf = s->dAPf; p.BPf = s->dBPf;
     p.info = s->dinfo; p.scratch = s->dscratch;
     p.use_lds = precompute_scratch_doubles(s->nx, s->nu) <= 6500 ? 1 : 0;
+    // TINYMPC_PRECOMPUTE=lds: the one-workgroup LDS kernel also where the register-resident one applies (A/B runs, tests)
+    const char *env = getenv("TINYMPC_PRECOMPUTE");
+    const bool rows = precompute_rows_supported(s->nx, s->nu) && !(env && (env[0] == 'l' || env[0] == 'L'));
     if (s->layout_m) HIP_TRY(launch_precompute_large(p, s->stream));  // (large systems: one launch per matrix product, on the matrix cores)
+    else if (rows) HIP_TRY(launch_precompute_rows(p, s->stream));     // (nx <= 12, nu <= 4: registers of one wavefront)
     else HIP_TRY(launch_precompute(p, s->stream));
     s->ops_dirty = true;
     s->tables_dirty = true;
@@ -360,17 +455,11 @@ void destroy(tinympc_solver *s) {
     park_sessions_on_device(s->device, s);  // (hipFree synchronises the device: no other handle's resident kernel may be spinning)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void *q : s->allocs) (void)hipFree(q);
-    if (s->h_sol) (void)hipHostFree(s->h_sol);
-    if (s->h_mail) (void)hipHostFree(s->h_mail);
-    if (s->h_xref) (void)hipHostFree(s->h_xref);
-    if (s->h_uref) (void)hipHostFree(s->h_uref);
-    if (s->h_x0) (void)hipHostFree(s->h_x0);
-    if (s->h_u0) (void)hipHostFree(s->h_u0);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (void *q : s->host_allocs) (void)hipHostFree(q);
+    release_arenas(s);  // (small ones: back to the device's pool)
     for (hipEvent_t e : s->ring_ev) (void)hipEventDestroy(e);
     s->ring_ev.clear();
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    release_stream_kit(s);  // (back to the device's pool; an errored stream is destroyed)
     delete s;
 }
 

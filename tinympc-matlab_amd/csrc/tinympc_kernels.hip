@@ -415,6 +415,19 @@ hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int
     return hipGetLastError();
 }
 
+// Setup: the four bound arrays <- -inf / +inf (TinyMPC.m:261-264's 1e17) in ONE launch
+__global__ void __launch_bounds__(256) k_fill_bounds(double *xmin, double *xmax, size_t X, double *umin, double *umax, size_t U, double inf) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < X + U; i += (size_t)gridDim.x * 256) {
+        if (i < X) { xmin[i] = -inf; xmax[i] = inf; }
+        else { umin[i - X] = -inf; umax[i - X] = inf; }
+    }
+}
+hipError_t launch_fill_bounds(double *xmin, double *xmax, size_t X, double *umin, double *umax, size_t U, double inf, hipStream_t stream) {
+    const size_t blocks = (X + U + 255) / 256;
+    hipLaunchKernelGGL(k_fill_bounds, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0, stream, xmin, xmax, X, umin, umax, U, inf);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream) {
     const unsigned blocks = (unsigned)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
     hipLaunchKernelGGL(k_fill, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, count, value);

@@ -165,10 +165,7 @@ int tinympc_session_begin(tinympc_solver *s) {
                         "(run-time specialised; TINYMPC_JIT not 0) has a resident kernel for this configuration (N = %d)", s->N);
         s->session_on_f = true;
     }
-    if (!s->h_mail) {
-        HIP_TRY(hipHostMalloc((void **)&s->h_mail, sizeof(double) * 64, hipHostMallocCoherent));
-        std::memset(s->h_mail, 0, sizeof(double) * 64);
-    }
+    // (the mailbox h_mail is part of a single-instance handle's pinned arena: tinympc_setup_batch)
     HIP_TRY(hipStreamSynchronize(s->stream));
     {
         std::lock_guard<std::mutex> tick(s->session_mu);
@@ -178,6 +175,16 @@ int tinympc_session_begin(tinympc_solver *s) {
     }
     session_registry(s, true);
     return TINYMPC_OK;
+}
+
+// The session is over without the kernel's orderly exit (restart failed, stream error, no answer): the handle goes back to ordinary
+// launches, whose device tables may lag behind the pinned references -- after shifts that only reached the resident kernel's LDS
+// tables, or a full re-read (`pending_flags` & 2) the kernel never consumed. Restage them at the next launch.
+static void mark_session_dead(tinympc_solver *s, int pending_flags) {
+    s->session_active = false;
+    s->session_on_f = false;
+    if ((pending_flags & 14) || s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;
+    s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
 }
 
 // One tick under the handle's session mutex. `*dead` is set when the session ended with an error: the caller then takes the
@@ -199,26 +206,29 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
         if (*done == want) break;
         __builtin_ia32_pause();
         if ((spin & 0xffff) == 0xffff) {
-            // Nothing for a while: has the kernel left (idle time-out)? Then start it again; it waits for exactly the
-            // command that is pending. A stream error or 30 s without an answer end the session with an error.
+            // Nothing for a while: has the kernel left (idle time-out, or parked by another handle's setup)? Then start it again; it
+            // waits for exactly the command that is pending. A stream error or 30 s without an answer end the session with an error.
             const hipError_t q = hipStreamQuery(s->stream);
             if (q == hipSuccess) {
-                // The new kernel stages the (current) pinned references in its prologue, so the command is issued again
-                // under a NEW stamp and without reference flags -- the old one, still in the mailbox, must not be taken.
+                // The command is issued again under a NEW stamp and without reference flags -- the old one, still in the mailbox,
+                // must not be taken. What it asked for is handed to the start of the new kernel instead: a full re-read the kernel
+                // that left never consumed (flags 2) is pending again -- layout C's prologue stages the pinned references, layout
+                // F's kernel has no staging, launch_session_kernel uploads them the ordinary way first -- and shifts (flags 4 / 8)
+                // count as "the device copies lag" (session_refs_shifted, set above).
+                if (flags & 2) s->refs_on_host = true;
                 rc = launch_session_kernel(s);  // waits for session_seq + 1
-                if (rc) { s->session_active = false; *dead = true; return rc; }
+                if (rc) { mark_session_dead(s, flags); *dead = true; return rc; }
+                flags = 0;
                 write_command(s, 0, x0);
                 want = (double)s->session_seq;
             } else if (q != hipErrorNotReady) {
-                s->session_active = false;
+                mark_session_dead(s, flags);
                 *dead = true;
                 return fail(TINYMPC_ERR_HIP, "session_step: the handle's stream reports %s", hipGetErrorString(q));
             }
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
                 write_command(s, 1, nullptr);  // stop (should the kernel still be there); the caller waits for the stream
-                s->session_active = false;
-                if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;
-                s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
+                mark_session_dead(s, flags);
                 *dead = true;
                 return fail(TINYMPC_ERR_HIP, "session_step: no answer from the resident kernel within 30 s");
             }

@@ -356,20 +356,32 @@ class TinyMPC:
         return ub[:, 0].copy()
 
     def bench_closed_loop(self, A, B, x0, ticks: int, skip: int = 0, session: bool = False, fdyn=None) -> dict:
-        """`ticks` closed-loop ticks driven from C (tinympc_bench_closed_loop): what a caller written in C pays per tick -- no
-        Python call inside a tick. With session=True the caller has opened the session. Returns the per-tick durations (us) of the
-        counted ticks, their mean / median, the iterations per tick and the final state."""
+        """`ticks` closed-loop ticks driven from C (libtinympc_bench.so: tinympc_bench_closed_loop, include/tinympc_hip_bench.h): what a
+        caller written in C pays per tick -- no Python call inside a tick. With session=True the caller has opened the session.
+        Returns the per-tick durations (us) of the counted ticks (`tick_us`), their mean / median / maximum, the iterations per tick
+        and the final state. A measurement helper, not part of the reference class's surface."""
         self._check_setup()
+        if not 0 <= int(skip) < int(ticks):
+            raise ValueError(f"bench_closed_loop: need 0 <= skip < ticks (got skip={skip}, ticks={ticks})")
         a, b = _f(A), _f(B)
         x = _f(np.asarray(x0, dtype=np.float64).reshape(-1, 1).copy())
         f = _f(np.asarray(fdyn, dtype=np.float64).reshape(-1, 1)) if fdyn is not None else None
         sec, its = C.c_double(0.0), C.c_long(0)
         per = np.zeros(ticks)
-        _lib.check(self._L.tinympc_bench_closed_loop(self._h, _p(a), _p(b), _p(f) if f is not None else None, _p(x), int(ticks), int(skip), int(bool(session)),
-                                                     C.byref(sec), C.byref(its), _p(per)))
-        n = max(ticks - skip, 1)
+        rc = _lib.load_bench_library().tinympc_bench_closed_loop(self._h, self.nx, self.nu, _p(a), _p(b), _p(f) if f is not None else None, _p(x), int(ticks),
+                                                                 int(skip), int(bool(session)), C.byref(sec), C.byref(its), _p(per))
+        _lib.check(rc)
+        n = ticks - skip
         return dict(us_per_tick=1e6 * sec.value / n, us_per_tick_median=float(np.median(per[skip:])), us_per_tick_max=float(np.max(per[skip:])),
-                    iterations_per_tick=its.value / n, x=x.ravel().copy())
+                    iterations_per_tick=its.value / n, x=x.ravel().copy(), tick_us=per[skip:].copy())
+
+    def debug_setup_timing(self) -> dict:
+        """Host microseconds of the phases of this handle's setup (tinympc_debug_setup_timing, include/tinympc_hip_bench.h)."""
+        self._check_setup()
+        out = np.zeros(10)
+        _lib.check(self._L.tinympc_debug_setup_timing(self._h, _p(out)))
+        return dict(zip(("prologue_us", "device_arena_us", "pinned_arena_us", "stage_and_queue_us", "queue_precompute_us", "wait_us", "total_us",
+                         "riccati_loop_clocks", "riccati_loop_us", "riccati_steps"), out))
 
     def session_end(self):
         self._check_setup()
