@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--worker-index", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-rocket", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-latency", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-ticks", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker-count", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-round5-legs", action="store_true", help="skip the setup and batched_tick legs")
     return ap.parse_args()
 
 
@@ -134,7 +137,7 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
     # trajectory re-sent every tick, tol 5e-2, max_iter 200, 100 ticks -- same loop as bench.py's `rocket_closed_loop` leg
     solver = O.OraclePort(prob).load_problem(prob, dict(abs_pri_tol=5e-2, abs_dua_tol=5e-2, max_iter=200, check_termination=1))
     x, goal = prob.x0.copy(), np.zeros(prob.nx)
-    tl, its = 0.0, 0
+    per, its = [], 0
     for k in range(110):
         x_ref = np.stack([prob.x0 + (goal - prob.x0) * min(i + k, 140) / 140 for i in range(prob.N)], axis=1)
         t1 = time.perf_counter()
@@ -143,10 +146,11 @@ def cpu_worker_rocket(seconds: float, iters: int) -> int:
         solver.solve()
         u0 = solver.solution()[1][:, 0]
         if k >= 10:
-            tl += time.perf_counter() - t1
+            per.append(1e6 * (time.perf_counter() - t1))
             its += solver.stats()["iter"]
         x = prob.A @ x + prob.B @ u0 + prob.fdyn
-    print(total, elapsed_iter, 1e6 * tl / 100, its / 100, flush=True)
+    from tools.bench_legs import stats_us
+    print(json.dumps({"iterations": total, "seconds": elapsed_iter, "closed_loop_tick_us": stats_us(per), "closed_loop_iterations_per_tick": its / 100}), flush=True)
     return 0
 
 
@@ -172,15 +176,10 @@ def cpu_worker_latency(seconds: float) -> int:
     while time.perf_counter() - t0 < seconds:
         n += s.bench_solves(cp.x0.reshape(-1, 1), 20)
     cart_us = 1e6 * (time.perf_counter() - t0) / n
-    prob = P.quadrotor(50)
-    s = O.OracleRef(prob).load_problem(prob, dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1))
-    runs = []
-    for _ in range(5):  # (each run starts from the state the last one left: warm, like the GPU leg's handle)
-        s.reset_workspace()
-        its, sec, _x = s.bench_closed_loop(prob.x0, 220, 20)
-        runs.append((sec, its))
-    sec, its = sorted(runs)[len(runs) // 2]
-    print(json.dumps({"cartpole_us_per_iter": cart_us, "closed_loop_us_per_tick": 1e6 * sec / 200, "closed_loop_iterations_per_tick": its / 200}), flush=True)
+    from tools.bench_legs import cpu_setup_and_ticks
+    out = cpu_setup_and_ticks()  # tiny_setup per system + the per-tick samples of the quadrotor closed loop
+    out["cartpole_us_per_iter"] = cart_us
+    print(json.dumps(out), flush=True)
     return 0
 
 
@@ -246,7 +245,7 @@ def usable_cpus():
     return cpus, quota, src
 
 
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def leg_counters(leg: str, iters_per_s: float) -> dict:
@@ -274,7 +273,7 @@ def leg_counters(leg: str, iters_per_s: float) -> dict:
     return {"measured": out}
 
 
-def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
+def cpu_baseline(iters: int, horizon: int, seconds: float, round5: bool = True) -> dict:
     """The reference's own compiled core (oracle/_ref; the C port where that binary is absent) on the host cores this
     process may use: one PROCESS per usable CPU (Eigen's per-operation malloc makes threads of one process contend), each
     pinned to its own CPU of the affinity mask, the count capped by the cgroup quota, each running seeded cold-started
@@ -329,23 +328,28 @@ def cpu_baseline(iters: int, horizon: int, seconds: float) -> dict:
     if eff is not None and len(rates) > 1.2 * eff:
         note = ("%d pinned workers delivered the throughput of %.1f undisturbed single processes: SMT siblings share a core's FP units "
                 "(%s physical cores) and %.0f s of work took %.1f s of wall clock" % (len(rates), eff, physical, seconds, wall))
-    rocket = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
-                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.split()
-    rocket_us = rocket_tick_us = rocket_tick_its = None
-    if len(rocket) >= 4 and int(rocket[-4]) > 0:
-        rocket_us = 1e6 * float(rocket[-3]) / int(rocket[-4])
-        rocket_tick_us, rocket_tick_its = float(rocket[-2]), float(rocket[-1])
+    rocket = {}
+    try:
+        rocket = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-rocket", "--cpu-seconds", "2", "--iters", str(iters)],
+                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        pass
+    rocket_us = 1e6 * rocket["seconds"] / rocket["iterations"] if rocket.get("iterations") else None
+    rocket_tick, rocket_tick_its = rocket.get("closed_loop_tick_us"), rocket.get("closed_loop_iterations_per_tick")
     lat = {}
     try:
         lat = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker-latency", "--cpu-seconds", "1"],
                                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=pin(cpus[0])).stdout.strip().splitlines()[-1])
     except (ValueError, IndexError):
         pass
+    from tools.bench_legs import cpu_batched_ticks
+    batched = cpu_batched_ticks(cpus, nworkers, os.path.abspath(__file__)) if round5 else {}
     return {"value": value, "rocket_us_per_iter_single_process": rocket_us,
-            "rocket_closed_loop_us_per_tick_single_process": rocket_tick_us, "rocket_closed_loop_iterations_per_tick": rocket_tick_its,
+            "rocket_closed_loop_tick_us_single_process": rocket_tick, "rocket_closed_loop_iterations_per_tick": rocket_tick_its,
             "cartpole_us_per_iter_single_process": lat.get("cartpole_us_per_iter"),
-            "closed_loop_us_per_tick_single_process": lat.get("closed_loop_us_per_tick"),
+            "closed_loop_tick_us_single_process": lat.get("closed_loop_tick_us"),
             "closed_loop_iterations_per_tick": lat.get("closed_loop_iterations_per_tick"),
+            "setup_us": lat.get("setup_us"), "batched_ticks": batched,
             "unit": "ADMM iters/s", "cores": len(rates),
             "effective_parallelism": eff, "affinity_cpus": len(cpus), "cgroup_quota": quota, "cgroup_quota_source": quota_src,
             "cores_logical": os.cpu_count(), "cores_physical": physical, "kind": kind,
@@ -365,6 +369,11 @@ def main() -> int:
         return cpu_worker_rocket(args.cpu_seconds, args.iters)
     if args.cpu_worker_latency:
         return cpu_worker_latency(args.cpu_seconds)
+    if args.cpu_worker_ticks:
+        sys.path.insert(0, ROOT)
+        from tools.bench_legs import cpu_ticks_worker, TICKS, TICK_SKIP
+        print(json.dumps(cpu_ticks_worker(args.worker_index, args.worker_count, TICKS, TICK_SKIP)), flush=True)
+        return 0
     rccl_environment()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
@@ -375,7 +384,7 @@ def main() -> int:
     # has initialised the GPU, so the host cores are not shared with the timed GPU region either.
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.iters, args.horizon, args.cpu_seconds)
+        cpu = cpu_baseline(args.iters, args.horizon, args.cpu_seconds, round5=not args.no_round5_legs)
 
     import numpy as np
     import torch
@@ -384,6 +393,7 @@ def main() -> int:
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
 
+    from tools.bench_legs import batched_tick_leg, setup_leg, stats_us
     pkg = ge.load_package()
     P = pkg.problems
     if not torch.cuda.is_available():
@@ -924,15 +934,26 @@ def main() -> int:
                 if mode == "session":
                     tk.session_end()
                 tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick_max": 1e6 * float(np.max(dts)),
-                              "iterations_per_tick": its / 200,
-                              "c_loop": {k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")}}
+                              "tick_us": stats_us(1e6 * np.asarray(dts)), "iterations_per_tick": its / 200,
+                              "c_loop": dict({k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")},
+                                             tick_us=stats_us(cl["tick_us"]))}
                 if slow:
                     tick[mode]["ticks_above_1ms"] = slow
                 tk.reset()
-            tick["cpu_reference_us_per_tick"] = cpu.get("closed_loop_us_per_tick_single_process") if cpu else None
+            # The SAME statistics on both sides (round 5): mean, median, p90, max of the 200 per-tick samples -- the GPU's from
+            # libtinympc_bench.so's C loop, the reference core's from oracle/ref_shim.cpp's (ref_bench_closed_loop_samples)
+            cref = (cpu or {}).get("closed_loop_tick_us_single_process") or {}
+            tick["cpu_reference_tick_us"] = cref or None
+            tick["cpu_reference_us_per_tick"] = cref.get("mean")
+            tick["cpu_reference_us_per_tick_median"] = cref.get("median")
             tick["cpu_reference_iterations_per_tick"] = cpu.get("closed_loop_iterations_per_tick") if cpu else None
             tick["cpu_reference_note"] = ("the reference's own core (oracle/_ref) on one host core: set_x0 + solve + first control per tick, the loop in "
-                                          "compiled code; no MATLAB / MEX overhead on its side, the Python mirror's ctypes calls on the GPU's side")
+                                          "compiled code; no MATLAB / MEX overhead on its side. Like against like: c_loop.tick_us.{mean,median} against "
+                                          "cpu_reference_tick_us.{mean,median} (both loops in C); the Python-mirror numbers carry ctypes calls the host side does not")
+            if cref:
+                for mode in ("launch", "session"):
+                    g_ = tick[mode]["c_loop"]["tick_us"]
+                    tick[mode]["c_loop"]["gpu_over_cpu_time"] = {"mean": g_["mean"] / cref["mean"], "median": g_["median"] / cref["median"]}
             # ... and BASELINE config 4's own closed loop (rocket_landing_constraints.m:86-121): N = 100, cones + linear row + fdyn, the
             # reference trajectory re-sent every tick (a receding horizon: inside a session only its new last column travels)
             rk = P.rocket(100)
@@ -964,13 +985,25 @@ def main() -> int:
                     x = rk.A @ x + rk.B @ u0 + rk.fdyn
                 if mode == "session":
                     tk.session_end()
-                rtick[mode] = {"us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick": 1e6 * float(np.mean(dts)), "iterations_per_tick": its / 100, "layout": layout}
+                rtick[mode] = {"us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick": 1e6 * float(np.mean(dts)), "tick_us": stats_us(1e6 * np.asarray(dts)),
+                               "iterations_per_tick": its / 100, "layout": layout}
                 tk.reset()
-            rtick["cpu_port_us_per_tick"] = cpu.get("rocket_closed_loop_us_per_tick_single_process") if cpu else None
+            # (like against like, round 5: both sides time set_x_ref + tick per tick through Python calls of their C libraries and quote the
+            # same statistics of the same 100 ticks; the early ticks are long -- 38 iterations on average -- so mean and median differ 2x)
+            rref = (cpu or {}).get("rocket_closed_loop_tick_us_single_process") or {}
+            rtick["cpu_port_tick_us"] = rref or None
+            rtick["cpu_port_us_per_tick"] = rref.get("mean")
+            rtick["cpu_port_us_per_tick_median"] = rref.get("median")
             rtick["cpu_port_iterations_per_tick"] = cpu.get("rocket_closed_loop_iterations_per_tick") if cpu else None
+            if rref:
+                for mode in ("launch", "session"):
+                    rtick[mode]["cpu_over_gpu_time"] = {"mean": rref["mean"] / rtick[mode]["tick_us"]["mean"], "median": rref["median"] / rtick[mode]["tick_us"]["median"]}
             out["rocket_closed_loop"] = dict(workload="rocket landing N=100, cones + linear row + fdyn, one instance, warm start, tol 5e-2, the reference trajectory "
                                                       "re-sent every tick, 100 ticks (set_x_ref + tick, through the Python mirror)", **rtick)
             out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
+        if world == 1 and not args.no_round5_legs:
+            out["setup"] = setup_leg(pkg, cpu)
+            out["batched_tick"] = batched_tick_leg(pkg, cpu, dev_index)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
@@ -997,12 +1030,20 @@ def main() -> int:
                 "very_large_system_fp64_frac": leg("very_large_system/fp64_frac"),
                 "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),
                 "cartpole_batch_8192_iters_per_s": leg("cartpole/batch_8192/iters_per_s"), "cartpole_batch_8192_fp64_frac": leg("cartpole/batch_8192/fp64_frac"),
-                "closed_loop_tick_launch_us": leg("closed_loop_tick/launch/us_per_tick_median"), "closed_loop_tick_session_us": leg("closed_loop_tick/session/us_per_tick_median"),
-                "closed_loop_tick_launch_c_loop_us": leg("closed_loop_tick/launch/c_loop/us_per_tick_median"),
-                "closed_loop_tick_session_c_loop_us": leg("closed_loop_tick/session/c_loop/us_per_tick_median"),
-                "closed_loop_tick_cpu_reference_us": leg("cpu_baseline/closed_loop_us_per_tick_single_process"),
-                "rocket_closed_loop_launch_us": leg("rocket_closed_loop/launch/us_per_tick_median"), "rocket_closed_loop_session_us": leg("rocket_closed_loop/session/us_per_tick_median"),
-                "rocket_closed_loop_cpu_port_us": leg("cpu_baseline/rocket_closed_loop_us_per_tick_single_process")}
+                # latency comparisons: the SAME statistic on both sides, mean and median each (round 5)
+                "closed_loop_tick_launch_c_loop_us_mean": leg("closed_loop_tick/launch/c_loop/tick_us/mean"), "closed_loop_tick_launch_c_loop_us_median": leg("closed_loop_tick/launch/c_loop/tick_us/median"),
+                "closed_loop_tick_session_c_loop_us_mean": leg("closed_loop_tick/session/c_loop/tick_us/mean"), "closed_loop_tick_session_c_loop_us_median": leg("closed_loop_tick/session/c_loop/tick_us/median"),
+                "closed_loop_tick_cpu_reference_us_mean": leg("closed_loop_tick/cpu_reference_tick_us/mean"), "closed_loop_tick_cpu_reference_us_median": leg("closed_loop_tick/cpu_reference_tick_us/median"),
+                "closed_loop_tick_session_python_us_mean": leg("closed_loop_tick/session/tick_us/mean"), "closed_loop_tick_session_python_us_median": leg("closed_loop_tick/session/tick_us/median"),
+                "rocket_closed_loop_launch_us_mean": leg("rocket_closed_loop/launch/tick_us/mean"), "rocket_closed_loop_launch_us_median": leg("rocket_closed_loop/launch/tick_us/median"),
+                "rocket_closed_loop_session_us_mean": leg("rocket_closed_loop/session/tick_us/mean"), "rocket_closed_loop_session_us_median": leg("rocket_closed_loop/session/tick_us/median"),
+                "rocket_closed_loop_cpu_port_us_mean": leg("rocket_closed_loop/cpu_port_tick_us/mean"), "rocket_closed_loop_cpu_port_us_median": leg("rocket_closed_loop/cpu_port_tick_us/median"),
+                "setup_quadrotor_gpu_ms": leg("setup/quadrotor/gpu_ms"), "setup_quadrotor_cpu_reference_ms": leg("setup/quadrotor/cpu_reference_ms"),
+                "setup_cartpole_gpu_ms": leg("setup/cartpole/gpu_ms"), "setup_cartpole_cpu_reference_ms": leg("setup/cartpole/cpu_reference_ms"),
+                "setup_rocket_gpu_ms": leg("setup/rocket/gpu_ms"), "setup_quadrotor_riccati_loop_us": leg("setup/quadrotor/k_precompute_riccati_loop_us"),
+                "batched_tick_smallest_batch_where_gpu_wins": leg("batched_tick/smallest_batch_where_gpu_wins"),
+                **{"batched_tick_B%d_%s" % (b_, k_): leg("batched_tick/%d/%s" % (b_, p_)) for b_ in (1, 16, 256, 4096, 8192)
+                   for k_, p_ in (("host_us_mean", "host_exchange_us/mean"), ("resident_us_mean", "device_resident_us/mean"), ("cpu_us_mean", "cpu_reference_us_per_tick_mean"))}}
         legs = {k: v for k, v in legs.items() if v is not None}
         for k, v in legs.items():
             if k != "value_as_asked":

@@ -430,6 +430,19 @@ class OracleRef(_Base):
         return its, float(sec.value), a.ravel(), per[int(skip):].copy()
 
     @staticmethod
+    def bench_ticks_many(solvers, x0s, ticks: int, skip: int = 0):
+        """`ticks` closed-loop ticks of len(solvers) independent instances on one thread (ref_bench_ticks_many): returns
+        (iterations of the counted ticks, per-tick microseconds for all instances together [ticks], final states)."""
+        L = solvers[0].L
+        L.ref_bench_ticks_many.argtypes = [C.POINTER(C.c_void_p), C.c_int, _dp, C.c_int, C.c_int, _dp]
+        L.ref_bench_ticks_many.restype = C.c_long
+        hs = (C.c_void_p * len(solvers))(*[s.h for s in solvers])
+        x = _f(np.asarray(x0s, dtype=np.float64).copy())
+        per = np.zeros(int(ticks))
+        its = int(L.ref_bench_ticks_many(hs, len(solvers), _p(x), int(ticks), int(skip), _p(per)))
+        return its, per, x
+
+    @staticmethod
     def bench_setup(prob, reps: int = 20):
         """The reference's tiny_setup (tiny_api.cpp:21-122, precompute included) `reps` times on one thread: per-call microseconds."""
         L = C.CDLL(REF_LIB)

@@ -15,6 +15,7 @@
 //
 // The output (oracle/_ref/libtinympc_ref.so) is git-ignored and travels to the GPU box as a
 // prebuilt binary only.
+#include <vector>
 #include <cstring>
 #include <ctime>
 #include <iostream>
@@ -315,6 +316,39 @@ long ref_bench_closed_loop_samples(void *h, double *x0, int ticks, int skip, dou
 
 long ref_bench_closed_loop(void *h, double *x0, int ticks, int skip, double *seconds) {
     return ref_bench_closed_loop_samples(h, x0, ticks, skip, seconds, nullptr);
+}
+
+// CPU-baseline helper for bench.py's `batched_tick` leg: `count` independent solvers (one per MPC instance: the reference keeps one
+// instance's warm-start state per TinySolver) advanced tick by tick on ONE thread -- for every tick, for every instance: set_x0 ->
+// solve -> first control -> plant step x+ = A x + B u0. x0s is nx x count (column = instance), overwritten with the final states;
+// tick_us[k] receives the microseconds tick k took for ALL `count` instances (plant steps excluded, as on the GPU side); the first
+// `skip` ticks are not counted in the returned iteration total.
+long ref_bench_ticks_many(void **hs, int count, double *x0s, int ticks, int skip, double *tick_us) {
+    CoutSilencer quiet(true);
+    if (count < 1) return 0;
+    const int nx = static_cast<TinySolver *>(hs[0])->work->nx;
+    long iters = 0;
+    std::vector<tinyVector> xs(count), us(count);
+    for (int b = 0; b < count; ++b) xs[b] = Eigen::Map<const Eigen::VectorXd>(x0s + (size_t)b * nx, nx);
+    for (int k = 0; k < ticks; ++k) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int b = 0; b < count; ++b) {
+            TinySolver *s = static_cast<TinySolver *>(hs[b]);
+            tiny_set_x0(s, xs[b]);
+            tiny_solve(s);
+            us[b] = s->solution->u.col(0);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (tick_us) tick_us[k] = 1e6 * (double)(t1.tv_sec - t0.tv_sec) + 1e-3 * (double)(t1.tv_nsec - t0.tv_nsec);
+        for (int b = 0; b < count; ++b) {
+            TinySolver *s = static_cast<TinySolver *>(hs[b]);
+            if (k >= skip) iters += s->work->iter;
+            xs[b] = s->work->Adyn * xs[b] + s->work->Bdyn * us[b];
+        }
+    }
+    for (int b = 0; b < count; ++b) Eigen::Map<Eigen::VectorXd>(x0s + (size_t)b * nx, nx) = xs[b];
+    return iters;
 }
 
 // CPU-baseline helper for bench.py's `setup` leg: tiny_setup (tiny_api.cpp:21-122, precompute included) + the teardown the MEX's
