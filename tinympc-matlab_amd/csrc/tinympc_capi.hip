@@ -203,9 +203,9 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     pin.add(&s->h_stage, upload_bytes / sizeof(double));
     if (batch == 1) {
         pin.add(&s->h_sol, X + U + 8); pin.add(&s->h_x0, nx); pin.add(&s->h_u0, nu);
-        pin.add(&s->h_xref, X); pin.add(&s->h_uref, U ? U : 1); pin.add(&s->h_mail, 64);
+        pin.add(&s->h_xref, X); pin.add(&s->h_uref, U ? U : 1); pin.add(&s->h_mail, 64); pin.add(&s->h_ans, 32);
     }
-    TRY(acquire_arenas(s, dev.mark(), pin.mark()));
+    TRY(acquire_arenas(s, dev.mark(), pin.mark(), batch == 1));
     dev.bind(s->arena_dev);
     s->setup_us[1] = us_since(t_phase); t_phase = clk::now();
     pin.bind(s->arena_pin);
@@ -220,6 +220,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     std::memcpy(uQ, Q, sizeof(double) * nx * nx); std::memcpy(uR, R, sizeof(double) * nu * nu);
     HIP_TRY_S(hipMemcpyAsync(s->dA, s->h_stage, upload_bytes, hipMemcpyHostToDevice, s->stream));
     HIP_TRY_S(hipMemsetAsync(static_cast<char *>(s->arena_dev) + zero_begin, 0, zero_end - zero_begin, s->stream));
+    if (s->d_mail) HIP_TRY_S(hipMemsetAsync(s->d_mail, 0, sizeof(double) * 64, s->stream));
     HIP_TRY_S(launch_fill_bounds(s->dxmin, s->dxmax, X, s->dumin, s->dumax, U, kBoundInf, s->stream));  // TinyMPC.m:261-264
     HIP_TRY_S(launch_reset_stats(s->distats, s->ddstats, s->drho_inst, batch, rho, s->stream));
     s->setup_us[3] = us_since(t_phase); t_phase = clk::now();
@@ -514,6 +515,17 @@ int tinympc_debug_setup_timing(tinympc_solver *s, double *out10) {
 int tinympc_debug_tick_timing(tinympc_solver *s, double *out4) {
     int rc = check_handle(s);
     if (rc) return rc;
+    if (s->session_active && s->session_on_f && s->h_sol) {
+        // layout F's resident kernel leaves its own split of the last tick in the spare slot behind the completion stamp: us it waited
+        // for the command since its previous answer, us of ADMM iterations, us of write-out (16 bits each, ticks of 10 ns)
+        if (s->host_sol_state == 3 && (rc = wait_session_solution(s))) return rc;
+        const unsigned long long packed = (unsigned long long)s->h_sol[s->X() + s->U() + 7];
+        out4[0] = 0.01 * (double)(packed & 0xffffull);
+        out4[1] = 0.01 * (double)((packed >> 16) & 0xffffull);
+        out4[2] = 0.01 * (double)((packed >> 32) & 0xffffull);
+        out4[3] = 0.0;
+        return TINYMPC_OK;
+    }
     for (int i = 0; i < 4; ++i) out4[i] = s->dbg_tick[i];
     return TINYMPC_OK;
 }
@@ -525,6 +537,7 @@ int tinympc_get_solution_batch(tinympc_solver *s, double *x_out, double *u_out, 
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
     if (s->host_path() && count == 1 && s->host_sol_state != 0) {
         if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
+        if (s->host_sol_state == 3 && (rc = wait_session_solution(s))) return rc;
         if (x_out) std::memcpy(x_out, s->h_sol, sizeof(double) * s->X());
         if (u_out) std::memcpy(u_out, s->h_sol + s->X(), sizeof(double) * s->U());
         return TINYMPC_OK;
@@ -563,6 +576,7 @@ int tinympc_get_stats_batch(tinympc_solver *s, int *iters, int *status, double *
         return fail(TINYMPC_ERR_INVALID_INPUT, "instance range [%d, %d) outside batch of %d", first, first + count, s->batch);
     if (s->host_path() && count == 1 && s->host_sol_state != 0) {
         if (s->host_sol_state == 1 && (rc = tinympc_synchronize(s))) return rc;
+        if (s->host_sol_state == 3 && (rc = wait_session_solution(s))) return rc;
         const double *hs = s->h_sol + s->X() + s->U();
         if (iters) iters[0] = (int)hs[4];
         if (status) status[0] = (int)hs[5];

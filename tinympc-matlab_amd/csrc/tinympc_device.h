@@ -35,6 +35,14 @@ constexpr int V_PAD = 4;
 __host__ __device__ inline size_t v_rows(int N) { return (size_t)N + 1 + 2 * V_PAD; }
 __host__ __device__ inline size_t tables_doubles(int W, int N) { return 3 * table_rows(N) * W + W; }
 
+// A store into pinned host memory that must be visible to the HOST while the kernel is still running (the solution / statistics behind
+// a completion stamp, SolveParams::host_sol): system scope, i.e. written through the device's caches at once. A plain store may stay
+// dirty in the L2 until something writes the whole L2 back -- the system-scope release fence the stamp used to carry (round 2-4), which
+// also cost every tick the L2's other dirty lines and, as an acquire, its cached operators and tables.
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+__device__ __forceinline__ void host_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
+
 struct PrecomputeParams {
     int nx, nu;
     double rho;
@@ -152,6 +160,12 @@ struct SolveParams {
     // payload): a line is complete when its stamp fits the expected sequence number AND the payload read with it.
     // NULL = an ordinary one-shot launch.
     const double *mail;
+    // The session's EARLY answer (round 5, layout F's resident kernel): the tick's first controls travel ahead of everything else, in
+    // 64-byte lines [7 controls | mail_stamp(sequence number, controls)] written by ONE store instruction each -- the host takes them as
+    // soon as a line's stamp fits its payload (no fence in front of it, no wait for the solution's write-out: 1.2 us of a 7 us
+    // quadrotor tick). Solution, statistics and the completion stamp behind host_sol follow; host readers of those wait for that
+    // stamp. NULL: the completion stamp is the answer (layout C's resident kernel, one-shot launches).
+    double *host_ans;
     double session_expect;             // stamp of the first command to wait for
     unsigned long long session_idle;   // exit after this many 100 MHz ticks without a command (the exit every wave reaches)
     // Single-instance handles, references left in pinned host memory by set_x_ref / set_u_ref (the closed-loop tick

@@ -151,7 +151,10 @@ struct tinympc_solver {
     double *h_sol = nullptr;           // [X | U | 4 residuals | iter, status | completion flag]
     // Closed-loop session (tinympc_session_begin / _step / _end): the latency kernel stays resident and takes its ticks
     // from this mailbox in pinned memory (layout: SolveParams::mail).
-    double *h_mail = nullptr;          // [64]
+    double *h_mail = nullptr;          // [64] in pinned host memory (the kernel polls across PCIe) ...
+    double *h_ans = nullptr;           // [32] pinned: the early answer lines of layout F's resident kernel (SolveParams::host_ans)
+    double *d_mail = nullptr;          // ... or, where the host can store into device memory (large BAR), in fine-grained device memory
+    double *mailbox() const { return d_mail ? d_mail : h_mail; }  // what the session uses (tinympc_handle.hip: acquire_arenas)
     bool session_active = false;
     bool session_on_f = false;  // ... and its resident kernel is layout F's (families beyond what the latency kernel's session holds)
     // Taken by everything that writes the mailbox or (re)starts the resident kernel: session_step (for the whole tick), end_session
@@ -173,7 +176,8 @@ struct tinympc_solver {
     double *h_xref = nullptr, *h_uref = nullptr;
     bool refs_on_host = false;         // the pinned references are newer than dXref / dUref and the tables
     bool x0_on_host = false;           // h_x0 is newer than dx0
-    int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid
+    int host_sol_state = 0;            // 0: not valid, 1: a launch that writes it is in flight, 2: valid, 3: a session tick has answered with
+                                       //    its first controls; solution + statistics are valid once the stamp behind them reads session_seq
     bool host_path() const { return batch == 1 && h_sol != nullptr && !layout_d && !layout_m; }  // (layout D writes to device memory only)
     bool state_in_global = false;             // horizon too long for LDS: layout-A kernels work on dscratch
     double *dscratch_state = nullptr;
@@ -246,7 +250,7 @@ int dalloc(tinympc_solver *s, T **p, size_t count) {
 }
 
 // ---- tinympc_handle.hip
-int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes);  // -> s->arena_dev / arena_pin (from the device's pool when one fits)
+int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes, bool want_mailbox);  // -> s->arena_dev / arena_pin (from the device's pool when one fits)
 int acquire_stream_kit(tinympc_solver *s);  // stream + event pair from the device's pool (created when the pool is empty)
 int bind_device(tinympc_solver *s);   // every verb that touches the device passes through here first (ends an open session)
 bool rows_constant(const double *m, int rows, int cols);
@@ -279,6 +283,7 @@ int launch(tinympc_solver *s, bool timed);
 
 // ---- tinympc_session.hip
 int end_session(tinympc_solver *s);
+int wait_session_solution(tinympc_solver *s);  // host_sol_state 3 -> 2: spins on the completion stamp of the last session tick
 // Resident session kernels of OTHER handles on `device` are sent home before anything that synchronises the device (hipMalloc /
 // hipFree in setup and teardown): such a call would otherwise stall until the spinning kernel's idle time-out (2 s). Their
 // sessions stay open: the next session_step finds the kernel gone and starts it again (its restart path).

@@ -2,6 +2,7 @@
 // operators / per-knot tables, the per-lane description of the cone / linear families. No solver arithmetic happens here.
 #include "tinympc_handle.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstring>
 #include <limits>
@@ -41,24 +42,49 @@ constexpr size_t kKitsKept = 16;    // per device; beyond that a returned stream
 // (three times the reference's whole tiny_setup), and a MEX user's `setup` destroys the previous solver first (bindings.cpp:92).
 // Arenas of up to kArenaKeepBytes go back to a per-device pool when their handle is destroyed and serve the next setup that fits.
 namespace {
-struct ArenaKit { void *dev; size_t dev_bytes; void *pin; size_t pin_bytes; };
+struct ArenaKit { void *dev; size_t dev_bytes; void *pin; size_t pin_bytes; void *mail; };
 std::vector<ArenaKit> g_arenas[64];             // [device]; under g_kits_mu
 constexpr size_t kArenaKeepBytes = 4u << 20;    // device bytes of an arena worth keeping (a quadrotor N=50 instance: 0.1 MB)
 constexpr size_t kArenasKept = 8;
 }  // namespace
 
-int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes) {
+// Can the host store into device memory (the whole of it mapped through the PCIe BAR)? Asked once per device.
+static bool device_is_large_bar(int device) {
+    static std::atomic<int> cache[64];  // 0: not asked, 1: no, 2: yes
+    if (device < 0 || device >= 64) return false;
+    int v = cache[device].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int flag = 0;
+        v = (hipDeviceGetAttribute(&flag, hipDeviceAttributeIsLargeBar, device) == hipSuccess && flag) ? 2 : 1;
+        cache[device].store(v, std::memory_order_relaxed);
+    }
+    return v == 2;
+}
+
+int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes, bool want_mailbox) {
     if (s->device >= 0 && s->device < 64) {
         std::lock_guard<std::mutex> lock(g_kits_mu);
         auto &pool = g_arenas[s->device];
         for (size_t i = 0; i < pool.size(); ++i) {
-            if (pool[i].dev_bytes >= dev_bytes && pool[i].pin_bytes >= pin_bytes) {
+            if (pool[i].dev_bytes >= dev_bytes && pool[i].pin_bytes >= pin_bytes && (pool[i].mail != nullptr || !want_mailbox)) {
                 s->arena_dev = pool[i].dev; s->arena_dev_bytes = pool[i].dev_bytes;
                 s->arena_pin = pool[i].pin; s->arena_pin_bytes = pool[i].pin_bytes;
+                s->d_mail = static_cast<double *>(pool[i].mail);
                 pool.erase(pool.begin() + (long)i);
                 return TINYMPC_OK;
             }
         }
+    }
+    // The session's mailbox on the DEVICE side of the bus (round 5): a line of fine-grained device memory the host stores into through
+    // the BAR (posted writes) and the resident kernel polls in its own HBM -- a poll is 0.2 us instead of a 1.2 us PCIe read
+    // (tools/mailbox_probe.hip, profiles/r05_mailbox_probe.txt). Where the device's memory is not mapped into the host's address space,
+    // or the allocation is refused, the mailbox stays in pinned host memory (h_mail). TINYMPC_MAILBOX=host forces that (A/B runs).
+    s->d_mail = nullptr;
+    const char *env = getenv("TINYMPC_MAILBOX");
+    if (want_mailbox && device_is_large_bar(s->device) && !(env && (env[0] == 'h' || env[0] == 'H'))) {
+        void *m = nullptr;
+        if (hipExtMallocWithFlags(&m, 4096, hipDeviceMallocFinegrained) == hipSuccess) s->d_mail = static_cast<double *>(m);
+        else (void)hipGetLastError();
     }
     hipError_t e = hipMalloc(&s->arena_dev, dev_bytes);
     if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", dev_bytes, hipGetErrorString(e));
@@ -74,14 +100,17 @@ static void release_arenas(tinympc_solver *s) {
         std::lock_guard<std::mutex> lock(g_kits_mu);
         auto &pool = g_arenas[s->device];
         if (pool.size() < kArenasKept) {
-            pool.push_back({s->arena_dev, s->arena_dev_bytes, s->arena_pin, s->arena_pin_bytes});
+            pool.push_back({s->arena_dev, s->arena_dev_bytes, s->arena_pin, s->arena_pin_bytes, s->d_mail});
             s->arena_dev = s->arena_pin = nullptr;
+            s->d_mail = nullptr;
             return;
         }
     }
     if (s->arena_dev) (void)hipFree(s->arena_dev);
     if (s->arena_pin) (void)hipHostFree(s->arena_pin);
+    if (s->d_mail) (void)hipFree(s->d_mail);
     s->arena_dev = s->arena_pin = nullptr;
+    s->d_mail = nullptr;
 }
 
 int acquire_stream_kit(tinympc_solver *s) {

@@ -9,6 +9,7 @@
 #include <vector>
 #include <chrono>
 #include <cstring>
+#include <immintrin.h>
 
 using namespace tinympc;
 using namespace tinympc::host;
@@ -29,7 +30,7 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
     for (int i = 0; i < s->nx; ++i) pay[npay++] = x0 ? x0[i] : 0.0;
     if (flags & 4) for (int i = 0; i < s->nx; ++i) pay[npay++] = s->h_xref[(size_t)(s->N - 1) * s->nx + i];
     if (flags & 8) for (int i = 0; i < s->nu; ++i) pay[npay++] = s->h_uref[(size_t)(s->N - 2) * s->nu + i];
-    volatile double *m = s->h_mail;
+    volatile double *m = s->mailbox();  // (device memory through the BAR: stores only -- the host never reads the mailbox)
     const double seq = (double)(++s->session_seq);
     const int nlines = (npay + 6) / 7;
     for (int q = npay; q < 7 * nlines; ++q) pay[q] = 0.0;  // (every word of a used line is written: the stamp covers all seven)
@@ -45,6 +46,7 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
         m[8 * l + 7] = tinympc::mail_stamp(seq, x);  // (sequence number + checksum of the line's payload, see tinympc_device.h)
     }
     std::atomic_thread_fence(std::memory_order_seq_cst);
+    _mm_sfence();  // (a mailbox behind the BAR is write-combining memory: push the lines out now, not when the buffer is evicted)
 }
 
 int launch_session_kernel(tinympc_solver *s) {
@@ -77,7 +79,8 @@ int launch_session_kernel(tinympc_solver *s) {
     s->xref_shift = s->uref_shift = false;
     p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
     p.families = fam ? 1 : 0;
-    p.mail = s->h_mail;
+    p.mail = s->mailbox();
+    p.host_ans = s->session_on_f ? s->h_ans : nullptr;  // (layout F's resident kernel answers early, see SolveParams::host_ans)
     p.session_expect = (double)(s->session_seq + 1);
     p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
     if (s->session_on_f) {
@@ -115,7 +118,23 @@ void tinympc::host::park_sessions_on_device(int device, const tinympc_solver *ex
         if (!o->session_active) continue;
         write_command(o, 1, nullptr);                 // stop: the kernel writes its state back and leaves
         (void)hipStreamSynchronize(o->stream);        // (session_active stays set: session_step restarts the kernel)
+        if (o->host_sol_state == 3) o->host_sol_state = 2;  // (the kernel has left: its last tick's write-out is complete)
     }
+}
+
+int tinympc::host::wait_session_solution(tinympc_solver *s) {
+    if (s->host_sol_state != 3) return TINYMPC_OK;
+    const volatile double *done = s->h_sol + s->X() + s->U() + 6;
+    const double want = (double)s->session_seq;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long spin = 0; *done != want; ++spin) {
+        __builtin_ia32_pause();
+        if ((spin & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(5))
+            return fail(TINYMPC_ERR_HIP, "the resident kernel has not completed the write-out of its last tick within 5 s");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->host_sol_state = 2;
+    return TINYMPC_OK;
 }
 
 int tinympc::host::end_session(tinympc_solver *s) {
@@ -129,6 +148,7 @@ int tinympc::host::end_session(tinympc_solver *s) {
     if (s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;  // device copies / tables lag: restage
     s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->host_sol_state == 3) s->host_sol_state = 2;  // (the kernel has left: its last tick's write-out is complete)
     return TINYMPC_OK;
 }
 
@@ -182,6 +202,7 @@ int tinympc_session_begin(tinympc_solver *s) {
 // tables, or a full re-read (`pending_flags` & 2) the kernel never consumed. Restage them at the next launch.
 static void mark_session_dead(tinympc_solver *s, int pending_flags) {
     s->session_active = false;
+    if (s->host_sol_state == 3) s->host_sol_state = 0;  // (whatever the kernel completed is in the device copies)
     s->session_on_f = false;
     if ((pending_flags & 14) || s->session_refs_shifted || s->xref_shift || s->uref_shift) s->refs_on_host = true;
     s->session_refs_shifted = s->xref_shift = s->uref_shift = false;
@@ -201,9 +222,31 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
     write_command(s, flags, x0);
     const volatile double *done = s->h_sol + s->X() + s->U() + 6;
     double want = (double)s->session_seq;
+    // The answer: layout F's resident kernel sends the first controls ahead, in lines [7 controls | mail_stamp(seq, controls)] that are
+    // complete when the stamp fits the payload read with it (SolveParams::host_ans); layout C's raises the completion stamp behind the
+    // solution, which is then all there.
+    const bool early = s->session_on_f;
+    const int nlines = (s->nu + 6) / 7;
+    double u0_lines[24];
+    auto answered = [&]() -> bool {
+        if (!early) return *done == want;
+        const volatile double *a = s->h_ans;
+        for (int l = 0; l < nlines; ++l) {
+            unsigned long long x = 0ull;
+            for (int q = 0; q < 7; ++q) {
+                const double v = a[8 * l + q];
+                u0_lines[7 * l + q] = v;
+                unsigned long long bits;
+                std::memcpy(&bits, &v, sizeof bits);
+                x ^= bits;
+            }
+            if (a[8 * l + 7] != tinympc::mail_stamp(want, x)) return false;
+        }
+        return true;
+    };
     const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
-        if (*done == want) break;
+        if (answered()) break;
         __builtin_ia32_pause();
         if ((spin & 0xffff) == 0xffff) {
             // Nothing for a while: has the kernel left (idle time-out, or parked by another handle's setup)? Then start it again; it
@@ -235,8 +278,13 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    s->host_sol_state = 2;
-    std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
+    if (early) {
+        s->host_sol_state = 3;  // (solution + statistics: valid once the stamp behind them reads session_seq -- wait_session_solution)
+        std::memcpy(u0_out, u0_lines, sizeof(double) * s->nu);
+    } else {
+        s->host_sol_state = 2;
+        std::memcpy(u0_out, s->h_sol + s->X(), sizeof(double) * s->nu);
+    }
     return TINYMPC_OK;
 }
 

@@ -775,17 +775,17 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                     p.sol_x[((size_t)inst * N + kn) * nx + r] = v[i];
                 } else {
                     p.sol_u[((size_t)inst * (N - 1) + kn) * nu + (r - nx)] = v[i];
-                    if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * nu + (r - nx)] = v[i];  // first controls straight to the host
+                    if (kn == 0 && p.u0_host) host_store(&p.u0_host[(size_t)inst * nu + (r - nx)], v[i]);  // first controls straight to the host
                 }
                 if (p.host_sol) {  // single-instance handle: the solution also goes straight into pinned host memory
-                    if (is_x) p.host_sol[(size_t)kn * nx + r] = v[i];
-                    else p.host_sol[(size_t)N * nx + (size_t)kn * nu + (r - nx)] = v[i];
+                    if (is_x) host_store(&p.host_sol[(size_t)kn * nx + r], v[i]);
+                    else host_store(&p.host_sol[(size_t)N * nx + (size_t)kn * nu + (r - nx)], v[i]);
                 }
             }
         }
         if (k0) {
             p.sol_x[(size_t)inst * N * nx + r] = v0;
-            if (p.host_sol) p.host_sol[r] = v0;
+            if (p.host_sol) host_store(&p.host_sol[r], v0);
         }
         if constexpr (!SESSION) write_state(converged);
     }
@@ -794,9 +794,9 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         p.istats[inst * 2 + 1] = status;
         if (p.host_sol) {
             double *hs = p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu;
-            hs[4] = (double)it_done;
-            hs[5] = (double)status;
-            if (res_valid) { hs[0] = res_px; hs[1] = res_dx; hs[2] = res_pu; hs[3] = res_du; }
+            host_store(&hs[4], (double)it_done);
+            host_store(&hs[5], (double)status);
+            if (res_valid) { host_store(&hs[0], res_px); host_store(&hs[1], res_dx); host_store(&hs[2], res_pu); host_store(&hs[3], res_du); }
         }
         if (res_valid) {
             p.dstats[inst * 4 + 0] = res_px;
@@ -807,13 +807,16 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
     }
 
     if (p.host_sol && (session || p.host_seq != 0.0)) {  // (uniform) everything above is in pinned memory: raise the flag
-        __threadfence_system();
+        // Everything the host reads after the stamp was stored with host_store() (system scope: written through, nothing of it stays dirty in
+        // the L2): once every thread's stores have been handed over (s_waitcnt vmcnt(0) -- a workgroup-scope release) the stamp may follow
+        // them. Rounds 2-4 had plain stores and a system-scope fence here (__threadfence_system + a release store), which wrote back the
+        // L2's dirty lines -- the solution just stored to HBM included -- and INVALIDATED the caches, twice per tick: the next tick then
+        // fetched its operators and tables from HBM again.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        // (a system-scope atomic store: a plain store may sit in the L2 until the kernel ends -- which a resident session
-        // kernel does not do)
+        // (a system-scope atomic store: written through at once -- a plain store might be combined or delayed)
         if (tid == 0)
-            __hip_atomic_store(p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu + 6, session ? expect : p.host_seq, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.host_sol + (size_t)N * nx + (size_t)(N - 1) * nu + 6, session ? expect : p.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if constexpr (!SESSION) break;
     // The next tick warm-starts from the registers. A converged solve returns before v <- vnew (admm.cpp:181-197): its

@@ -392,6 +392,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
     const int max_iter = p.max_iter;
     const int tid = (int)threadIdx.x;
     double expect = p.session_expect;
+    unsigned long long t_prev_out = 0ull, t_seen = 0ull;  // (SESSION diagnostics: 100 MHz stamps, see the completion stamp below)
     for (;;) {  // ---- SESSION: every pass is one closed-loop tick (one pass otherwise)
     if constexpr (SESSION) {
         // Poll the mailbox (layout: SolveParams::mail; protocol and checksum as in tinympc_solve_c.hip): lanes 0..55 fetch its lines
@@ -416,6 +417,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             quit = !go && sMail[56] != 0.0;
             __syncthreads();  // (the next poll overwrites sMail)
         }
+        t_seen = __builtin_amdgcn_s_memrealtime();
         const int flags = go ? (int)sMail[0] : 1;
         if (quit || (flags & 1)) {  // stop requested, or nobody is talking to this kernel any more
             write_state(false);     // (a converged tick already rolled its slack back, see the end of the loop)
@@ -692,12 +694,41 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         F_STAMP(7);
     }
 
+    const unsigned long long t_iter_end = SESSION ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // ---- the four residual norms of the last check: rows, then chunks through LDS
     const double gpx = group_max<W>(is_x ? snap_pri : 0.0), gpu = group_max<W>(is_u ? snap_pri : 0.0);
     const double gdx = group_max<W>(is_x ? snap_dua : 0.0), gdu = group_max<W>(is_u ? snap_dua : 0.0);
     e_barrier();
     if (r < 4) sRes[c * 4 + r] = (r == 0) ? gpx : (r == 1) ? gdx : (r == 2) ? gpu : gdu;
+    if constexpr (SESSION) {
+        // the tick's first controls, for the early answer below (sMail's command has been consumed: its first words are free)
+        if (max_iter > 0) {
+            e_static_for<0, S>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if ((i < nsl) && row_ok && !is_x && ((size_t)(s0 + i) + koff) == 0) sMail[r - NX] = V[i];
+            });
+        }
+    }
     e_barrier();
+    if constexpr (SESSION) {
+        // EARLY ANSWER (SolveParams::host_ans): lines [7 controls | mail_stamp(sequence number, controls)], each written by ONE store
+        // instruction of wavefront 0 -- the host accepts a line whose stamp fits the payload it read with it, so nothing has to be
+        // fenced or waited for here; the solution's write-out below happens while the host already steps its plant.
+        constexpr int NLA = (NU + 6) / 7;
+        if (p.host_ans && max_iter > 0 && tid < 8 * NLA) {
+            const int line = tid >> 3, slot = tid & 7;
+            unsigned long long x = 0ull;
+            double mine = 0.0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int idx = line * 7 + q;
+                const double v = idx < NU ? sMail[idx] : 0.0;
+                x ^= (unsigned long long)__builtin_bit_cast(long long, v);
+                if (q == slot) mine = v;
+            }
+            host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, x) : mine);
+        }
+    }
 
     // ---- write-back: solution (device + pinned host); one-shot launches also leave the ADMM state for the next launch
     if (max_iter > 0) {
@@ -707,17 +738,17 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
                 const size_t kn = (size_t)(s0 + i) + koff;
                 if (is_x) {
                     p.sol_x[((size_t)inst * N + kn) * NX + r] = V[i];
-                    if (p.host_sol) p.host_sol[kn * NX + r] = V[i];
+                    if (p.host_sol) host_store(&p.host_sol[kn * NX + r], V[i]);
                 } else {
                     p.sol_u[((size_t)inst * NS + kn) * NU + (r - NX)] = V[i];
-                    if (kn == 0 && p.u0_host) p.u0_host[(size_t)inst * NU + (r - NX)] = V[i];  // first controls straight to the host
-                    if (p.host_sol) p.host_sol[(size_t)N * NX + kn * NU + (r - NX)] = V[i];
+                    if (kn == 0 && p.u0_host) host_store(&p.u0_host[(size_t)inst * NU + (r - NX)], V[i]);  // first controls straight to the host
+                    if (p.host_sol) host_store(&p.host_sol[(size_t)N * NX + kn * NU + (r - NX)], V[i]);
                 }
             }
         });
         if (k0) {
             p.sol_x[(size_t)inst * N * NX + r] = V0;
-            if (p.host_sol) p.host_sol[r] = V0;
+            if (p.host_sol) host_store(&p.host_sol[r], V0);
         }
         if constexpr (!SESSION) write_state(converged);
     }
@@ -734,25 +765,41 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         if (p.host_sol) {
             double *hs = p.host_sol + (size_t)N * NX + (size_t)NS * NU;
             if (k == 0) {
-                hs[4] = (double)it_done;
-                hs[5] = (double)status;
+                host_store(&hs[4], (double)it_done);
+                host_store(&hs[5], (double)status);
             }
-            if (res_valid) hs[k] = out;
+            if (res_valid) host_store(&hs[k], out);
         }
     }
 #if TINY_F_STAMP
     e_barrier();
     if (lane < 8) {
         p.sol_x[(size_t)inst * N * NX + wv * 8 + lane] = (double)(stamp[lane] - stamp[0]);
-        if (p.host_sol) p.host_sol[wv * 8 + lane] = (double)(stamp[lane] - stamp[0]);
+        if (p.host_sol) host_store(&p.host_sol[wv * 8 + lane], (double)(stamp[lane] - stamp[0]));
     }
 #endif
     if (p.host_sol && (SESSION || p.host_seq != 0.0)) {  // (uniform) everything above is in pinned memory: raise the completion stamp
-        __threadfence_system();
+        // Everything the host reads after the stamp was stored with host_store() (system scope: written through, nothing of it stays dirty in
+        // the L2): once every thread's stores have been handed over (s_waitcnt vmcnt(0) -- a workgroup-scope release) the stamp may follow
+        // them. Rounds 2-4 had plain stores and a system-scope fence here (__threadfence_system + a release store), which wrote back the
+        // L2's dirty lines -- the solution just stored to HBM included -- and INVALIDATED the caches, twice per tick: the next tick then
+        // fetched its operators and tables from HBM again.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        // (a system-scope atomic store: a plain store may sit in the L2 until the kernel ends -- which a resident session kernel does not do)
-        if (threadIdx.x == 0)
-            __hip_atomic_store(p.host_sol + (size_t)N * NX + (size_t)NS * NU + 6, SESSION ? expect : p.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a system-scope atomic store: written through at once -- a plain store might be combined or delayed)
+        if (threadIdx.x == 0) {
+            double *const hs = p.host_sol + (size_t)N * NX + (size_t)NS * NU;
+            if constexpr (SESSION) {
+                // diagnostics in the spare slot behind the stamp (tinympc_debug_tick_timing): how long the kernel waited for this command
+                // since its last answer, its ADMM iterations, its write-out -- 16 bits each, in ticks of 10 ns
+                const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
+                auto clip = [](unsigned long long d) -> unsigned long long { return d > 65535ull ? 65535ull : d; };
+                const unsigned long long packed = clip(t_prev_out ? t_seen - t_prev_out : 0ull) | (clip(t_iter_end - t_seen) << 16) | (clip(t_out - t_iter_end) << 32);
+                host_store(hs + 7, (double)packed);
+                t_prev_out = t_out;
+            }
+            __hip_atomic_store(hs + 6, SESSION ? expect : p.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if constexpr (!SESSION) break;
     // The next tick warm-starts from the registers. A converged solve returns before v <- vnew (admm.cpp:181-197): its canonical
