@@ -179,3 +179,54 @@ def test_cache_script_through_the_mex_verbs(mex, pkg):
     assert mex.call("compute_cache_terms")[0] == "TinyMPC:InvalidInput"
     assert mex.call("reset", 0.0)[0] is None
     assert mex.call("compute_cache_terms", 0.0, nlhs=4)[0] == "TinyMPC:NotInitialized"
+
+
+def test_missing_trailing_arguments_the_reference_does_not_check(mex):
+    """bindings.cpp:188-195, 408-414, 450-459 read prhs[0..] without looking at nrhs: a call with too few arguments dereferences
+    past the argument list there (undefined behaviour, typically a MATLAB crash). The shim raises TinyMPC:InvalidInput instead --
+    before it looks at the handle, so this needs no GPU. (INTEGRATION.md section 2a lists every such deviation.)"""
+    mex.call("reset", 0.0)
+    z = np.zeros((4, 20))
+    assert mex.call("set_bound_constraints", z, z, np.zeros((1, 19)))[0] in ("TinyMPC:InvalidInput", "TinyMPC:NotInitialized")
+    assert mex.call("set_linear_constraints", np.zeros((1, 4)), np.zeros(1))[0] in ("TinyMPC:InvalidInput", "TinyMPC:NotInitialized")
+    assert mex.call("set_cone_constraints", np.array([0], dtype=np.int32), np.array([3], dtype=np.int32), np.array([0.5]))[0] in (
+        "TinyMPC:InvalidInput", "TinyMPC:NotInitialized")
+
+
+@pytest.mark.gpu
+def test_sloppy_inputs_the_reference_lets_through(mex, pkg):
+    """One case per deviation of INTEGRATION.md section 2a -- inputs the reference accepts (it prints and assigns, or reads past its
+    argument list) and this build refuses, with the identifier a MATLAB caller sees:
+      wrong-length x0            tiny_api.cpp:238-240 perror()s and assigns        -> TinyMPC:SetX0Failed
+      wrong-shape Xref / Uref    tiny_api.cpp:250-254, 262-266 print and assign   -> TinyMPC:SetXRefFailed / SetURefFailed
+      too few arguments          bindings.cpp:188-195, 408-414, 450-459 unchecked -> TinyMPC:InvalidInput
+      cone index / length lists of different lengths (bindings.cpp:450-466 forwards them) -> TinyMPC:InvalidInput
+    and after every refusal the solver is untouched: the solve that follows equals the golden one."""
+    g = golden("cartpole_box_tol")
+    nx, nu, N = 4, 1, 20
+    err, out = mex.call("setup", g["A"], g["B"], np.zeros((nx, 1)), g["Q"], g["R"], float(g["rho"]), float(nx), float(nu), float(N), 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] == 0
+    settings = [1e-4, 1e-4, 100.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 10.0, 1.0, 0.0]
+    assert mex.call("set_bound_constraints", g["x_min"], g["x_max"], g["u_min"], g["u_max"], 0.0)[0] is None
+    assert mex.call("update_settings", *settings)[0] is None
+    assert mex.call("set_x0", g["x0"], 0.0)[0] is None
+    # --- the refusals
+    assert mex.call("set_x0", np.zeros(nx + 1), 0.0)[0] == "TinyMPC:SetX0Failed"
+    assert mex.call("set_x0", np.zeros(nx - 1), 0.0)[0] == "TinyMPC:SetX0Failed"
+    assert mex.call("set_x_ref", np.zeros((nx, N - 1)), 0.0)[0] == "TinyMPC:SetXRefFailed"
+    assert mex.call("set_x_ref", np.zeros((nx + 1, N)), 0.0)[0] == "TinyMPC:SetXRefFailed"
+    assert mex.call("set_u_ref", np.zeros((nu, N)), 0.0)[0] == "TinyMPC:SetURefFailed"
+    assert mex.call("set_u_ref", np.zeros((nu + 1, N - 1)), 0.0)[0] == "TinyMPC:SetURefFailed"
+    assert mex.call("set_bound_constraints", g["x_min"], g["x_max"], g["u_min"])[0] == "TinyMPC:InvalidInput"
+    assert mex.call("set_linear_constraints", np.zeros((1, nx)), np.zeros(1), np.zeros((0, 0)))[0] == "TinyMPC:InvalidInput"
+    i32 = lambda *v: np.array(v, dtype=np.int32)
+    assert mex.call("set_cone_constraints", i32(0), i32(3), np.array([0.5]), i32(), i32())[0] == "TinyMPC:InvalidInput"
+    assert mex.call("set_cone_constraints", i32(0, 1), i32(3), np.array([0.5]), i32(), i32(), np.zeros(0))[0] == "TinyMPC:InvalidInput"
+    # --- nothing of the above reached the solver
+    err, out = mex.call("solve", 0.0, nlhs=1)
+    assert err is None and out[0][0, 0] == 0
+    err, (x, u) = mex.call("get_solution", 0.0, nlhs=2)
+    assert rel_err(x, g["sol_x"]) < 1e-9 and rel_err(u, g["sol_u"]) < 1e-9
+    err, (it, status, _, _) = mex.call("get_stats", 0.0, nlhs=4)
+    assert int(it[0, 0]) == int(g["iter"]) and int(status[0, 0]) == 1
+    assert mex.call("reset", 0.0)[0] is None

@@ -57,6 +57,12 @@ def main():
                 out["kernel"] = {"name": kname, "calls": k[1], "average_ms_under_the_profiler": k[3] * 1e-3}
                 q = "select duration, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, workgroup_x, grid_x from kernels where name = ? order by start"
                 tr = list(con.execute(q, (kname,)))
+                nlast = int((plain or {}).get("launches") or 0)
+                if tr and nlast and len(tr) > nlast:  # (the measured launches: whatever came before them was the clock settling)
+                    out["kernel"]["calls_warmup"] = len(tr) - nlast
+                    tr = tr[-nlast:]
+                    out["kernel"]["average_ms_under_the_profiler"] = sum(r[0] for r in tr) / len(tr) * 1e-6
+                    out["kernel"]["calls"] = len(tr)
                 if tr:
                     out["kernel"].update({"lds_bytes": tr[-1][1], "vgpr_count": tr[-1][2], "accum_vgpr_count": tr[-1][3], "sgpr_count": tr[-1][4],
                                           "workgroup": tr[-1][5], "grid": tr[-1][6], "durations_ns": [r[0] for r in tr]})
@@ -67,6 +73,9 @@ def main():
                 for name, cn, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
                     if kname and name == kname or (not kname and ("k_admm_solve" in name or "tinympc_jit_solve" in name or "k_builtin_" in name)):
                         counters.setdefault(cn, []).append(float(v))
+        nlast = int((plain or {}).get("launches") or 0)
+        if nlast:  # (per pass, the counters of its LAST `launches` dispatches of the kernel)
+            counters = {k: (v[-nlast:] if len(v) > nlast else v) for k, v in counters.items()}
         c = {k: {"launches": len(v), "mean": st.mean(v)} for k, v in counters.items()}
         out["counters_per_launch"] = c
         if plain and "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
