@@ -940,6 +940,18 @@ def main() -> int:
                 if slow:
                     tick[mode]["ticks_above_1ms"] = slow
                 tk.reset()
+            # ... and the reference's own three verbs per tick (set_x0 + solve + get_solution, the whole solution copied out) from the same C
+            # loop: launched solves (what a script written against the reference gets as it stands) and RESIDENT solves (one extra line,
+            # tinympc_set_resident: the same verbs on the resident session kernel)
+            for mode in ("verbs_launched", "verbs_resident"):
+                tk = pkg.TinyMPC()
+                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+                tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+                if mode == "verbs_resident":
+                    tk.set_resident(True)
+                cl = tk.bench_closed_loop(prob.A, prob.B, prob.x0, 220, 20, session="verbs")
+                tick[mode] = {"c_loop": dict({k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")}, tick_us=stats_us(cl["tick_us"]))}
+                tk.reset()
             # The SAME statistics on both sides (round 5): mean, median, p90, max of the 200 per-tick samples -- the GPU's from
             # libtinympc_bench.so's C loop, the reference core's from oracle/ref_shim.cpp's (ref_bench_closed_loop_samples)
             cref = (cpu or {}).get("closed_loop_tick_us_single_process") or {}
@@ -951,7 +963,7 @@ def main() -> int:
                                           "compiled code; no MATLAB / MEX overhead on its side. Like against like: c_loop.tick_us.{mean,median} against "
                                           "cpu_reference_tick_us.{mean,median} (both loops in C); the Python-mirror numbers carry ctypes calls the host side does not")
             if cref:
-                for mode in ("launch", "session"):
+                for mode in ("launch", "session", "verbs_launched", "verbs_resident"):
                     g_ = tick[mode]["c_loop"]["tick_us"]
                     tick[mode]["c_loop"]["gpu_over_cpu_time"] = {"mean": g_["mean"] / cref["mean"], "median": g_["median"] / cref["median"]}
             # ... and BASELINE config 4's own closed loop (rocket_landing_constraints.m:86-121): N = 100, cones + linear row + fdyn, the
@@ -1033,6 +1045,8 @@ def main() -> int:
                 # latency comparisons: the SAME statistic on both sides, mean and median each (round 5)
                 "closed_loop_tick_launch_c_loop_us_mean": leg("closed_loop_tick/launch/c_loop/tick_us/mean"), "closed_loop_tick_launch_c_loop_us_median": leg("closed_loop_tick/launch/c_loop/tick_us/median"),
                 "closed_loop_tick_session_c_loop_us_mean": leg("closed_loop_tick/session/c_loop/tick_us/mean"), "closed_loop_tick_session_c_loop_us_median": leg("closed_loop_tick/session/c_loop/tick_us/median"),
+                "closed_loop_tick_verbs_launched_us_mean": leg("closed_loop_tick/verbs_launched/c_loop/tick_us/mean"), "closed_loop_tick_verbs_launched_us_median": leg("closed_loop_tick/verbs_launched/c_loop/tick_us/median"),
+                "closed_loop_tick_verbs_resident_us_mean": leg("closed_loop_tick/verbs_resident/c_loop/tick_us/mean"), "closed_loop_tick_verbs_resident_us_median": leg("closed_loop_tick/verbs_resident/c_loop/tick_us/median"),
                 "closed_loop_tick_cpu_reference_us_mean": leg("closed_loop_tick/cpu_reference_tick_us/mean"), "closed_loop_tick_cpu_reference_us_median": leg("closed_loop_tick/cpu_reference_tick_us/median"),
                 "closed_loop_tick_session_python_us_mean": leg("closed_loop_tick/session/tick_us/mean"), "closed_loop_tick_session_python_us_median": leg("closed_loop_tick/session/tick_us/median"),
                 "rocket_closed_loop_launch_us_mean": leg("rocket_closed_loop/launch/tick_us/mean"), "rocket_closed_loop_launch_us_median": leg("rocket_closed_loop/launch/tick_us/median"),

@@ -264,6 +264,14 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
 int tinympc_session_begin(tinympc_solver *s);
 int tinympc_session_step(tinympc_solver *s, const double *x0, double *u0_out);
 int tinympc_session_end(tinympc_solver *s);
+/* Resident solves (an extension, off by default): after tinympc_set_resident(h, 1) the reference's own per-tick sequence
+ * tinympc_set_x0 -> tinympc_solve -> tinympc_get_solution / tinympc_get_stats runs on the resident session kernel instead of one launch per
+ * solve (a quadrotor N=50 tick: 6 us instead of 15). Results are bit-identical to launched solves. Single-instance handles with nx+nu <= 16
+ * and no adaptive rho; elsewhere solves are launched as before. Any verb that needs the device (new bounds, settings, ...) sends the
+ * resident kernel home, the next solve starts it again; it also leaves by itself after 2 s without a solve. While it is resident it occupies
+ * one compute unit and a DEVICE-wide synchronisation of other code in the process (hipMalloc, hipDeviceSynchronize) waits for it -- up to
+ * that idle time-out: the reason this is not the default. enable = 0 ends it. */
+int tinympc_set_resident(tinympc_solver *s, int enable);
 
 /* Launch the solve without waiting (same kernel as tinympc_solve); pair with tinympc_synchronize. Every verb
  * that changes an input of the launch in flight (set_x0, mpc_step, ... -- on single-instance handles x0 lives in

@@ -17,11 +17,12 @@ extern "C" {
 
 /* `ticks` closed-loop ticks of a single-instance handle (of an nx-state, nu-input system) driven from C (x0 in, warm-started solve, first controls out, plant step
  * x+ = A x + B u0 + f; f may be NULL) through tinympc_mpc_step_batch (session == 0) or the session the caller has opened
- * (session != 0): what a caller written in C pays per tick, next to the reference core timed the same way (oracle/ref_shim.cpp:
+ * (session == 1), or -- session == 2 -- the reference's own three verbs per tick, tinympc_set_x0 + tinympc_solve + tinympc_get_solution (whole
+ * solution copied out; launched solves, or resident ones after tinympc_set_resident): what a caller written in C pays per tick, next to the reference core timed the same way (oracle/ref_shim.cpp:
  * ref_bench_closed_loop -- /root/reference/examples/cartpole_example_mpc.m:36-44 is the loop). Only the tick verb is timed; the first
  * `skip` ticks are not counted (0 <= skip < ticks); *seconds and *iterations are sums over the counted ticks, tick_us (may be NULL)
  * receives every tick's duration. x is advanced in place. */
-int tinympc_bench_closed_loop(tinympc_solver *s, int nx, int nu, const double *A, const double *B, const double *f, double *x, int ticks, int skip, int session,
+int tinympc_bench_closed_loop(tinympc_solver *s, int nx, int nu, int N, const double *A, const double *B, const double *f, double *x, int ticks, int skip, int session,
                               double *seconds, long *iterations, double *tick_us);
 
 /* Where the last zero-copy tick spent its time: launch us, wait us, polls, 1 if the polling budget ran out. */

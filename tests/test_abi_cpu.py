@@ -48,8 +48,8 @@ def test_measurement_helpers_live_outside_the_boundary(pkg):
     x = np.zeros(4)
     p = x.ctypes.data_as(L.c_double_p)
     h = C.c_void_p(1)  # (never dereferenced: validation comes first)
-    assert bench.tinympc_bench_closed_loop(h, 2, 1, p, p, None, p, 5, 5, 0, None, None, None) == L.ERR_INVALID_INPUT
-    assert bench.tinympc_bench_closed_loop(None, 2, 1, p, p, None, p, 5, 1, 0, None, None, None) == L.ERR_INVALID_INPUT
+    assert bench.tinympc_bench_closed_loop(h, 2, 1, 5, p, p, None, p, 5, 5, 0, None, None, None) == L.ERR_INVALID_INPUT
+    assert bench.tinympc_bench_closed_loop(None, 2, 1, 5, p, p, None, p, 5, 1, 0, None, None, None) == L.ERR_INVALID_INPUT
 
 
 def test_seventeen_mex_verbs_have_entry_points(pkg):

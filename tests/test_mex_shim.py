@@ -161,6 +161,36 @@ def test_one_solve_script_through_the_mex_verbs(mex, pkg):
 
 
 @pytest.mark.gpu
+def test_resident_solves_through_the_mex_verbs(mex, pkg):
+    """The 'set_resident' verb (extension): the same three-verb loop, the solves on the resident kernel; equal to the launched loop."""
+    prob = pkg.problems.quadrotor(50)
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    settings = [1e-3, 1e-3, 60.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 10.0, 1.0, 0.0]
+    runs = []
+    for resident in (False, True):
+        err, _ = mex.call("setup", prob.A, prob.B, np.zeros((nx, 1)), prob.Q, prob.R, float(prob.rho), float(nx), float(nu), float(N), 0.0, nlhs=1)
+        assert err is None
+        xmin, xmax = np.repeat(prob.x_min[:, None], N, 1), np.repeat(prob.x_max[:, None], N, 1)
+        umin, umax = np.repeat(prob.u_min[:, None], N - 1, 1), np.repeat(prob.u_max[:, None], N - 1, 1)
+        assert mex.call("set_bound_constraints", xmin, xmax, umin, umax, 0.0)[0] is None
+        assert mex.call("update_settings", *settings)[0] is None
+        if resident:
+            assert mex.call("set_resident", 1.0)[0] is None
+        x, us = prob.x0.copy(), []
+        for k in range(8):
+            assert mex.call("set_x0", x, 0.0)[0] is None
+            assert mex.call("solve", 0.0, nlhs=1)[0] is None
+            err, (xs, u) = mex.call("get_solution", 0.0, nlhs=2)
+            assert err is None
+            us.append(u.copy())
+            x = prob.A @ x + prob.B @ u[:, 0]
+        runs.append(np.array(us))
+        assert mex.call("reset", 0.0)[0] is None
+    np.testing.assert_array_equal(runs[0], runs[1])
+    assert mex.call("set_resident", 1.0)[0] == "TinyMPC:NotInitialized"
+
+
+@pytest.mark.gpu
 def test_cache_script_through_the_mex_verbs(mex, pkg):
     """tests/test_cache.m of the reference (setup with N = 2, then compute_cache_terms), plus the two other
     class-side recursions, as the MEX calls this build's TinyMPC.m makes for them."""

@@ -314,3 +314,47 @@ def test_closed_loop_driven_from_c_equals_the_python_loop(pkg):
             b.session_end()
         a.reset()
         b.reset()
+
+
+@pytest.mark.parametrize("name", ["quadrotor", "cartpole10", "rocket"])
+def test_resident_solves_are_the_reference_loop_on_the_resident_kernel(pkg, name):
+    """tinympc_set_resident (round 5): the reference's per-tick sequence set_x0 -> solve -> get_solution / get_stats
+    (examples/cartpole_example_mpc.m:36-44) served by the resident session kernel -- bit-identical to launched solves, through verbs
+    that end the session (new bounds) and references that change, and back to launches when switched off."""
+    P = pkg.problems
+    prob = {"quadrotor": P.quadrotor(50), "cartpole10": P.cartpole(10, True), "rocket": P.rocket(20)}[name]
+    fam = name == "rocket"
+    settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60)
+    a, b = _solver(pkg, prob, settings, families=fam), _solver(pkg, prob, settings, families=fam)
+    a.set_resident(True)
+    x = prob.x0.copy()
+    f = prob.fdyn if prob.fdyn is not None else 0.0
+    for k in range(16):
+        if k == 6:  # a verb that needs the device: the resident kernel goes home, the next solve starts it again
+            for h in (a, b):
+                h.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min * 0.9, prob.u_max * 0.9)
+        if k == 9:
+            x_ref = np.repeat((0.3 * prob.x0)[:, None], prob.N, axis=1)
+            x_ref[:, ::2] *= 0.5
+            for h in (a, b):
+                h.set_x_ref(x_ref)
+        if k == 12:
+            a.set_resident(False)
+        for h in (a, b):
+            h.set_x0(x)
+            h.solve()
+        sa, sb = a.get_solution(), b.get_solution()
+        np.testing.assert_array_equal(sa["controls"], sb["controls"], err_msg=f"tick {k}")
+        np.testing.assert_array_equal(sa["states"], sb["states"])
+        assert a.get_stats() == b.get_stats(), k
+        x = prob.A @ x + prob.B @ sa["controls"][:, 0] + f
+    a.reset()
+    b.reset()
+    # a batched handle has no resident kernel: the switch is accepted, solves are launched
+    c = pkg.TinyMPC()
+    c.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=8, rho=prob.rho, fdyn=prob.fdyn, **settings)
+    c.set_resident(True)
+    c.set_x0_batch(np.asfortranarray(np.repeat(prob.x0[:, None], 8, axis=1)))
+    c.solve()
+    assert c.get_stats_batch()["iter"].min() >= 1
+    c.reset()

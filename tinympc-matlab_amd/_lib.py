@@ -91,6 +91,7 @@ SIGNATURES = {
     "tinympc_session_begin": (C.c_int, [Handle]),
     "tinympc_session_step": (C.c_int, [Handle, c_double_p, c_double_p]),
     "tinympc_session_end": (C.c_int, [Handle]),
+    "tinympc_set_resident": (C.c_int, [Handle, C.c_int]),
     "tinympc_get_launch_info": (C.c_int, [Handle, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "tinympc_get_layout": (C.c_int, [Handle]),
     "tinympc_prepare": (C.c_int, [Handle]),
@@ -101,7 +102,7 @@ SIGNATURES = {
 # include/tinympc_hip_bench.h: measurement helpers / diagnostics, not part of the drop-in boundary
 BENCH_LIB_PATH = os.path.join(_HERE, "libtinympc_bench.so")
 BENCH_SIGNATURES = {
-    "tinympc_bench_closed_loop": (C.c_int, [Handle, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
+    "tinympc_bench_closed_loop": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
                                             c_double_p, C.POINTER(C.c_long), c_double_p]),
 }
 DEBUG_SIGNATURES = {  # (exported by the product library itself: they read the handle's diagnostic counters)

@@ -383,8 +383,50 @@ int tinympc_synchronize(tinympc_solver *s) {
     return TINYMPC_OK;
 }
 
+// Resident solves (round 5, an extension; off by default): the reference's per-tick sequence  set_x0 -> solve -> get_solution  served by the
+// resident session kernel instead of a launch per solve -- what tinympc_session_step does, behind the reference's own verbs, so that a
+// script written against the reference needs ONE extra line (solver.set_resident(true)) for a 2.5x shorter tick. Bit-identical to
+// launched solves (the session's contract). Everything that ends a session (any verb that needs the device) ends this one too; the next
+// solve opens it again. Where no resident kernel exists for the configuration (batched handles, adaptive rho, wide systems) solves are
+// launched as before.
+int tinympc_set_resident(tinympc_solver *s, int enable) {
+    int rc = check_handle(s);
+    if (rc) return rc;
+    s->resident_solves = enable != 0;
+    s->resident_refused = false;
+    if (!enable && s->session_active) {
+        HIP_TRY(hipSetDevice(s->device));
+        return end_session(s);
+    }
+    return TINYMPC_OK;
+}
+
+static int print_solve_result(tinympc_solver *s) {
+    int it = 0, st = 0;
+    int rc = tinympc_get_stats(s, &it, &st, nullptr, nullptr, 0);
+    if (rc) return rc;
+    if (st == TINYMPC_STATUS_SOLVED) printf("Solver converged in %d iterations\n", it);  // admm.cpp:190
+    printf("Solve completed with status: %d\n", st == TINYMPC_STATUS_SOLVED ? 0 : 1);
+    return TINYMPC_OK;
+}
+
 int tinympc_solve(tinympc_solver *s, int verbose) {
-    int rc = tinympc_solve_async(s);
+    int rc = check_handle(s);
+    if (rc) return rc;
+    if (s->resident_solves && !s->resident_refused && s->host_path()) {
+        if (!s->session_active) {
+            rc = tinympc_session_begin(s);
+            if (rc == TINYMPC_ERR_UNSUPPORTED || rc == TINYMPC_ERR_INVALID_INPUT) s->resident_refused = true;  // (launched solves from here on)
+            else if (rc) return rc;
+        }
+        if (s->session_active) {
+            double u0[16];
+            if ((rc = tinympc_session_step(s, s->h_x0, u0))) return rc;  // (x0: what tinympc_set_x0 left in the pinned buffer)
+            s->x0_on_host = false;
+            return verbose ? print_solve_result(s) : TINYMPC_OK;
+        }
+    }
+    rc = tinympc_solve_async(s);
     if (rc) return rc;
     if ((rc = tinympc_synchronize(s))) return rc;
     if (verbose) {

@@ -156,6 +156,8 @@ struct tinympc_solver {
     double *d_mail = nullptr;          // ... or, where the host can store into device memory (large BAR), in fine-grained device memory
     double *mailbox() const { return d_mail ? d_mail : h_mail; }  // what the session uses (tinympc_handle.hip: acquire_arenas)
     bool session_active = false;
+    bool resident_solves = false;  // tinympc_set_resident: tinympc_solve goes through the resident session kernel where one exists
+    bool resident_refused = false; // ... and none does for this configuration (asked once)
     bool session_on_f = false;  // ... and its resident kernel is layout F's (families beyond what the latency kernel's session holds)
     // Taken by everything that writes the mailbox or (re)starts the resident kernel: session_step (for the whole tick), end_session
     // and park_sessions_on_device -- the one place where a thread reaches into a handle it does not own. Lock order: the session

@@ -166,6 +166,12 @@ void verb_session_end(int, mxArray *[], int, const mxArray *[]) {
     check(tinympc_session_end(g_handle));
 }
 
+void verb_set_resident(int, mxArray *[], int nrhs, const mxArray *prhs[]) {  // on/off: solve() on the resident session kernel (extension)
+    need_args(nrhs, 1, "set_resident");
+    need_solver();
+    check(tinympc_set_resident(g_handle, as_int(prhs[0])));
+}
+
 void verb_get_solution(int, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     need_args(nrhs, 1, "get_solution");
     need_solver();
@@ -310,7 +316,7 @@ const Verb kVerbs[] = {
     {"set_cone_constraints", verb_set_cone_constraints},
     {"compute_cache_terms", verb_compute_cache_terms}, {"solve_lqr", verb_solve_lqr},
     {"compute_sensitivity", verb_compute_sensitivity},
-    {"prepare", verb_prepare}, {"session_begin", verb_session_begin}, {"session_step", verb_session_step}, {"session_end", verb_session_end},
+    {"prepare", verb_prepare}, {"session_begin", verb_session_begin}, {"session_step", verb_session_step}, {"session_end", verb_session_end}, {"set_resident", verb_set_resident},
 };
 
 }  // namespace

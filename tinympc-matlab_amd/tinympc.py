@@ -355,9 +355,10 @@ class TinyMPC:
             _lib.check(rc)
         return ub[:, 0].copy()
 
-    def bench_closed_loop(self, A, B, x0, ticks: int, skip: int = 0, session: bool = False, fdyn=None) -> dict:
+    def bench_closed_loop(self, A, B, x0, ticks: int, skip: int = 0, session=False, fdyn=None) -> dict:
         """`ticks` closed-loop ticks driven from C (libtinympc_bench.so: tinympc_bench_closed_loop, include/tinympc_hip_bench.h): what a
-        caller written in C pays per tick -- no Python call inside a tick. With session=True the caller has opened the session.
+        caller written in C pays per tick -- no Python call inside a tick. With session=True the caller has opened the session; session="verbs": the reference's own three verbs per
+        tick (set_x0 + solve + get_solution), launched or -- after set_resident(True) -- resident.
         Returns the per-tick durations (us) of the counted ticks (`tick_us`), their mean / median / maximum, the iterations per tick
         and the final state. A measurement helper, not part of the reference class's surface."""
         self._check_setup()
@@ -368,8 +369,8 @@ class TinyMPC:
         f = _f(np.asarray(fdyn, dtype=np.float64).reshape(-1, 1)) if fdyn is not None else None
         sec, its = C.c_double(0.0), C.c_long(0)
         per = np.zeros(ticks)
-        rc = _lib.load_bench_library().tinympc_bench_closed_loop(self._h, self.nx, self.nu, _p(a), _p(b), _p(f) if f is not None else None, _p(x), int(ticks),
-                                                                 int(skip), int(bool(session)), C.byref(sec), C.byref(its), _p(per))
+        rc = _lib.load_bench_library().tinympc_bench_closed_loop(self._h, self.nx, self.nu, self.N, _p(a), _p(b), _p(f) if f is not None else None, _p(x), int(ticks),
+                                                                 int(skip), 2 if session == "verbs" else int(bool(session)), C.byref(sec), C.byref(its), _p(per))
         _lib.check(rc)
         n = ticks - skip
         return dict(us_per_tick=1e6 * sec.value / n, us_per_tick_median=float(np.median(per[skip:])), us_per_tick_max=float(np.max(per[skip:])),
@@ -382,6 +383,12 @@ class TinyMPC:
         _lib.check(self._L.tinympc_debug_setup_timing(self._h, _p(out)))
         return dict(zip(("prologue_us", "device_arena_us", "pinned_arena_us", "stage_and_queue_us", "queue_precompute_us", "wait_us", "total_us",
                          "riccati_loop_clocks", "riccati_loop_us", "riccati_steps"), out))
+
+    def set_resident(self, on: bool = True):
+        """Resident solves (tinympc_set_resident): set_x0 / solve / get_solution served by the resident session kernel instead of a
+        launch per solve -- bit-identical results, a 2.5x shorter tick. Off by default (include/tinympc_hip.h says why)."""
+        self._check_setup()
+        _lib.check(self._L.tinympc_set_resident(self._h, int(bool(on))))
 
     def session_end(self):
         self._check_setup()
