@@ -558,7 +558,7 @@ int tinympc_debug_tick_timing(tinympc_solver *s, double *out4) {
     int rc = check_handle(s);
     if (rc) return rc;
     if (s->session_active && s->session_on_f && s->h_sol) {
-        // layout F's resident kernel leaves its own split of the last tick in the spare slot behind the completion stamp: us it waited
+        // layout F's resident kernel (not layout C's) leaves its own split of the last tick in the spare slot behind the completion stamp: us it waited
         // for the command since its previous answer, us of ADMM iterations, us of write-out (16 bits each, ticks of 10 ns)
         if (s->host_sol_state == 3 && (rc = wait_session_solution(s))) return rc;
         const unsigned long long packed = (unsigned long long)s->h_sol[s->X() + s->U() + 7];

@@ -160,11 +160,11 @@ struct SolveParams {
     // payload): a line is complete when its stamp fits the expected sequence number AND the payload read with it.
     // NULL = an ordinary one-shot launch.
     const double *mail;
-    // The session's EARLY answer (round 5, layout F's resident kernel): the tick's first controls travel ahead of everything else, in
+    // The session's EARLY answer (round 5, both resident kernels): the tick's first controls travel ahead of everything else, in
     // 64-byte lines [7 controls | mail_stamp(sequence number, controls)] written by ONE store instruction each -- the host takes them as
     // soon as a line's stamp fits its payload (no fence in front of it, no wait for the solution's write-out: 1.2 us of a 7 us
     // quadrotor tick). Solution, statistics and the completion stamp behind host_sol follow; host readers of those wait for that
-    // stamp. NULL: the completion stamp is the answer (layout C's resident kernel, one-shot launches).
+    // stamp. NULL: the completion stamp is the answer (one-shot launches).
     double *host_ans;
     double session_expect;             // stamp of the first command to wait for
     unsigned long long session_idle;   // exit after this many 100 MHz ticks without a command (the exit every wave reaches)

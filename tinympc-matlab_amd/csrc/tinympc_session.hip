@@ -80,7 +80,7 @@ int launch_session_kernel(tinympc_solver *s) {
     p.ctab = s->dctab; p.chunk_len = s->chunk_len; p.chunk_count = s->chunk_count; p.chunk_levels = s->chunk_levels;
     p.families = fam ? 1 : 0;
     p.mail = s->mailbox();
-    p.host_ans = s->session_on_f ? s->h_ans : nullptr;  // (layout F's resident kernel answers early, see SolveParams::host_ans)
+    p.host_ans = s->h_ans;  // (both resident kernels answer early, see SolveParams::host_ans)
     p.session_expect = (double)(s->session_seq + 1);
     p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
     if (s->session_on_f) {
@@ -222,10 +222,9 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
     write_command(s, flags, x0);
     const volatile double *done = s->h_sol + s->X() + s->U() + 6;
     double want = (double)s->session_seq;
-    // The answer: layout F's resident kernel sends the first controls ahead, in lines [7 controls | mail_stamp(seq, controls)] that are
-    // complete when the stamp fits the payload read with it (SolveParams::host_ans); layout C's raises the completion stamp behind the
-    // solution, which is then all there.
-    const bool early = s->session_on_f;
+    // The answer: the resident kernels send the first controls ahead, in lines [7 controls | mail_stamp(seq, controls)] that are complete
+    // when the stamp fits the payload read with it (SolveParams::host_ans); solution and statistics follow under the completion stamp.
+    const bool early = s->h_ans != nullptr;
     const int nlines = (s->nu + 6) / 7;
     double u0_lines[24];
     auto answered = [&]() -> bool {
