@@ -119,6 +119,47 @@ def test_precompute_kernel_matches_reference_cache(pkg, name):
     s.reset()
 
 
+@pytest.mark.layouts("C")  # (the precompute does not depend on the solve kernel: once, not once per layout)
+@pytest.mark.parametrize("nx,nu", [(3, 1), (4, 3), (5, 2), (7, 3), (8, 4), (10, 4), (12, 1), (9, 2), (12, 4), (6, 3), (13, 2), (6, 5)])
+def test_register_resident_precompute_on_every_shape_class(pkg, monkeypatch, nx, nu):
+    """k_precompute_rows (round 5: the Riccati fixed point in the registers of one wavefront) is instantiated for the BASELINE shapes exactly
+    and for zero-padded classes (4,4), (8,4), (12,4); nx > 12 or nu > 4 stay on the one-workgroup LDS kernel. Every class against the
+    reference's own core (box problems: oracle/_ref where it is there) incl. the truncated step count, with fdyn against the restatement, and
+    against the LDS kernel on the same handle data (TINYMPC_PRECOMPUTE=lds)."""
+    P = pkg.problems
+    rng = np.random.default_rng(100 * nx + nu)
+    A = 0.92 * np.eye(nx) + (0.25 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    B = 0.3 * rng.standard_normal((nx, nu))
+    Q, R = np.diag(rng.uniform(0.5, 20.0, nx)), np.diag(rng.uniform(0.2, 4.0, nu))
+    for fdyn in (None, 0.05 * rng.standard_normal(nx)):
+        prob = P.Problem("rows", A, B, Q, R, 8, float(rng.uniform(0.3, 6.0)), rng.standard_normal(nx))
+        prob.fdyn = fdyn
+        caches = {}
+        for mode in ("rows", "lds"):
+            if mode == "lds":
+                monkeypatch.setenv("TINYMPC_PRECOMPUTE", "lds")
+            else:
+                monkeypatch.delenv("TINYMPC_PRECOMPUTE", raising=False)
+            s = pkg.TinyMPC()
+            s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, rho=prob.rho, fdyn=prob.fdyn)
+            caches[mode] = s.get_cache()
+            # (what the affine terms APf / BPf feed: one solve from a non-zero state)
+            s.set_x0(prob.x0)
+            s.update_settings(max_iter=12, abs_pri_tol=0.0, abs_dua_tol=0.0)
+            s.solve()
+            caches[mode]["sol"] = s.get_solution()["controls"]
+            s.reset()
+        monkeypatch.delenv("TINYMPC_PRECOMPUTE", raising=False)
+        orc = (O.OracleRef if (fdyn is None and O.ref_available()) else O.OraclePort)(prob)
+        steps = O.OraclePort(prob).stats()["riccati_iters"]  # (the restatement counts its Riccati steps; pinned to the reference's cache below)
+        for n, key in (("Kinf", "Kinf"), ("Pinf", "Pinf"), ("Quu_inv", "Quu_inv"), ("AmBKt", "AmBKt")):
+            ref = orc.get(key)
+            assert rel_err(caches["rows"][n], ref.reshape(caches["rows"][n].shape, order="F")) < 1e-10, (n, nx, nu)
+            assert rel_err(caches["rows"][n], caches["lds"][n]) < 1e-11, (n, "rows vs lds")
+        assert caches["rows"]["riccati_iters"] == caches["lds"]["riccati_iters"] == steps
+        assert rel_err(caches["rows"]["sol"], caches["lds"]["sol"]) < 1e-9
+
+
 @pytest.mark.parametrize("name", SINGLE)
 def test_solve_matches_golden(pkg, name):
     g = golden(name)
