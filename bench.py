@@ -393,7 +393,8 @@ def main() -> int:
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
 
-    from tools.bench_legs import batched_tick_leg, setup_leg, stats_us
+    from tools.bench_legs import (LegContext, batched_tick_leg, config5_legs, instance_and_family_legs, setup_leg, shape_and_latency_legs,
+                                  stats_us)
     pkg = ge.load_package()
     P = pkg.problems
     if not torch.cuda.is_available():
@@ -617,402 +618,14 @@ def main() -> int:
             "launch": info,
             "summary": summary,
         }
+        ctx = LegContext(pkg=pkg, prob=prob, args=args, cpu=cpu, dev_index=dev_index, dev=dev, torch=torch, np=np, out=out, flops_iter=flops_iter,
+                         bytes_iter=bytes_iter, sol=(sol if parity else None), parity=parity, leg_counters=leg_counters)
+        # (the legs of rounds 1-4 live in tools/bench_legs.py since round 5: this file keeps the headline, the contract and the flat `legs`)
         if world == 1 and not args.no_config5:
-            # BASELINE config 5 on ONE GPU: all 65,536 instances in one launch (8 waves per CU x 8 rounds)
-            nb = 65536
-            big = pkg.TinyMPC()
-            big.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=dev_index, rho=prob.rho,
-                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
-            big.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-            big.set_x0_batch(torch.from_numpy(np.ascontiguousarray(P.quadrotor_batch_x0(nb).T)).to(dev))
-            big.synchronize()
-            big.reset_workspace()
-            big.solve_timed()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            kms = []
-            for _ in range(3):
-                big.reset_workspace()
-                kms.append(big.solve_timed())
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            u_first = big.get_solution_batch(0, 64)["controls"]
-            out["config5_single_gpu"] = {"workload": "65,536 quadrotor N=%d instances x %d forced iterations on ONE GPU, 3 cold-started steps" % (prob.N, args.iters),
-                                         "value": 3 * nb * args.iters / dt, "unit": "ADMM iters/s", "ms_per_step": 1e3 * dt / 3,
-                                         "kernel_ms_avg": sum(kms) / 3, "layout": big.launch_info()["layout"],
-                                         "fp64_frac": nb * args.iters * flops_iter / (sum(kms) / 3 * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                         "prefix_matches_8192_run": (bool(np.array_equal(u_first, sol["controls"])) if parity else None),
-                                         "kernel": big.jit_info()}
-            big.reset()
-            # The same 65,536 instances as a CONVERGING batch (tol 1e-3, x0 scaled 0.05 ... 3: 5 to 200 iterations per instance):
-            # the plain kernel holds a wavefront until its slowest instance is done; with slot refill (tinympc_solve_d.hip) a
-            # row takes the next instance as soon as its own has finished. Same results bit for bit (tests/test_slot_refill_gpu.py).
-            rng = np.random.default_rng(0)
-            x0c = np.ascontiguousarray((P.quadrotor_batch_x0(nb) * rng.uniform(0.05, 3.0, nb)[None, :]).T)
-            conv = {}
-            for mode in ("0", None):
-                if mode is None:
-                    os.environ.pop("TINYMPC_REFILL", None)
-                else:
-                    os.environ["TINYMPC_REFILL"] = mode
-                cb = pkg.TinyMPC()
-                cb.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=nb, device=dev_index, rho=prob.rho,
-                         abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=args.iters, check_termination=1)
-                cb.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-                cb.set_x0_batch(torch.from_numpy(x0c).to(dev))
-                kms = []
-                for _ in range(4):
-                    cb.reset_workspace()
-                    kms.append(cb.solve_timed())
-                its = cb.get_stats_batch()["iter"].astype(np.float64)
-                conv["plain" if mode == "0" else "default"] = {"kernel_ms": float(np.median(kms[1:])), "kernel": cb.jit_info(), "instance_iterations": float(its.sum())}
-                cb.reset()
-            os.environ.pop("TINYMPC_REFILL", None)
-            forced_rate = nb * args.iters / (out["config5_single_gpu"]["kernel_ms_avg"] * 1e-3)  # instance-iterations/s with every row busy
-            d = conv["default"]
-            out["converging_batch"] = {"workload": "65,536 quadrotor N=%d instances, tol 1e-3, max_iter %d, x0 scaled 0.05 ... 3 (mean %.0f iterations per instance)"
-                                                   % (prob.N, args.iters, d["instance_iterations"] / nb),
-                                       "kernel_ms": d["kernel_ms"], "kernel": d["kernel"], "iters_per_s": d["instance_iterations"] / (d["kernel_ms"] * 1e-3),
-                                       "fraction_of_forced_iteration_rate": d["instance_iterations"] / (d["kernel_ms"] * 1e-3) / forced_rate,
-                                       "plain_kernel_ms": conv["plain"]["kernel_ms"],
-                                       "same_iteration_total": conv["plain"]["instance_iterations"] == d["instance_iterations"]}
+            config5_legs(ctx)
         if world == 1 and not args.no_single:
-            one = pkg.TinyMPC()
-            one.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho,
-                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
-            one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-            one.set_x0(prob.x0)
-            ms = []
-            for k in range(13):
-                one.reset_workspace()
-                ms.append(one.solve_timed())
-            ms = sorted(ms[3:])
-            med = ms[len(ms) // 2]
-            out["single_instance"] = {"iters_per_s": args.iters / (med * 1e-3), "us_per_iter": 1e3 * med / args.iters,
-                                      "kernel_ms": med, "roofline_frac": args.iters * bytes_iter / (med * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                      "layout": one.launch_info()["layout"], **leg_counters("single_instance", args.iters / (med * 1e-3))}
-            one.reset()
-            # BASELINE config 4: one rocket-landing instance, N=100, second-order cones + a linear row + fdyn
-            rk = P.rocket(100)
-            one = pkg.TinyMPC()
-            one.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=dev_index, rho=rk.rho, fdyn=rk.fdyn,
-                      abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
-            one.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
-            if rk.x_ref is not None:
-                one.set_x_ref(rk.x_ref)
-            if rk.u_ref is not None:
-                one.set_u_ref(rk.u_ref)
-            one.set_cone_constraints(**rk.cones)
-            if rk.linear:
-                one.set_linear_constraints(**rk.linear)
-            one.set_x0(rk.x0)
-            ms = []
-            for k in range(9):
-                one.reset_workspace()
-                ms.append(one.solve_timed())
-            med = sorted(ms[2:])[len(ms[2:]) // 2]
-            out["rocket_instance"] = {"workload": "rocket landing nx=6 nu=3 N=100, state + input cones, 1 linear row, fdyn, %d forced iterations" % args.iters,
-                                      "us_per_iter": 1e3 * med / args.iters, "kernel_ms": med, "layout": one.launch_info()["layout"],
-                                      "flops_per_instance_iteration": rk.flops_per_iteration_families()["with_box"],
-                                      "flops_model": "problems.flops_per_iteration_families(): SURVEY section 8a's box-path formula + the cone / half-space projections, "
-                                                     "their slack / dual / linear-cost terms and fdyn, counted on oracle/tinympc_oracle.c:348-470",
-                                      "fp64_frac": args.iters * rk.flops_per_iteration_families()["with_box"] / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                      "cpu_port_us_per_iter_single_process": cpu.get("rocket_us_per_iter_single_process") if cpu else None,
-                                      **leg_counters("rocket_instance", args.iters / (med * 1e-3))}
-            one.reset()
-            # ... and batches of it: N=100 (BASELINE config 4's horizon: the latency kernel, one workgroup per instance) and
-            # N=10 (the horizon of examples/rocket_landing_constraints.m:14: layout D with the families in registers)
-            rb = {}
-            for rN in (100, 10):
-                rkb = P.rocket(rN)
-                rB, rit = 4096, 100
-                many = pkg.TinyMPC()
-                many.setup(rkb.A, rkb.B, rkb.Q, rkb.R, rkb.N, batch=rB, device=dev_index, rho=rkb.rho, fdyn=rkb.fdyn,
-                           abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=rit, check_termination=1)
-                many.set_bound_constraints(rkb.x_min, rkb.x_max, rkb.u_min, rkb.u_max)
-                many.set_x_ref(rkb.x_ref)
-                many.set_u_ref(rkb.u_ref)
-                many.set_cone_constraints(**rkb.cones)
-                many.set_linear_constraints(**rkb.linear)
-                many.set_x0_batch(np.asfortranarray(rkb.x0[:, None] * np.linspace(0.6, 1.2, rB)[None, :]))
-                ms = []
-                for k in range(5):
-                    many.reset_workspace()
-                    ms.append(many.solve_timed())
-                med = sorted(ms[1:])[len(ms[1:]) // 2]
-                rb["N=%d" % rN] = {"iters_per_s": rB * rit / (med * 1e-3), "kernel_ms": med, "layout": many.launch_info()["layout"], "jit": many.jit_info(),
-                                   "box_part_fp64_frac": rB * rit * rkb.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                   "flops_per_instance_iteration": rkb.flops_per_iteration_families()["with_box"],
-                                   "fp64_frac": rB * rit * rkb.flops_per_iteration_families()["with_box"] / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                   **(leg_counters("rocket_batch", rB * rit / (med * 1e-3)) if rN == 100 else {})}
-                many.reset()
-            out["rocket_batch"] = dict(workload="4096 rocket-landing instances (cones + linear row + fdyn) x 100 forced iterations", **rb)
-            # Adaptive rho (admm.cpp:117-174) on a batch: rho, its operator rows and pNref per instance, layout D's ADAPT variant
-            ad = pkg.TinyMPC()
-            aB, ait = 8192, 100
-            ad.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=aB, device=dev_index, rho=prob.rho, abs_pri_tol=0.0, abs_dua_tol=0.0,
-                     max_iter=ait, adaptive_rho=True, adaptive_rho_min=0.2, adaptive_rho_max=40.0)
-            ad.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-            ad.set_sensitivity_matrices(*ad.compute_sensitivity_autograd())
-            ad.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(aB)))
-            ms = []
-            for k in range(5):
-                ad.reset_workspace()
-                ms.append(ad.solve_timed())
-            med = sorted(ms[1:])[len(ms[1:]) // 2]
-            out["adaptive_rho_batch"] = {"workload": "quadrotor N=%d, %d instances x %d forced iterations, rho adapted every 5th" % (prob.N, aB, ait),
-                                         "iters_per_s": aB * ait / (med * 1e-3), "kernel_ms": med, "layout": ad.launch_info()["layout"],
-                                         "fp64_frac_box_part": aB * ait * flops_iter / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                                         "rho_spread": [float(np.min(ad.get_rho_batch())), float(np.max(ad.get_rho_batch()))],
-                                         **leg_counters("adaptive_rho_batch", aB * ait / (med * 1e-3))}
-            ad.reset()
-        if world == 1 and not args.no_single:
-            # Wide systems (16 < nx+nu <= 64: dynamic sizes in the reference, types.hpp:16-17): 32 lanes per instance,
-            # cross-row swaps + fused DPP chain. Synthetic stable system, box constraints, 100 forced iterations.
-            rng = np.random.default_rng(0)
-            wnx, wnu, wN, wB, wit = 24, 8, 30, 4096, 100
-            wA = np.eye(wnx) + 0.03 * rng.standard_normal((wnx, wnx))
-            wBm = 0.1 * rng.standard_normal((wnx, wnu))
-            wp = P.Problem("wide", wA, wBm, np.diag(rng.uniform(1, 10, wnx)), np.diag(rng.uniform(0.5, 2, wnu)), wN, 2.0, rng.standard_normal(wnx))
-            wide = pkg.TinyMPC()
-            wide.setup(wp.A, wp.B, wp.Q, wp.R, wp.N, batch=wB, device=dev_index, rho=wp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=wit)
-            wide.set_bound_constraints(np.full(wnx, -2.0), np.full(wnx, 2.0), np.full(wnu, -0.3), np.full(wnu, 0.3))
-            wide.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((wnx, wB))))
-            ms = []
-            for k in range(6):
-                wide.reset_workspace()
-                ms.append(wide.solve_timed())
-            med = sorted(ms[1:])[len(ms[1:]) // 2]
-            wtf = wB * wit * wp.flops_per_iteration() / (med * 1e-3) / 1e12
-            out["wide_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (wnx, wnu, wN, wB, wit),
-                                  "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
-                                  "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"],
-                                  **leg_counters("wide_system", wB * wit / (med * 1e-3))}
-            wide.reset()
-            # Long horizon: the quadrotor at N = 100. The duals of 99 knots do not fit 256 registers, so layout D runs its second
-            # plan (one wavefront per SIMD with all 512 registers; the kernel is specialised at run time by tinympc_jit.hip).
-            hp = P.quadrotor(100)
-            hB, hit = 8192, 100
-            longh = pkg.TinyMPC()
-            longh.setup(hp.A, hp.B, hp.Q, hp.R, hp.N, batch=hB, device=dev_index, rho=hp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=hit)
-            longh.set_bound_constraints(hp.x_min, hp.x_max, hp.u_min, hp.u_max)
-            longh.set_x0_batch(np.asfortranarray(P.quadrotor_batch_x0(hB)))
-            ms = []
-            for k in range(5):
-                longh.reset_workspace()
-                ms.append(longh.solve_timed())
-            med = sorted(ms[1:])[len(ms[1:]) // 2]
-            htf = hB * hit * hp.flops_per_iteration() / (med * 1e-3) / 1e12
-            out["long_horizon"] = {"workload": "quadrotor N=100, box constraints, %d instances x %d forced iterations" % (hB, hit),
-                                   "iters_per_s": hB * hit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": htf, "fp64_frac": htf / PEAK_FP64_TFLOPS,
-                                   "layout": longh.launch_info()["layout"], "workgroups": longh.launch_info()["workgroups"],
-                                   **leg_counters("long_horizon", hB * hit / (med * 1e-3))}
-            longh.reset()
-            # Large systems (64 < nx+nu <= 512): 16 instances per tile on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the
-            # state streaming through HBM -- the north_star's "MFMA when nx is large enough" clause. HBM-bound: priced on both roofs.
-            lnx, lnu, lN, lB, lit = 96, 32, 20, 4096, 50
-            rng = np.random.default_rng(lnx)
-            lA = np.eye(lnx) * 0.98 + 0.015 * rng.standard_normal((lnx, lnx))
-            lBm = 0.08 * rng.standard_normal((lnx, lnu))
-            lp = P.Problem("large", lA, lBm, np.diag(rng.uniform(1, 10, lnx)), np.diag(rng.uniform(0.5, 2, lnu)), lN, 2.0, rng.standard_normal(lnx))
-            big = pkg.TinyMPC()
-            big.setup(lp.A, lp.B, lp.Q, lp.R, lp.N, batch=lB, device=dev_index, rho=lp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=lit)
-            big.set_bound_constraints(np.full(lnx, -2.0), np.full(lnx, 2.0), np.full(lnu, -0.3), np.full(lnu, 0.3))
-            big.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((lnx, lB))))
-            ms = []
-            for k in range(4):
-                big.reset_workspace()
-                ms.append(big.solve_timed())
-            med = sorted(ms[1:])[1]
-            ltf = lB * lit * lp.flops_per_iteration() / (med * 1e-3) / 1e12
-            lgb = lB * lit * lp.bytes_per_iteration() / (med * 1e-3) / 1e9
-            lmeas = leg_counters("large_system", lB * lit / (med * 1e-3))
-            out["large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (lnx, lnu, lN, lB, lit),
-                                   "iters_per_s": lB * lit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": ltf, "fp64_frac": ltf / PEAK_FP64_TFLOPS,
-                                   "hbm_measured_gbs": (lmeas.get("measured") or {}).get("hbm_measured_gbs"),
-                                   "hbm_measured_frac": (lmeas.get("measured") or {}).get("hbm_measured_frac"),
-                                   "hbm_model_gbs": lgb, "layout": big.launch_info()["layout"],
-                                   "hbm_note": "hbm_measured_*: the kernel's PMC-measured traffic per instance and iteration (FETCH_SIZE x 2 + WRITE_SIZE) at "
-                                               "this run's rate; hbm_model_gbs: SURVEY.md section 8d's streaming model (9-11 accesses per element), of which "
-                                               "the kernel moves about 2/3",
-                                   "kernel": "k_admm_solve_m (v_mfma_f64_16x16x4_f64, 16 instances per tile)", **lmeas}
-            # ... and the same system with a state cone, an input cone and two linear rows per side (round 4: the families' phase of
-            # layout M between the sweeps, one knot per wavefront; HBM-bound at a multiple of the box path's bytes)
-            frng = np.random.default_rng(5)
-            big.set_cone_constraints(Acx=[0, 40], qcx=[3, 6], cx=[0.8, 0.6], Acu=[0], qcu=[3], cu=[0.7])
-            big.set_linear_constraints(Alin_x=frng.standard_normal((2, lnx)) / np.sqrt(lnx), blin_x=np.array([0.3, 0.4]),
-                                       Alin_u=frng.standard_normal((2, lnu)) / np.sqrt(lnu), blin_u=np.array([0.2, 0.25]))
-            fms = []
-            for k in range(4):
-                big.reset_workspace()
-                fms.append(big.solve_timed())
-            fmed = sorted(fms[1:])[1]
-            out["large_system"]["with_families"] = {"workload": "+ 2 state cones, 1 input cone, 2 linear rows per side", "iters_per_s": lB * lit / (fmed * 1e-3),
-                                                    "kernel_ms": fmed, "layout": big.launch_info()["layout"], "fraction_of_box_rate": med / fmed}
-            big.reset()
-            # ... and beyond 256 rows (round 3): four row tiles per wavefront, the operator tiles streamed from a tile-major copy in L2;
-            # with nxu / 20 flop per byte of state this one is priced on the matrix pipe
-            vnx, vnu, vN, vB, vit = 480, 32, 20, 4096, 20
-            rng = np.random.default_rng(7)
-            vA = 0.6 * np.eye(vnx) + (0.1 / np.sqrt(vnx)) * rng.standard_normal((vnx, vnx))
-            vp = P.Problem("very_large", vA, 0.08 * rng.standard_normal((vnx, vnu)), np.diag(rng.uniform(1, 10, vnx)), np.diag(rng.uniform(0.5, 2, vnu)), vN, 2.0,
-                           rng.standard_normal(vnx))
-            vbig = pkg.TinyMPC()
-            vbig.setup(vp.A, vp.B, vp.Q, vp.R, vp.N, batch=vB, device=dev_index, rho=vp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=vit)
-            vbig.set_bound_constraints(np.full(vnx, -2.0), np.full(vnx, 2.0), np.full(vnu, -0.3), np.full(vnu, 0.3))
-            vbig.set_x0_batch(np.asfortranarray(np.random.default_rng(1).standard_normal((vnx, vB))))
-            ms = []
-            for k in range(3):
-                vbig.reset_workspace()
-                ms.append(vbig.solve_timed())
-            med = sorted(ms[1:])[0]
-            vtf = vB * vit * vp.flops_per_iteration() / (med * 1e-3) / 1e12
-            out["very_large_system"] = {"workload": "synthetic nx=%d nu=%d N=%d, box constraints, %d instances x %d forced iterations" % (vnx, vnu, vN, vB, vit),
-                                        "iters_per_s": vB * vit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": vtf, "fp64_frac": vtf / PEAK_FP64_TFLOPS,
-                                        "layout": vbig.launch_info()["layout"], "kernel": "k_admm_solve_m<32> (four row tiles per wavefront, streamed operator tiles)",
-                                        **leg_counters("very_large_system", vB * vit / (med * 1e-3))}
-            vbig.reset()
-            # BASELINE config 1: cartpole nx=4 nu=1 N=20, box input constraints, 200 ADMM iterations -- one instance (the reference's
-            # example as it stands) and a batch of 8,192 (layout D's compiled-in cartpole shape)
-            cp = P.cartpole(20, True)
-            cart = {}
-            for cB in (1, 8192):
-                cs = pkg.TinyMPC()
-                cs.setup(cp.A, cp.B, cp.Q, cp.R, cp.N, batch=cB, device=dev_index, rho=cp.rho, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=200)
-                cs.set_bound_constraints(cp.x_min, cp.x_max, cp.u_min, cp.u_max)
-                if cB == 1:
-                    cs.set_x0(cp.x0)
-                else:
-                    cs.set_x0_batch(np.asfortranarray(cp.x0[:, None] * np.linspace(0.5, 1.5, cB)[None, :]))
-                ms = []
-                for k in range(6):
-                    cs.reset_workspace()
-                    ms.append(cs.solve_timed())
-                med = sorted(ms[1:])[2]
-                key = "one_instance" if cB == 1 else "batch_8192"
-                cart[key] = {"kernel_ms": med, "iters_per_s": cB * 200 / (med * 1e-3), "us_per_iter": 1e3 * med / 200 if cB == 1 else None,
-                             **({"cpu_reference_us_per_iter": cpu.get("cartpole_us_per_iter_single_process") if cpu else None} if cB == 1 else {}),
-                             "layout": cs.launch_info()["layout"], "fp64_frac": cB * 200 * cp.flops_per_iteration() / (med * 1e-3) / 1e12 / PEAK_FP64_TFLOPS}
-                cs.reset()
-            out["cartpole"] = dict(workload="BASELINE config 1: cartpole nx=4 nu=1 N=20, box input constraints, 200 forced iterations", **cart)
-            # Closed-loop tick (examples/cartpole_example_mpc.m:36-44 on the quadrotor): x0 in -> warm-started solve -> first
-            # controls out, tol 1e-3, 200 ticks of the same trajectory, (a) one launch per tick, (b) resident session kernel.
-            # (Mean, median and maximum of the 200 timed ticks: one tick in a few thousand takes milliseconds -- 41 ms once in this
-            # file's run -- and moves the mean of 200 by a factor of ten. tools/tick_outliers.py (20,000 ticks, the library's own
-            # split per outlier via tinympc_debug_tick_timing): the launch call and the wait of such a tick are the usual
-            # 5 + 18 us; the time goes to the calling thread being descheduled, outside the library.)
-            tick = {}
-            for mode in ("launch", "session"):
-                tk = pkg.TinyMPC()
-                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
-                tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-                if mode == "session":
-                    tk.session_begin()
-                x = prob.x0.copy()
-                t_acc, its, dts, slow = 0.0, 0, [], []
-                import ctypes as _C
-                _L = pkg.load_library()
-                _L.tinympc_debug_tick_timing.restype = _C.c_int
-                _L.tinympc_debug_tick_timing.argtypes = [_C.c_void_p, _C.POINTER(_C.c_double)]
-                split = (_C.c_double * 4)()
-                for k in range(220):
-                    t0 = time.perf_counter()
-                    u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
-                    dt = time.perf_counter() - t0
-                    if k >= 20:
-                        t_acc += dt
-                        dts.append(dt)
-                        its += int(tk.get_stats()["iter"])
-                        if dt > 1e-3 and mode == "launch" and len(slow) < 4:  # where did a millisecond tick spend its time?
-                            _L.tinympc_debug_tick_timing(tk._h, split)
-                            slow.append({"tick": k, "us": 1e6 * dt, "library_launch_call_us": split[0], "library_wait_us": split[1],
-                                         "polls": int(split[2]), "polling_budget_ran_out": bool(split[3])})
-                    x = prob.A @ x + prob.B @ u0
-                # ... and the same 200 ticks driven from C (tinympc_bench_closed_loop: no Python call inside a tick) -- how the reference
-                # core beside it is timed too (oracle/ref_shim.cpp: ref_bench_closed_loop)
-                cl = tk.bench_closed_loop(prob.A, prob.B, prob.x0, 220, 20, session=(mode == "session"))
-                if mode == "session":
-                    tk.session_end()
-                tick[mode] = {"us_per_tick": 1e6 * t_acc / 200, "us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick_max": 1e6 * float(np.max(dts)),
-                              "tick_us": stats_us(1e6 * np.asarray(dts)), "iterations_per_tick": its / 200,
-                              "c_loop": dict({k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")},
-                                             tick_us=stats_us(cl["tick_us"]))}
-                if slow:
-                    tick[mode]["ticks_above_1ms"] = slow
-                tk.reset()
-            # ... and the reference's own three verbs per tick (set_x0 + solve + get_solution, the whole solution copied out) from the same C
-            # loop: launched solves (what a script written against the reference gets as it stands) and RESIDENT solves (one extra line,
-            # tinympc_set_resident: the same verbs on the resident session kernel)
-            for mode in ("verbs_launched", "verbs_resident"):
-                tk = pkg.TinyMPC()
-                tk.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, device=dev_index, rho=prob.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
-                tk.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-                if mode == "verbs_resident":
-                    tk.set_resident(True)
-                cl = tk.bench_closed_loop(prob.A, prob.B, prob.x0, 220, 20, session="verbs")
-                tick[mode] = {"c_loop": dict({k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")}, tick_us=stats_us(cl["tick_us"]))}
-                tk.reset()
-            # The SAME statistics on both sides (round 5): mean, median, p90, max of the 200 per-tick samples -- the GPU's from
-            # libtinympc_bench.so's C loop, the reference core's from oracle/ref_shim.cpp's (ref_bench_closed_loop_samples)
-            cref = (cpu or {}).get("closed_loop_tick_us_single_process") or {}
-            tick["cpu_reference_tick_us"] = cref or None
-            tick["cpu_reference_us_per_tick"] = cref.get("mean")
-            tick["cpu_reference_us_per_tick_median"] = cref.get("median")
-            tick["cpu_reference_iterations_per_tick"] = cpu.get("closed_loop_iterations_per_tick") if cpu else None
-            tick["cpu_reference_note"] = ("the reference's own core (oracle/_ref) on one host core: set_x0 + solve + first control per tick, the loop in "
-                                          "compiled code; no MATLAB / MEX overhead on its side. Like against like: c_loop.tick_us.{mean,median} against "
-                                          "cpu_reference_tick_us.{mean,median} (both loops in C); the Python-mirror numbers carry ctypes calls the host side does not")
-            if cref:
-                for mode in ("launch", "session", "verbs_launched", "verbs_resident"):
-                    g_ = tick[mode]["c_loop"]["tick_us"]
-                    tick[mode]["c_loop"]["gpu_over_cpu_time"] = {"mean": g_["mean"] / cref["mean"], "median": g_["median"] / cref["median"]}
-            # ... and BASELINE config 4's own closed loop (rocket_landing_constraints.m:86-121): N = 100, cones + linear row + fdyn, the
-            # reference trajectory re-sent every tick (a receding horizon: inside a session only its new last column travels)
-            rk = P.rocket(100)
-            goal = np.zeros(rk.nx)
-            rtick = {}
-            for mode in ("launch", "session"):
-                tk = pkg.TinyMPC()
-                tk.setup(rk.A, rk.B, rk.Q, rk.R, rk.N, batch=1, device=dev_index, rho=rk.rho, fdyn=rk.fdyn, abs_pri_tol=5e-2, abs_dua_tol=5e-2, max_iter=200)
-                tk.set_bound_constraints(rk.x_min, rk.x_max, rk.u_min, rk.u_max)
-                tk.set_u_ref(rk.u_ref)
-                tk.set_cone_constraints(**rk.cones)
-                tk.set_linear_constraints(**rk.linear)
-                tk.set_x_ref(rk.x_ref)
-                tk.prepare()
-                layout = tk.launch_info()["layout"]
-                if mode == "session":
-                    tk.session_begin()
-                x = rk.x0.copy()
-                dts, its = [], 0
-                for k in range(110):
-                    x_ref = np.stack([rk.x0 + (goal - rk.x0) * min(i + k, 140) / 140 for i in range(rk.N)], axis=1)
-                    t0 = time.perf_counter()
-                    tk.set_x_ref(x_ref)
-                    u0 = tk.session_step(x) if mode == "session" else tk.mpc_step(x)[:, 0]
-                    dt = time.perf_counter() - t0
-                    if k >= 10:
-                        dts.append(dt)
-                        its += int(tk.get_stats()["iter"])
-                    x = rk.A @ x + rk.B @ u0 + rk.fdyn
-                if mode == "session":
-                    tk.session_end()
-                rtick[mode] = {"us_per_tick_median": 1e6 * float(np.median(dts)), "us_per_tick": 1e6 * float(np.mean(dts)), "tick_us": stats_us(1e6 * np.asarray(dts)),
-                               "iterations_per_tick": its / 100, "layout": layout}
-                tk.reset()
-            # (like against like, round 5: both sides time set_x_ref + tick per tick through Python calls of their C libraries and quote the
-            # same statistics of the same 100 ticks; the early ticks are long -- 38 iterations on average -- so mean and median differ 2x)
-            rref = (cpu or {}).get("rocket_closed_loop_tick_us_single_process") or {}
-            rtick["cpu_port_tick_us"] = rref or None
-            rtick["cpu_port_us_per_tick"] = rref.get("mean")
-            rtick["cpu_port_us_per_tick_median"] = rref.get("median")
-            rtick["cpu_port_iterations_per_tick"] = cpu.get("rocket_closed_loop_iterations_per_tick") if cpu else None
-            if rref:
-                for mode in ("launch", "session"):
-                    rtick[mode]["cpu_over_gpu_time"] = {"mean": rref["mean"] / rtick[mode]["tick_us"]["mean"], "median": rref["median"] / rtick[mode]["tick_us"]["median"]}
-            out["rocket_closed_loop"] = dict(workload="rocket landing N=100, cones + linear row + fdyn, one instance, warm start, tol 5e-2, the reference trajectory "
-                                                      "re-sent every tick, 100 ticks (set_x_ref + tick, through the Python mirror)", **rtick)
-            out["closed_loop_tick"] = dict(workload="quadrotor N=%d, one instance, warm start, tol 1e-3, 200 ticks through the Python mirror of the C ABI" % prob.N, **tick)
+            instance_and_family_legs(ctx)
+            shape_and_latency_legs(ctx)
         if world == 1 and not args.no_round5_legs:
             out["setup"] = setup_leg(pkg, cpu)
             out["batched_tick"] = batched_tick_leg(pkg, cpu, dev_index)
