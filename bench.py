@@ -650,7 +650,7 @@ def main() -> int:
                 "rocket_batch_N100_iters_per_s": leg("rocket_batch/N=100/iters_per_s"), "rocket_batch_N100_fp64_frac": leg("rocket_batch/N=100/fp64_frac"),
                 "rocket_batch_N10_iters_per_s": leg("rocket_batch/N=10/iters_per_s"),
                 "adaptive_rho_batch_iters_per_s": leg("adaptive_rho_batch/iters_per_s"), "adaptive_rho_batch_fp64_frac_box_part": leg("adaptive_rho_batch/fp64_frac_box_part"),
-                "wide_system_fp64_frac": leg("wide_system/fp64_frac"), "long_horizon_fp64_frac": leg("long_horizon/fp64_frac"),
+                "wide_system_fp64_frac": leg("wide_system/fp64_frac"), "wide_system_with_families_kernel_ms": leg("wide_system/with_families/kernel_ms"), "long_horizon_fp64_frac": leg("long_horizon/fp64_frac"),
                 "large_system_fp64_frac": leg("large_system/fp64_frac"), "large_system_with_families_iters_per_s": leg("large_system/with_families/iters_per_s"), "large_system_hbm_measured_frac": leg("large_system/hbm_measured_frac"),
                 "very_large_system_fp64_frac": leg("very_large_system/fp64_frac"),
                 "cartpole_one_instance_us_per_iter": leg("cartpole/one_instance/us_per_iter"), "cartpole_cpu_reference_us_per_iter": leg("cpu_baseline/cartpole_us_per_iter_single_process"),

@@ -90,6 +90,7 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     constexpr size_t kLdsMax = 160 * 1024;
     // Horizons whose state does not fit a CU's LDS run the same kernels on an HBM working copy (GMEM variant).
     s->state_in_global = !large && without > kLdsMax;
+    if (const char *e = getenv("TINYMPC_STATE_GLOBAL")) s->state_in_global = !large && (e[0] == '1' || s->state_in_global);  // (experiments: the HBM working copy also where LDS would hold the state)
     // Two workgroups per CU need <= 80 KB each; prefer LDS tables whenever they do not cost a workgroup slot.
     const size_t slots_without = s->state_in_global ? 0 : kLdsMax / without;
     const size_t slots_with = kLdsMax / with_tables;

@@ -54,7 +54,10 @@ void decide_layout_d_variants(tinympc_solver *s) {
             e_uncut = solve_e_plan(s->nx, s->nu, s->N, s->tables_const(), true, fsd, nullptr, &wpg, nullptr, nullptr) && wpg == 1 &&
                       solve_e_supported(s->nx, s->nu, s->N, s->tables_const(), true, fsd);
         }
-        s->d_fam = (!e_uncut && s->W == 16 && fsd.nround <= 1 && !fsd.beyond_generic() && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+        if (s->W == 16)
+            s->d_fam = (!e_uncut && fsd.nround <= 1 && !fsd.beyond_generic() && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
+        else  // (round 5) wide systems: the families streamed from HBM next to the register-resident box sweeps; rounds are walked there
+            s->d_fam = (!s->layout_m && !fsd.beyond_generic() && fsd.nround <= MAX_ROUNDS && solve_jit_supported(s->W, s->nx, s->nu, s->N, s->tables_const(), true)) ? 1 : 0;
     }
 }
 

@@ -15,11 +15,20 @@
 //   fwd_head(op, m, cf) -> a                   a = cf + the first blocks of the chain
 //   fwd_tail_reg / fwd_tail_lds(a, op, ...)    the last block + the row-local phase (slack in a register / in LDS)
 //   bwd(a, op, ...), bwd_last(a, op, m)        the backward step (+ the tail that prepares the next ones)
+//
+// FAM (round 5, run-time specialised only): the cone / linear-inequality families on wide systems, STREAMED. Their duals gc | gl and the
+// linear-cost term lx do not fit next to the box path's state (three more arrays of the slack's size: registers are full, LDS would hold
+// them for one wavefront in four), so they stay in HBM / L2 in V's layout: the forward sweep reads a slot's duals WIDE_FAM_AHEAD steps
+// ahead of its use (a ring of registers), evaluates the element with the group-reduction form of tinympc_fam_red.h between two chain
+// blocks, and stores the new duals and lx; the backward sweep reads lx back the same way, descending. Before this variant the families on
+// 32 / 64 lanes ran on k_admm_solve_fam (layout A: state in LDS, ONE wavefront per SIMD): 9.1 ms where the box path takes 1.2 (nx=24,
+// nu=8, N=30 x 4,096, one cone + two linear rows; tools/wide_families_probe.py).
 #pragma once
 #include <type_traits>
 
 #include "tinympc_device.h"
 #include "tinympc_sweep.h"
+#include "tinympc_fam_red.h"
 
 namespace tinympc {
 
@@ -43,6 +52,19 @@ constexpr int WIDE_GROUP = 8;        // forward steps between two "can this swee
 constexpr int WIDE_FIRST = 8;        // ... and before the first one inside the sweep (after the one on knot 0)
 #endif
 constexpr int WIDE_LDS_PER_CU = 160 * 1024;
+#ifdef TINY_WIDE_FAM_AHEAD
+constexpr int WIDE_FAM_AHEAD = TINY_WIDE_FAM_AHEAD;  // (experiments)
+#else
+constexpr int WIDE_FAM_AHEAD = 4;    // FAM: sweep steps between the request of a slot's duals / lx and their use
+#endif
+#ifdef TINY_WIDE_FAM_BATCH
+constexpr int WIDE_FAM_BATCH = TINY_WIDE_FAM_BATCH;  // (experiments)
+#else
+constexpr int WIDE_FAM_BATCH = 4;    // FAM: slots whose families are evaluated together (measured 1 .. 6: profiles/r05_wide_families.txt)
+#endif
+#ifndef TINY_WIDE_FAM_FENCE
+#define TINY_WIDE_FAM_FENCE 1        // FAM: scheduling fences around a step's families block (experiments: 0)
+#endif
 // ---- LDS plan per workgroup, in doubles: operators [2][W k][W r] | tables (!ct) | per wave: V[VL][64], D[(N-1) * (64 / W) * nu]
 __host__ __device__ constexpr int wide_ops_doubles(int W) { return 2 * W * W; }
 __host__ __device__ constexpr int wide_d_doubles(int W, int nu, int N) { return ((N - 1) * (64 / W) * nu + 1) & ~1; }
@@ -60,6 +82,10 @@ __host__ __device__ constexpr int wide_vl(int W, int vreg_max, int nu, int N, bo
 __host__ __device__ constexpr size_t wide_lds_bytes(int W, int nu, int N, bool ct, int wpg, int vl) {
     return sizeof(double) * ((size_t)wide_ops_doubles(W) + (ct ? 0 : wide_tab_doubles(W, N)) + (size_t)wpg * (vl * 64 + wide_d_doubles(W, nu, N)));
 }
+
+// FAM: the workgroup's LDS copy of the linear rows (behind everything else): nl | per row k: a_k[W] | b_k[W] | 1 / ||a_k||^2 [W] -- the family
+// buffer's own layout (tinympc_handle.hip: refresh_families) with the RECIPROCAL of the norm, so that a sweep step neither waits for L2 nor divides
+__host__ __device__ constexpr size_t wide_fam_lin_doubles(int W) { return (size_t)2 + (size_t)3 * MAX_LIN_ROWS * W; }
 
 typedef __attribute__((address_space(3))) double lds_double_w;
 __device__ __forceinline__ unsigned lds_addr_w(const double *p) { return (unsigned)(size_t)(const lds_double_w *)p; }
@@ -103,7 +129,7 @@ __device__ __forceinline__ bool wave_may_converge_w(unsigned long long bad, unsi
 }
 }  // namespace
 
-template <int W, int NX, int NU, int N, bool CT, int WPG, int VL>
+template <int W, int NX, int NU, int N, bool CT, int WPG, int VL, bool FAM = false>
 __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, double *smem) {
     constexpr int IPW = 64 / W, NXU = NX + NU, NS = N - 1, DS = IPW * NU, NVR = NS - VL;
     constexpr int KT = W;  // row stride of p.ops (choose_geometry)
@@ -183,6 +209,30 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
     const double *const sMf = sOps + r, *const sMb = sOps + W * W + r;
     const unsigned aV = lds_addr_w(sVl), aD = lds_addr_w(sDr), aT = lds_addr_w(sTl);
     const int ct = p.check_termination;
+    // FAM: the families' evaluation (group reductions) and the HBM arrays of their duals / linear-cost term, slot s <-> row s + koff like V
+    RedFamilies<W> fam;
+    constexpr int FB = WIDE_FAM_BATCH;                                                                 // slots whose families are evaluated together
+    constexpr int PD0 = (WIDE_FAM_AHEAD > FB ? WIDE_FAM_AHEAD : FB), PD = (PD0 < NS) ? PD0 : NS;      // ring depth (>= a batch: its duals are all in the ring)
+    // (wave-uniform bases in SGPRs + ONE 32-bit per-lane offset, `voff` = lane + koff * 64, for every row of the three arrays: with per-lane
+    // 64-bit pointers the compiler kept an address pair per (array, row) -- 170 VGPRs -- and the kernel spilled)
+    double *const bGC = FAM ? p.GC + (g0 * v_rows(N) + V_PAD) * 64 : nullptr;
+    double *const bGL = FAM ? p.GL + (g0 * v_rows(N) + V_PAD) * 64 : nullptr;
+    double *const bLX = FAM ? p.LX + (g0 * v_rows(N) + V_PAD) * 64 : nullptr;
+    if constexpr (FAM) {
+        // (the rows' coefficients: staged into LDS once, reciprocal norms computed here; every wavefront of the workgroup stages the same
+        // values -- no barrier needed beyond the wavefront's own program order... but other wavefronts read them too: written identically)
+        double *const sLinW = smem + wide_lds_bytes(W, NU, N, CT, WPG, VL) / sizeof(double);
+        const double *const gl = p.fam + 4 * W + (size_t)3 * W * KT;
+        const int nl_ = (int)gl[0];
+        for (int i = lane; i < 1 + 3 * nl_ * W; i += 64) {
+            double v = gl[i];
+            if (i >= 1 && ((i - 1) / W) % 3 == 2) v = 1.0 / v;  // 1 / ||a_k||^2
+            sLinW[i] = v;
+        }
+        lds_wait_w();  // (this wavefront's LDS writes have landed before its first read)
+        fam.init(p.fam, NXU, r, is_x, is_u, rho, sLinW);
+    }
+    const bool row_real = r < NXU;
 
     // Control: an instance that converges stops being `active` but its lanes keep iterating as a zombie (the sweeps are
     // unconditional for all 64 lanes -- no EXEC-masked region around the unrolled body). Its state is written back at
@@ -272,6 +322,22 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
             if (may && is_x && active) gV1u[(unsigned)lane] = V0;  // (active: as for the slots below)
             V0 = snew;
         }
+        // FAM: the first WIDE_FAM_AHEAD slots' duals are requested now, knot 0 of the state rows is evaluated while they travel (its lx only
+        // reaches p_0, which nothing reads; the duals persist)
+        double gcr[FAM ? PD : 1], glr[FAM ? PD : 1], xel[FAM ? FB : 1];
+        if constexpr (FAM) {
+            const double gc0 = bGC[(unsigned)lane], gl0 = bGL[(unsigned)lane];
+            static_for_w<0, PD>([&](auto Q) {
+                gcr[Q.value] = (bGC + Q.value * 64)[voff];
+                glr[Q.value] = (bGL + Q.value * 64)[voff];
+            });
+            double gcn, gln;
+            (void)fam.eval(x0v, gc0, gl0, gcn, gln);
+            if (is_x && active) {
+                bGC[(unsigned)lane] = gcn;
+                bGL[(unsigned)lane] = gln;
+            }
+        }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
         // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
         // PREVIOUS step's block and retired by that block's trailing s_waitcnt.
@@ -306,6 +372,45 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
                 lds_write_async_w<q * 512>(aV, vnew);
             }
             xcur = a;
+            if constexpr (FAM) {  // xcur: x_{q+1} on state lanes, u_q on input lanes -- this slot's element
+                // The element waits in a small batch: the families of WIDE_FAM_BATCH slots are evaluated TOGETHER, as independent instruction
+                // streams in one block -- a lone wavefront per SIMD (the variant's 470 registers) waits ~8 cycles for every dependent FP64
+                // result and ~100 for every cross-row exchange of a reduction; with several elements in flight those waits overlap.
+                xel[q % FB] = xcur;
+                if constexpr ((q % FB) == FB - 1 || q == NS - 1) {
+                    constexpr int q0 = q - (q % FB);
+                    if constexpr (TINY_WIDE_FAM_FENCE != 0) __builtin_amdgcn_sched_barrier(0);
+                    double gco[FB], glo[FB], gcn[FB], gln[FB], lxn[FB];
+                    static_for_w<q0, q + 1>([&](auto T) {  // take the batch's duals out of the ring and request the next ones BEFORE the evaluation:
+                        constexpr int t = decltype(T)::value;  // they travel while it runs
+                        gco[t - q0] = gcr[t % PD];
+                        glo[t - q0] = glr[t % PD];
+                        if constexpr (t + PD < NS) {
+                            gcr[t % PD] = (bGC + (t + PD) * 64)[voff];
+                            glr[t % PD] = (bGL + (t + PD) * 64)[voff];
+                        }
+                    });
+                    if constexpr (q - q0 + 1 == FB) {
+                        double xb[FB];
+                        static_for_w<0, FB>([&](auto T) { xb[T.value] = xel[(q0 + T.value) % FB]; });
+                        fam.template eval_batch<FB>(xb, gco, glo, gcn, gln, lxn);
+                    } else {  // (the sweep's last, shorter batch)
+                        static_for_w<q0, q + 1>([&](auto T) {
+                            constexpr int t = decltype(T)::value;
+                            lxn[t - q0] = fam.eval(xel[t % FB], gco[t - q0], glo[t - q0], gcn[t - q0], gln[t - q0]);
+                        });
+                    }
+                    static_for_w<q0, q + 1>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        if (active && row_real) {  // (a zombie's duals stay what they were when it converged)
+                            (bGC + t * 64)[voff] = gcn[t - q0];
+                            (bGL + t * 64)[voff] = gln[t - q0];
+                            (bLX + t * 64)[voff] = lxn[t - q0];
+                        }
+                    });
+                    if constexpr (TINY_WIDE_FAM_FENCE != 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             dcur = dn;
             vcur = vn;
             if constexpr (!CT) {
@@ -360,14 +465,31 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
         {
             const unsigned long long wr_d = __ballot(is_u && active);  // a zombie keeps the d of its last real iteration
             load_ops(sMb, m);
-            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type)
-                if constexpr (CT) return lr_c;
-                else return sTl[2 * TOFF + (S.value + 1) * W];
+            // FAM: the families' term of a slot's linear cost, read back from HBM in the order the sweep consumes it -- slots NS-1, NS-2 (the
+            // head), then NS-3 ... 0 -- through a ring requested WIDE_FAM_AHEAD slots ahead (this wavefront stored them in its forward sweep:
+            // same lane, same address, program order)
+            double lxr[FAM ? PD : 1];
+            if constexpr (FAM) static_for_w<0, PD>([&](auto Q) { lxr[Q.value] = (bLX + (NS - 1 - Q.value) * 64)[voff]; });
+            auto lx_of = [&](auto S) -> double {  // (every slot exactly once, descending; slot 0 a second time for the last block, whose tail is unused)
+                constexpr int sl = decltype(S)::value, idx = (NS - 1 - sl) % PD;
+                const double v = lxr[idx];
+                if constexpr (sl - PD >= 0) lxr[idx] = (bLX + (sl - PD) * 64)[voff];
+                return v;
+            };
+            auto lr_of = [&](auto S) -> double {  // linref of slot S (its knot differs by lane type) (+ the families' term)
+                double base;
+                if constexpr (CT) base = lr_c;
+                else base = sTl[2 * TOFF + (S.value + 1) * W];
+                return base;
             };
             double px, rcur, rnext, acc;
             {   // p_{N-1} (state lanes, admm.cpp:81-82) | r_{N-2} (input lanes) share slot NS-1; then slot NS-2
-                const double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
-                const double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
+                double lrT = is_x ? pnref : lr_of(std::integral_constant<int, NS - 1>{});
+                double lr2 = lr_of(std::integral_constant<int, NS - 2>{});
+                if constexpr (FAM) {
+                    lrT += lx_of(std::integral_constant<int, NS - 1>{});
+                    lr2 += lx_of(std::integral_constant<int, NS - 2>{});
+                }
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 const double v1 = vget(std::integral_constant<int, NS - 1>{}), v2 = vget(std::integral_constant<int, NS - 2>{});
                 double t;
@@ -396,7 +518,8 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
                 // the block's outputs while the read is still in flight)
                 double v2n = 0.0;
                 if constexpr (s >= 2) v2n = vreq(std::integral_constant<int, s3>{});
-                const double lr2 = lr_of(std::integral_constant<int, s2>{});
+                double lr2 = lr_of(std::integral_constant<int, s2>{});
+                if constexpr (FAM && s >= 2 && s <= NS - 1 && (s - 2) <= NS - 3) lr2 += lx_of(std::integral_constant<int, s2>{});  // (s = 1: the tail it feeds is unused)
                 const double lrmc2 = is_x ? lr2 + cb : cb;
                 double a = acc, an, rn;
                 typename Step::Operand op;

@@ -95,8 +95,15 @@ tinympc_jit_solve(const tinympc::SolveParams p) {
     constexpr int WPGJ = TINY_JIT_WPG;      // wavefronts per workgroup (4, or 8 where only that LDS plan fits)
     constexpr int VLJ = tinympc::wide_vl(64, tinympc::DX_VREG_MAX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, 4 * TINY_JIT_WPS);
     static_assert(VLJ >= 0, "shape does not fit the layout-D plan");
-    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::wide_lds_bytes(64, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double)];
-    tinympc::k_admm_solve_wide_body<64, TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ>(p, smem_jit);
+#ifndef TINY_JIT_FAM
+#define TINY_JIT_FAM 0
+#endif
+    __shared__ __attribute__((aligned(16))) double smem_jit[tinympc::wide_lds_bytes(64, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ) / sizeof(double) +
+                                                            (TINY_JIT_FAM != 0 ? tinympc::wide_fam_lin_doubles(64) : 0)];
+#ifndef TINY_JIT_FAM
+#define TINY_JIT_FAM 0
+#endif
+    tinympc::k_admm_solve_wide_body<64, TINY_JIT_NX, TINY_JIT_NU, TINY_JIT_N, CTJ, WPGJ, VLJ, TINY_JIT_FAM != 0>(p, smem_jit);  // (FAM: the streamed families, tinympc_solve_dwide.h)
 }
 #else
 template <int NX, int NU, int N, int WPG, int VL>

@@ -430,6 +430,17 @@ def shape_and_latency_legs(ctx) -> None:
                           "iters_per_s": wB * wit / (med * 1e-3), "kernel_ms": med, "fp64_tflops": wtf, "fp64_frac": wtf / PEAK_FP64_TFLOPS,
                           "lanes_per_instance": wide.launch_info()["lanes_per_instance"], "layout": wide.launch_info()["layout"],
                           **leg_counters("wide_system", wB * wit / (med * 1e-3))}
+    # ... and the same system with one state cone and two linear rows on the states (round 5: the families STREAMED next to layout D's wide sweeps,
+    # tinympc_solve_dwide.h; round 4: k_admm_solve_fam, layout A)
+    wide.set_cone_constraints(Acx=[0], qcx=[3], cx=[0.7], Acu=[], qcu=[], cu=[])
+    wide.set_linear_constraints(Alin_x=np.random.default_rng(1).standard_normal((2, wnx)), blin_x=np.array([1.0, 1.5]), Alin_u=np.zeros((0, wnu)), blin_u=np.zeros(0))
+    fms = []
+    for k in range(6):
+        wide.reset_workspace()
+        fms.append(wide.solve_timed())
+    fmed = sorted(fms[1:])[2]
+    out["wide_system"]["with_families"] = {"workload": "+ one state cone, two linear rows on the states", "kernel_ms": fmed, "iters_per_s": wB * wit / (fmed * 1e-3),
+                                           "layout": wide.launch_info()["layout"], "jit": wide.jit_info(), "fraction_of_box_rate": med / fmed}
     wide.reset()
     # Long horizon: the quadrotor at N = 100. The duals of 99 knots do not fit 256 registers, so layout D runs its second
     # plan (one wavefront per SIMD with all 512 registers; the kernel is specialised at run time by tinympc_jit.hip).
