@@ -219,11 +219,21 @@ int tinympc_setup_batch(tinympc_solver **out, const double *A, const double *B, 
     for (int i = 0; i < nx; ++i) uQd[i] = Q[i + (size_t)i * nx] + rho;
     for (int i = 0; i < nu; ++i) uRd[i] = R[i + (size_t)i * nu] + rho;
     std::memcpy(uQ, Q, sizeof(double) * nx * nx); std::memcpy(uR, R, sizeof(double) * nu * nu);
-    HIP_TRY_S(hipMemcpyAsync(s->dA, s->h_stage, upload_bytes, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY_S(hipMemsetAsync(static_cast<char *>(s->arena_dev) + zero_begin, 0, zero_end - zero_begin, s->stream));
-    if (s->d_mail) HIP_TRY_S(hipMemsetAsync(s->d_mail, 0, sizeof(double) * 64, s->stream));
-    HIP_TRY_S(launch_fill_bounds(s->dxmin, s->dxmax, X, s->dumin, s->dumax, U, kBoundInf, s->stream));  // TinyMPC.m:261-264
-    HIP_TRY_S(launch_reset_stats(s->distats, s->ddstats, s->drho_inst, batch, rho, s->stream));
+    if (zero_end - zero_begin <= ((size_t)1 << 20)) {
+        // a small handle: ONE launch does the upload (reading the pinned staging copy itself), the zeroing, the fills (k_setup_init)
+        SetupInitParams ip{};
+        ip.stage = s->h_stage; ip.upload_dst = s->dA; ip.upload_doubles = upload_bytes / sizeof(double);
+        ip.zero = reinterpret_cast<double *>(static_cast<char *>(s->arena_dev) + zero_begin); ip.zero_doubles = (zero_end - zero_begin) / sizeof(double);
+        ip.xmin = s->dxmin; ip.xmax = s->dxmax; ip.umin = s->dumin; ip.umax = s->dumax; ip.X = X; ip.U = U; ip.inf = kBoundInf;  // TinyMPC.m:261-264
+        ip.rho_inst = s->drho_inst; ip.batch = batch; ip.rho = rho; ip.mail = s->d_mail;
+        HIP_TRY_S(launch_setup_init(ip, s->stream));
+    } else {
+        HIP_TRY_S(hipMemcpyAsync(s->dA, s->h_stage, upload_bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY_S(hipMemsetAsync(static_cast<char *>(s->arena_dev) + zero_begin, 0, zero_end - zero_begin, s->stream));
+        if (s->d_mail) HIP_TRY_S(hipMemsetAsync(s->d_mail, 0, sizeof(double) * 64, s->stream));
+        HIP_TRY_S(launch_fill_bounds(s->dxmin, s->dxmax, X, s->dumin, s->dumax, U, kBoundInf, s->stream));  // TinyMPC.m:261-264
+        HIP_TRY_S(launch_reset_stats(s->distats, s->ddstats, s->drho_inst, batch, rho, s->stream));
+    }
     s->setup_us[3] = us_since(t_phase); t_phase = clk::now();
     TRY(run_precompute(s));  // tiny_api.cpp:113
     s->setup_us[4] = us_since(t_phase); t_phase = clk::now();

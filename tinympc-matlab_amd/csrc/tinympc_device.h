@@ -318,6 +318,21 @@ hipError_t launch_precompute_rows(const PrecomputeParams &p, hipStream_t stream)
 hipError_t launch_lqr(const LqrParams &p, hipStream_t stream);
 hipError_t launch_finite_diff(const FiniteDiffParams &p, hipStream_t stream);
 hipError_t launch_fill(double *dst, size_t count, double value, hipStream_t stream);  // asynchronous constant fill
+struct SetupInitParams {  // k_setup_init: everything a small handle's setup puts into device memory before k_precompute
+    const double *stage;  // pinned host: the problem data in the device arena's upload-span layout
+    double *upload_dst;
+    size_t upload_doubles;
+    double *zero;         // the zero-initialised span (references, x0, G, V, V2, D, solutions, statistics ...)
+    size_t zero_doubles;
+    double *xmin, *xmax, *umin, *umax;
+    size_t X, U;
+    double inf;
+    double *rho_inst;
+    int batch;
+    double rho;
+    double *mail;         // the session's device-side mailbox (or NULL)
+};
+hipError_t launch_setup_init(const SetupInitParams &p, hipStream_t stream);
 hipError_t launch_fill_bounds(double *xmin, double *xmax, size_t X, double *umin, double *umax, size_t U, double inf, hipStream_t stream);
 hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int batch, double rho, hipStream_t stream);
 size_t lqr_scratch_doubles(int nx, int nu);

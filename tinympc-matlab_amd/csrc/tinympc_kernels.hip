@@ -415,6 +415,28 @@ hipError_t launch_reset_stats(int *istats, double *dstats, double *rho_inst, int
     return hipGetLastError();
 }
 
+// Setup of a SMALL handle in ONE launch (round 5): the problem data from its pinned staging copy into the device arena (the kernel reads host
+// memory itself: no copy-engine hop), the zero-initialised span, the bounds' +-1e17, the per-instance statistics and rho, the session's mailbox
+// -- five stream operations (copy, two memsets, two fills) of ~3-5 us each in front of k_precompute.
+__global__ void __launch_bounds__(256) k_setup_init(const SetupInitParams p) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    for (size_t i = tid; i < p.upload_doubles; i += nth) p.upload_dst[i] = p.stage[i];
+    for (size_t i = tid; i < p.zero_doubles; i += nth) p.zero[i] = 0.0;
+    for (size_t i = tid; i < p.X + p.U; i += nth) {
+        if (i < p.X) { p.xmin[i] = -p.inf; p.xmax[i] = p.inf; }
+        else { p.umin[i - p.X] = -p.inf; p.umax[i - p.X] = p.inf; }
+    }
+    for (size_t i = tid; i < (size_t)p.batch; i += nth) p.rho_inst[i] = p.rho;  // (iteration counts, statuses, residuals: inside the zeroed span)
+    if (p.mail)
+        for (size_t i = tid; i < 64; i += nth) p.mail[i] = 0.0;
+}
+hipError_t launch_setup_init(const SetupInitParams &p, hipStream_t stream) {
+    const size_t work = p.zero_doubles > p.upload_doubles ? p.zero_doubles : p.upload_doubles;
+    const size_t blocks = (work + 255) / 256;
+    hipLaunchKernelGGL(k_setup_init, dim3((unsigned)(blocks < 256 ? (blocks ? blocks : 1) : 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 // Setup: the four bound arrays <- -inf / +inf (TinyMPC.m:261-264's 1e17) in ONE launch
 __global__ void __launch_bounds__(256) k_fill_bounds(double *xmin, double *xmax, size_t X, double *umin, double *umax, size_t U, double inf) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < X + U; i += (size_t)gridDim.x * 256) {
