@@ -350,6 +350,7 @@ def cpu_baseline(iters: int, horizon: int, seconds: float, round5: bool = True) 
             "closed_loop_tick_us_single_process": lat.get("closed_loop_tick_us"),
             "closed_loop_iterations_per_tick": lat.get("closed_loop_iterations_per_tick"),
             "setup_us": lat.get("setup_us"), "batched_ticks": batched,
+            "latency_extra": {k: lat.get(k) for k in ("cartpole10_closed_loop_tick_us", "cartpole10_closed_loop_iterations_per_tick")},
             "unit": "ADMM iters/s", "cores": len(rates),
             "effective_parallelism": eff, "affinity_cpus": len(cpus), "cgroup_quota": quota, "cgroup_quota_source": quota_src,
             "cores_logical": os.cpu_count(), "cores_physical": physical, "kind": kind,
@@ -660,6 +661,8 @@ def main() -> int:
                 "closed_loop_tick_session_c_loop_us_mean": leg("closed_loop_tick/session/c_loop/tick_us/mean"), "closed_loop_tick_session_c_loop_us_median": leg("closed_loop_tick/session/c_loop/tick_us/median"),
                 "closed_loop_tick_verbs_launched_us_mean": leg("closed_loop_tick/verbs_launched/c_loop/tick_us/mean"), "closed_loop_tick_verbs_launched_us_median": leg("closed_loop_tick/verbs_launched/c_loop/tick_us/median"),
                 "closed_loop_tick_verbs_resident_us_mean": leg("closed_loop_tick/verbs_resident/c_loop/tick_us/mean"), "closed_loop_tick_verbs_resident_us_median": leg("closed_loop_tick/verbs_resident/c_loop/tick_us/median"),
+                "cartpole_N10_session_c_loop_us_mean": leg("closed_loop_tick/cartpole_N10_session/c_loop/tick_us/mean"), "cartpole_N10_session_c_loop_us_median": leg("closed_loop_tick/cartpole_N10_session/c_loop/tick_us/median"),
+                "cartpole_N10_cpu_reference_us_mean": leg("closed_loop_tick/cartpole_N10_session/cpu_reference_tick_us/mean"), "cartpole_N10_cpu_reference_us_median": leg("closed_loop_tick/cartpole_N10_session/cpu_reference_tick_us/median"),
                 "closed_loop_tick_cpu_reference_us_mean": leg("closed_loop_tick/cpu_reference_tick_us/mean"), "closed_loop_tick_cpu_reference_us_median": leg("closed_loop_tick/cpu_reference_tick_us/median"),
                 "closed_loop_tick_session_python_us_mean": leg("closed_loop_tick/session/tick_us/mean"), "closed_loop_tick_session_python_us_median": leg("closed_loop_tick/session/tick_us/median"),
                 "rocket_closed_loop_launch_us_mean": leg("rocket_closed_loop/launch/tick_us/mean"), "rocket_closed_loop_launch_us_median": leg("rocket_closed_loop/launch/tick_us/median"),

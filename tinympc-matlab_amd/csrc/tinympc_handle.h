@@ -196,6 +196,7 @@ struct tinympc_solver {
         return (st.en_state_soc && n_cone_x > 0) || (st.en_input_soc && n_cone_u > 0) ||
                (st.en_state_linear && n_lin_x > 0) || (st.en_input_linear && n_lin_u > 0);
     }
+    void *arena_mail = nullptr;                       // ... and the 4 KB of fine-grained device memory that travel with them (the session's mailbox, d_mail)
     void *arena_dev = nullptr, *arena_pin = nullptr;  // the setup arenas (ArenaPlan below; pooled per device, tinympc_handle.hip)
     size_t arena_dev_bytes = 0, arena_pin_bytes = 0;
     std::vector<void *> allocs;       // hipMalloc blocks dalloc() added after setup

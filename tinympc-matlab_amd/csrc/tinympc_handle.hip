@@ -62,29 +62,36 @@ static bool device_is_large_bar(int device) {
 }
 
 int acquire_arenas(tinympc_solver *s, size_t dev_bytes, size_t pin_bytes, bool want_mailbox) {
+    // The session's mailbox on the DEVICE side of the bus (round 5): a line of fine-grained device memory the host stores into through
+    // the BAR (posted writes) and the resident kernel polls in its own HBM -- a poll is 0.2 us instead of a 1.2 us PCIe read
+    // (tools/mailbox_probe.hip, profiles/r05_mailbox_probe.txt). Where the device's memory is not mapped into the host's address space,
+    // or the allocation is refused, the mailbox stays in pinned host memory (h_mail). TINYMPC_MAILBOX=host forces that (A/B runs).
+    const char *env = getenv("TINYMPC_MAILBOX");
+    const bool use_mail = want_mailbox && device_is_large_bar(s->device) && !(env && (env[0] == 'h' || env[0] == 'H'));
+    s->arena_mail = nullptr;
+    s->d_mail = nullptr;
     if (s->device >= 0 && s->device < 64) {
         std::lock_guard<std::mutex> lock(g_kits_mu);
         auto &pool = g_arenas[s->device];
         for (size_t i = 0; i < pool.size(); ++i) {
-            if (pool[i].dev_bytes >= dev_bytes && pool[i].pin_bytes >= pin_bytes && (pool[i].mail != nullptr || !want_mailbox)) {
+            if (pool[i].dev_bytes >= dev_bytes && pool[i].pin_bytes >= pin_bytes && (pool[i].mail != nullptr || !use_mail)) {
                 s->arena_dev = pool[i].dev; s->arena_dev_bytes = pool[i].dev_bytes;
                 s->arena_pin = pool[i].pin; s->arena_pin_bytes = pool[i].pin_bytes;
-                s->d_mail = static_cast<double *>(pool[i].mail);
+                s->arena_mail = pool[i].mail;  // (owned with the arenas; used only if this handle wants a device-side mailbox)
+                s->d_mail = use_mail ? static_cast<double *>(pool[i].mail) : nullptr;
                 pool.erase(pool.begin() + (long)i);
                 return TINYMPC_OK;
             }
         }
     }
-    // The session's mailbox on the DEVICE side of the bus (round 5): a line of fine-grained device memory the host stores into through
-    // the BAR (posted writes) and the resident kernel polls in its own HBM -- a poll is 0.2 us instead of a 1.2 us PCIe read
-    // (tools/mailbox_probe.hip, profiles/r05_mailbox_probe.txt). Where the device's memory is not mapped into the host's address space,
-    // or the allocation is refused, the mailbox stays in pinned host memory (h_mail). TINYMPC_MAILBOX=host forces that (A/B runs).
-    s->d_mail = nullptr;
-    const char *env = getenv("TINYMPC_MAILBOX");
-    if (want_mailbox && device_is_large_bar(s->device) && !(env && (env[0] == 'h' || env[0] == 'H'))) {
+    if (use_mail) {
         void *m = nullptr;
-        if (hipExtMallocWithFlags(&m, 4096, hipDeviceMallocFinegrained) == hipSuccess) s->d_mail = static_cast<double *>(m);
-        else (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&m, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+            s->arena_mail = m;
+            s->d_mail = static_cast<double *>(m);
+        } else {
+            (void)hipGetLastError();
+        }
     }
     hipError_t e = hipMalloc(&s->arena_dev, dev_bytes);
     if (e != hipSuccess) return fail(TINYMPC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", dev_bytes, hipGetErrorString(e));
@@ -100,16 +107,16 @@ static void release_arenas(tinympc_solver *s) {
         std::lock_guard<std::mutex> lock(g_kits_mu);
         auto &pool = g_arenas[s->device];
         if (pool.size() < kArenasKept) {
-            pool.push_back({s->arena_dev, s->arena_dev_bytes, s->arena_pin, s->arena_pin_bytes, s->d_mail});
-            s->arena_dev = s->arena_pin = nullptr;
+            pool.push_back({s->arena_dev, s->arena_dev_bytes, s->arena_pin, s->arena_pin_bytes, s->arena_mail});
+            s->arena_dev = s->arena_pin = s->arena_mail = nullptr;
             s->d_mail = nullptr;
             return;
         }
     }
     if (s->arena_dev) (void)hipFree(s->arena_dev);
     if (s->arena_pin) (void)hipHostFree(s->arena_pin);
-    if (s->d_mail) (void)hipFree(s->d_mail);
-    s->arena_dev = s->arena_pin = nullptr;
+    if (s->arena_mail) (void)hipFree(s->arena_mail);
+    s->arena_dev = s->arena_pin = s->arena_mail = nullptr;
     s->d_mail = nullptr;
 }
 

@@ -58,6 +58,18 @@ def cpu_setup_and_ticks() -> dict:
     sec, its, per = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     out["closed_loop_tick_us"] = stats_us(per)
     out["closed_loop_iterations_per_tick"] = its / 200
+    # ... and the reference's own closed-loop example shape (examples/interactive_cartpole.m: cartpole, N = 10, |u| <= 5 there; here the bounded
+    # cartpole of problems.py), same loop
+    cp = P.cartpole(10, True)
+    s = O.OracleRef(cp).load_problem(cp, dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1))
+    runs = []
+    for _ in range(5):
+        s.reset_workspace()
+        its, sec, _x, per = s.bench_closed_loop_samples(cp.x0, 220, 20)
+        runs.append((sec, its, per))
+    sec, its, per = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    out["cartpole10_closed_loop_tick_us"] = stats_us(per)
+    out["cartpole10_closed_loop_iterations_per_tick"] = its / 200
     return out
 
 
@@ -605,6 +617,20 @@ def shape_and_latency_legs(ctx) -> None:
         cl = tk.bench_closed_loop(prob.A, prob.B, prob.x0, 220, 20, session="verbs")
         tick[mode] = {"c_loop": dict({k: cl[k] for k in ("us_per_tick", "us_per_tick_median", "us_per_tick_max", "iterations_per_tick")}, tick_us=stats_us(cl["tick_us"]))}
         tk.reset()
+    # ... and the cartpole at N = 10 (the reference's interactive closed-loop example's shape; no compiled-in specialisation: layout C's resident
+    # kernel, what ANY user system gets without tinympc_prepare()), resident session from the same C loop
+    cp10 = P.cartpole(10, True)
+    tk = pkg.TinyMPC()
+    tk.setup(cp10.A, cp10.B, cp10.Q, cp10.R, cp10.N, batch=1, device=dev_index, rho=cp10.rho, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    tk.set_bound_constraints(cp10.x_min, cp10.x_max, cp10.u_min, cp10.u_max)
+    tk.session_begin()
+    cl = tk.bench_closed_loop(cp10.A, cp10.B, cp10.x0, 220, 20, session=True)
+    c10 = ((cpu or {}).get("latency_extra") or {}).get("cartpole10_closed_loop_tick_us")
+    tick["cartpole_N10_session"] = {"layout": tk.launch_info()["layout"], "c_loop": dict(tick_us=stats_us(cl["tick_us"]), iterations_per_tick=cl["iterations_per_tick"]),
+                                    "cpu_reference_tick_us": c10,
+                                    "cpu_reference_iterations_per_tick": ((cpu or {}).get("latency_extra") or {}).get("cartpole10_closed_loop_iterations_per_tick")}
+    tk.session_end()
+    tk.reset()
     # The SAME statistics on both sides (round 5): mean, median, p90, max of the 200 per-tick samples -- the GPU's from
     # libtinympc_bench.so's C loop, the reference core's from oracle/ref_shim.cpp's (ref_bench_closed_loop_samples)
     cref = (cpu or {}).get("closed_loop_tick_us_single_process") or {}

@@ -3,7 +3,7 @@
 extra legs, a few launches each, nothing else in the process (no torch import: numpy + the C ABI only).
 
     python tools/leg_workload.py <leg> [launches]
-legs: headline, rocket_batch, rocket_batch_n10, rocket_instance, wide_system, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance,
+legs: headline, rocket_batch, rocket_batch_n10, rocket_instance, wide_system, wide_families, long_horizon, large_system, very_large_system, adaptive_rho_batch, single_instance,
       converging_batch, converging_batch_plain
 Prints one JSON line: leg, kernel layout, launches, iterations per launch, instances, median kernel ms (HIP events)."""
 import json
@@ -71,6 +71,11 @@ def build(leg):
         return rocket_handle(10, 4096, 100), 4096, 100
     if leg == "wide_system":
         return synthetic(24, 8, 30, 4096, 100, 0, 0.03, 0.1), 4096, 100
+    if leg == "wide_families":  # (round 5: the families streamed next to layout D's wide sweeps; bench.py: wide_system.with_families)
+        s = synthetic(24, 8, 30, 4096, 100, 0, 0.03, 0.1)
+        s.set_cone_constraints(Acx=[0], qcx=[3], cx=[0.7], Acu=[], qcu=[], cu=[])
+        s.set_linear_constraints(Alin_x=np.random.default_rng(1).standard_normal((2, 24)), blin_x=np.array([1.0, 1.5]), Alin_u=np.zeros((0, 8)), blin_u=np.zeros(0))
+        return s, 4096, 100
     if leg == "long_horizon":
         return quadrotor(100, 8192, 100), 8192, 100
     if leg == "large_system":

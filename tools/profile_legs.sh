@@ -8,7 +8,7 @@
 # `python tools/collect_leg_profiles.py <tag>` turns them into profiles/<tag>_<leg>_stats.csv / _pmc.json.
 set -o pipefail
 TAG=${1:?tag}; shift
-LEGS=${@:-headline rocket_batch rocket_batch_n10 rocket_instance wide_system long_horizon large_system very_large_system adaptive_rho_batch single_instance}
+LEGS=${@:-headline rocket_batch rocket_batch_n10 rocket_instance wide_system wide_families long_horizon large_system very_large_system adaptive_rho_batch single_instance}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/legs_$TAG
 mkdir -p "$O"
