@@ -135,10 +135,13 @@ def load_library() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "The HIP library is the only implementation; there is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    missing = [n for n in SIGNATURES if not hasattr(lib, n)]
-    if missing:
+    missing = [n for n in list(SIGNATURES) + list(DEBUG_SIGNATURES) if not hasattr(lib, n)]
+    # (an alternative build named by TINYMPC_HIP_LIBRARY may be an OLDER one -- A/B runs against a previous round: what it lacks stays unbound)
+    if missing and not os.environ.get("TINYMPC_HIP_LIBRARY"):
         raise ImportError(f"{LIB_PATH} does not export: {missing}")
     for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
+        if name in missing:
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -53,7 +53,8 @@ if __name__ == "__main__":
         sys.exit("no build assembly: run __graft_entry__.build() first")
     print(json.dumps(h, indent=1))
     if "--record" in sys.argv:
-        h["measured"] = "kernel 1.665-1.672 ms (8,192 x 200 iterations, bench.py on MI355X; profiles/r03_bench.json), tools/headline_ab.py: profiles/r03_dgroup_ab.txt"
+        h["measured"] = ("kernel 1.670-1.682 ms (8,192 x 200 iterations, bench.py on MI355X; profiles/r05_kernel_stats.csv); tools/headline_ab.py, one box, against round "
+                         "4's build (same instruction count, other kernel-argument offsets: SolveParams grew): 1.6753 vs 1.6736 ms, profiles/r05_headline_code_ab.txt")
         with open(RECORD, "w") as f:
             json.dump(h, f, indent=1)
             f.write("\n")
