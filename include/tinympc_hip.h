@@ -241,9 +241,11 @@ int tinympc_get_solution_device_ptrs(tinympc_solver *s, const double **d_x, cons
 
 /* Closed-loop SESSION (single-instance handles): the reference's control loops call set_x0 -> solve -> get_solution
  * once per tick (examples/cartpole_example_mpc.m:36-44); every such tick pays a kernel launch and a stream
- * synchronisation (~20 us of a ~25 us tick). In a session the solve kernel is launched ONCE and stays resident: it polls
- * a mailbox in pinned host memory for the next x0, runs the warm-started solve with the ADMM state kept in registers, and
- * writes the solution + a completion stamp back into pinned memory, where tinympc_session_step polls for it.
+ * synchronisation (~10 us of a ~15 us tick). In a session the solve kernel is launched ONCE and stays resident: it polls
+ * a mailbox for the next x0 (a line of device memory the host writes through the PCIe BAR; pinned host memory where the device's
+ * memory is not host-visible), runs the warm-started solve with the ADMM state kept in registers, sends the first controls to
+ * pinned host memory at once -- tinympc_session_step returns with them (a quadrotor N=50 tick: 6 us) -- and then the solution and
+ * a completion stamp, which tinympc_get_solution / _get_stats wait for.
  *   tinympc_session_begin   settings, bounds, cache are frozen for the session; references may change between ticks
  *                           (tinympc_set_x_ref / _set_u_ref: picked up by the next step)
  *   tinympc_session_step    x0 in (nx), first controls out (nu); tinympc_get_solution / _get_stats work as usual

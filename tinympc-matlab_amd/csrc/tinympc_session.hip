@@ -1,6 +1,14 @@
-// tinympc_session.hip -- the closed-loop SESSION (tinympc_session_begin / _step / _end, include/tinympc_hip.h): the latency kernel of
-// layout C stays resident and takes its ticks from a mailbox in pinned host memory (SolveParams::mail) instead of being launched
-// per tick. Host side only: the mailbox protocol, the (re)start of the resident kernel, the verbs.
+// tinympc_session.hip -- the closed-loop SESSION (tinympc_session_begin / _step / _end, include/tinympc_hip.h): a latency kernel -- layout
+// F's resident variant where the handle's launches run on layout F, else layout C's -- stays resident and takes its ticks from a MAILBOX
+// instead of being launched per tick. Host side only: the mailbox protocol, the (re)start of the resident kernel, the verbs.
+//   command   host -> kernel: lines [7 payload doubles | stamp], stamp = mail_stamp(sequence number, payload) -- a line is taken when the stamp
+//             fits the payload read with it. Round 5: the mailbox is a line of fine-grained DEVICE memory the host stores into through the
+//             PCIe BAR (the kernel polls its own HBM: 0.2 us per poll instead of a 1.2 us PCIe read), pinned host memory where the device is
+//             not large-BAR (tinympc_handle.hip: acquire_arenas).
+//   answer    kernel -> host, pinned memory: FIRST the tick's first controls in self-checking lines [7 controls | stamp] (SolveParams::host_ans:
+//             no fence, no wait for the rest), THEN solution + statistics behind a completion stamp (host_sol_state 3 until it is seen);
+//             every host-bound store of the kernels is a write-through store (host_store, tinympc_device.h).
+// tinympc_set_resident (tinympc_capi.hip) puts the reference's own verbs set_x0 / solve / get_solution on this path.
 #include "tinympc_handle.h"
 
 #include <algorithm>
