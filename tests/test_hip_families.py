@@ -686,6 +686,44 @@ def test_families_on_wide_systems(pkg, kernel_layout, monkeypatch, nx, nu, N, ba
 
 
 @pytest.mark.layouts("A")
+@pytest.mark.parametrize("nx,nu,N,batch", [(48, 14, 6, 70), (20, 4, 7, 16), (40, 10, 8, 33), (24, 8, 21, 40)])
+def test_families_on_wide_systems_with_bounds_that_vary_over_the_horizon(pkg, kernel_layout, monkeypatch, nx, nu, N, batch):
+    """The streamed-families kernels with the per-knot tables in LDS (!CT). (48, 14, 6) is the specialisation in which round 5's fuzzer
+    caught a register used while an asm-issued LDS read was still filling it (profiles/r05_inflight_bug.txt: the next step's bound,
+    parked in an AGPR before it had arrived; relative errors of order 10) -- a kernel's code depends on (nx, nu, N, tables, families)
+    only, so any data of that shape runs the code that failed. Against the restatement over a cold and a warm start."""
+    monkeypatch.delenv("TINYMPC_LAYOUT", raising=False)
+    P = pkg.problems
+    rng = np.random.default_rng(nx * 1000 + nu * 10 + N)
+    A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    Bm = 0.3 * rng.standard_normal((nx, nu))
+    prob = P.Problem("widefam_knots", A, Bm, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 1.2, rng.standard_normal(nx))
+    prob.fdyn = 0.01 * rng.standard_normal(nx)
+    prob.x_min = np.repeat(np.full((nx, 1), -3.0), N, 1) * rng.uniform(0.8, 1.0, (1, N))
+    prob.x_max = -prob.x_min
+    prob.u_min, prob.u_max = np.full(nu, -1.0), np.full(nu, 1.0)
+    prob.cones = dict(Acx=[nx - 6, 1], qcx=[4, 2], cx=[1.3, 0.55], Acu=[0], qcu=[2], cu=[0.7])
+    prob.linear = dict(Alin_x=rng.standard_normal((1, nx)), blin_x=rng.uniform(0.5, 1.5, 1), Alin_u=rng.standard_normal((2, nu)), blin_u=rng.uniform(0.3, 0.8, 2))
+    settings = dict(max_iter=60, abs_pri_tol=1e-3, abs_dua_tol=1e-3, check_termination=3)
+    s = make(pkg, prob, settings, batch=batch)
+    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.1, 1.0, batch)[None, :]
+    checked = sorted({0, batch // 2, batch - 1})
+    orc = {b: oracle(prob, settings) for b in checked}
+    for rnd in range(2):
+        xs = x0s * (1.0 - 0.3 * rnd)
+        s.set_x0_batch(xs)
+        s.solve()
+        assert s.launch_info()["layout"] == "D", s.jit_info()
+        sol, st = s.get_solution_batch(), s.get_stats_batch()
+        for b in checked:
+            orc[b].set_x0(xs[:, b])
+            orc[b].solve()
+            assert st["iter"][b] == orc[b].stats()["iter"] and st["status"][b] == orc[b].stats()["status"], (rnd, b)
+            assert rel_err(sol["states"][:, :, b], orc[b].solution()[0]) < TOL and rel_err(sol["controls"][:, :, b], orc[b].solution()[1]) < TOL, (rnd, b)
+    s.reset()
+
+
+@pytest.mark.layouts("A")
 def test_rocket_batch_properties_at_bench_size(pkg, kernel_layout, monkeypatch):
     """BASELINE config 4 in the batch the bench times (4,096 rocket landings, N=100, cones + linear row + fdyn, layout E): properties
     that need no oracle -- reversing the instance order reverses the results bit for bit; equal initial states give equal results

@@ -14,6 +14,7 @@ import subprocess
 import pytest
 from conftest import ROOT
 
+from tools.inflight_lint import lint_text as _inflight
 from tools.isa_lint import lint as _lint
 
 CSRC = os.path.join(ROOT, "tinympc-matlab_amd", "csrc")
@@ -47,6 +48,37 @@ def test_lint_catches_a_planted_hazard():
     n, bad = _lint("v_mul_f64 v[4:5], v[8:9], v[8:9]\n v_mov_b64_dpp v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n")
     assert n == 1 and len(bad) == 1
     assert _lint("v_mul_f64 v[4:5], v[8:9], v[8:9]\n s_and_saveexec_b64 s[0:1], s[2:3]\n s_nop 1\n v_mov_b64_dpp v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n") == (1, [])
+
+
+def test_inflight_lint_catches_a_register_touched_before_its_read_landed():
+    """What tools/fuzz_wide_families.py found in round 5 (profiles/r05_inflight_bug.txt): an LDS read issued from inline asm, whose
+    destination the compiler parked in an AGPR and reused before the block's s_waitcnt."""
+    read = ";;#ASMSTART\n ds_read_b64 v[0:1], v186 offset:0xa00\n ;;#ASMEND\n"
+    wait = ";;#ASMSTART\n v_add_f64 v[8:9], v[8:9], v[8:9]\n s_waitcnt lgkmcnt(0)\n ;;#ASMEND\n"
+    assert _inflight(read + wait + "v_mov_b32_e32 v2, v0\n") == []
+    bad = _inflight(read + "v_accvgpr_write_b32 a49, v1\n" + wait)
+    assert len(bad) == 1 and bad[0][2] == [("v", 1)]
+    assert len(_inflight(read + "v_cndmask_b32_e64 v0, v6, v192, s[0:1]\n" + wait)) == 1   # a write is as bad as a read
+    # LDS operations retire in order: lgkmcnt(1) behind a second read has retired the first one only
+    two = read + ";;#ASMSTART\n ds_read_b64 v[2:3], v186 offset:0xb00\n ;;#ASMEND\n s_waitcnt lgkmcnt(1)\n"
+    assert _inflight(two + "v_mov_b32_e32 v9, v0\n") == [] and len(_inflight(two + "v_mov_b32_e32 v9, v2\n")) == 1
+    # the compiler's own reads are its own business (it waits where it must) unless asked for
+    own = "ds_read_b64 v[0:1], v186 offset:2560\n v_mov_b32_e32 v9, v0\n"
+    assert _inflight(own) == [] and len(_inflight(own, asm_only=False)) == 1
+
+
+def test_no_kernel_source_issues_an_lds_read_the_compiler_cannot_see():
+    """Every LDS read with a result goes through tinympc_sweep.h's lds_read_issued_here (a volatile load: its place is pinned, its
+    arrival tracked) and every wait it relies on through lds_reads_landed (__builtin_amdgcn_s_waitcnt) -- no `ds_read` and no
+    `s_waitcnt lgkmcnt` in inline asm text (the exchange barrier of the matrix-core kernel excepted: it has no asynchronous reads)."""
+    for name in sorted(os.listdir(CSRC)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        code = "\n".join(line.split("//")[0] for line in open(os.path.join(CSRC, name)).read().splitlines())
+        strings = " ".join(re.findall(r'"([^"\n]*)"', code))  # (asm text holds no escaped quotes)
+        assert "ds_read" not in strings and "ds_bpermute" not in strings, name
+        if name != "tinympc_solve_m.hip":
+            assert "lgkmcnt" not in strings, name
 
 
 def test_every_solve_source_is_linted_by_the_build():

@@ -133,16 +133,13 @@ __host__ __device__ constexpr size_t d_lds_bytes(int nu, int N, bool ct, int wpg
                              (size_t)wpg * (vl * 64 + d_d_doubles(nu, N)));
 }
 
-// LDS traffic of the sweeps goes through asm volatile so that WHERE a read is issued is this file's decision, not the
-// scheduler's (see tinympc_solve_d_chain.h): reads are issued one block ahead and retired by the block's own s_waitcnt.
-typedef __attribute__((address_space(3))) double lds_double_t;
-__device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double_t *)p; }
+// LDS traffic of the sweeps: WHERE a read is issued is this file's decision, not the scheduler's (see tinympc_solve_d_chain.h) -- reads
+// are issued one block ahead and retired by the wait behind the block; both in a form the compiler tracks (tinympc_sweep.h:
+// lds_read_issued_here / lds_reads_landed). Writes carry no result and stay plain asm.
+__device__ __forceinline__ unsigned lds_addr(const double *p) { return lds_address(p); }
 template <int OFF>
-__device__ __forceinline__ double lds_read_async(unsigned addr) {  // the value is valid after the next s_waitcnt lgkmcnt(0)
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-    double v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
+__device__ __forceinline__ double lds_read_async(unsigned addr) {  // the value is valid after the next lds_reads_landed()
+    return lds_read_issued_here<OFF>(addr);
 }
 template <int OFF>
 __device__ __forceinline__ void lds_write_async(unsigned addr, double v) {
@@ -163,15 +160,19 @@ __device__ __forceinline__ void lds_write_masked(unsigned addr, double v, unsign
                  : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
                  : "memory", "scc");
 }
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait() {
+    lds_reads_landed();
+    asm volatile("" ::: "memory");
+}
 // ... and the point where the compiler retires ITS OWN reads of the sweep's operator rows: left alone it waits for them in
 // front of the first block that uses them, i.e. right behind the asynchronous reads issued for the second block -- a full
-// LDS latency in every sweep.
+// LDS latency in every sweep. (The empty asm makes the rows operands of THIS point.)
 __device__ __forceinline__ void lds_wait_ops(double (&m)[16]) {
+    lds_reads_landed();
 #ifdef TINY_D_NO_OPS_WAIT
-    lds_wait();
+    asm volatile("" ::: "memory");
 #else
-    asm volatile("s_waitcnt lgkmcnt(0)"
+    asm volatile(""
                  : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]),
                    "+v"(m[10]), "+v"(m[11]), "+v"(m[12]), "+v"(m[13]), "+v"(m[14]), "+v"(m[15])
                  :
@@ -698,7 +699,7 @@ __device__ __forceinline__ void k_admm_solve_d_body(const SolveParams &p, double
         }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
         // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
-        // PREVIOUS step's block and retired by that block's trailing s_waitcnt.
+        // PREVIOUS step's block and retired by the wait behind that block (lds_reads_landed, inside the Step functions).
         double xcur = x0v;
         double dcur = lds_read_async<0>(aD), vcur = 0.0;
         if constexpr (VL > 0) vcur = lds_read_async<0>(aV);

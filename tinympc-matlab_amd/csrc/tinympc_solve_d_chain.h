@@ -10,9 +10,11 @@
 // DEPENDENT chain of v_fmac_f64_dpp issues every 4.1 cycles from a single wave -- the FP64 pipe's own rate (16 lanes
 // per clock), so the mat-vec needs neither partial sums nor interleaving. What does stall a wave is waiting for LDS:
 // hipcc sinks ds_reads next to their use and waits lgkmcnt(0) right behind them, exposing ~100+ cycles per step.
-// Hence every block is `asm volatile` and ends with its own s_waitcnt: the caller issues the NEXT step's LDS reads
-// (asm volatile, tinympc_solve_d.hip) right before a block, they complete in the shadow of the block's ~25 FP64
-// instructions, and the block's trailing wait makes them architecturally visible before any later code can touch them.
+// Hence every block is `asm volatile` and is followed by a wait: the caller issues the NEXT step's LDS reads right before a
+// block, they complete in the shadow of the block's ~25 FP64 instructions, and the wait behind the block retires them before
+// any later code can touch them. Reads and wait are in the form the compiler TRACKS (tinympc_sweep.h: lds_read_issued_here,
+// a volatile load, and lds_reads_landed, __builtin_amdgcn_s_waitcnt -- through round 5 both were asm text, invisible to the
+// register allocator, which in one wide specialisation reused a register that was still being filled).
 //
 // DPP hazard (a VGPR written by VALU must not be read through DPP within 2 wait states; nothing guards it inside
 // inline asm): `x` is the `a` the previous block's chain wrote; forward blocks end with >= 8 non-DPP instructions
@@ -260,7 +262,6 @@
     "v_max_f64 %[pri], %[pri], |%[t]|\n\t"         \
     "v_add_f64 %[t], %[v], -%[sn]\n\t"             \
     "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
-#define D_WAIT "s_waitcnt lgkmcnt(0)"
 // The same row-local block for the element of the PREVIOUS step (%[ap], its slot's g / v / bounds), woven into the chain of the
 // current step one instruction per column (layout E, round 4): the block is a dependent sequence of its own, the chain another, and a
 // wavefront issues in order -- back to back each instruction waits for its predecessor's result (~8 cycles for FP64), interleaved
@@ -290,9 +291,10 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_reg(double x, double d, const double (&m)[16], double cf, double lo, double hi,
                                                      double &g, double &v, double &pri, double &dua) {
         double a, s, t, sn;
-        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT "v_mov_b64 %[v], %[sn]\n\t" D_WAIT
+        asm volatile("v_mov_b64 %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT "v_mov_b64 %[v], %[sn]\n\t"
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), D_MOPS);
+        lds_reads_landed();
         return a;
     }
     // Forward step, slack kept in LDS: vold comes in, vnew goes out (the caller loads / stores them).
@@ -302,9 +304,10 @@ struct DStep<D_NX, D_NU> {
         // (v_mov_b64 in its 8-byte encoding: with the 4-byte one this block and what the caller puts around it -- s_waitcnt, a
         // hazard s_nop, the slot's LDS write and the next step's two reads -- come to 4 bytes more than a multiple of 8, every
         // second LDS step's chain would straddle the 8-byte grid and D_AL would pad each of them with an s_nop)
-        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT D_WAIT
+        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN D_PROJECT
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), D_MOPS);
+        lds_reads_landed();
         return a;
     }
     // Forward step with the row-local block of the PREVIOUS step woven into its chain (layout E): returns a = cf + Mf * [x; d];
@@ -313,9 +316,10 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_reg_woven(double x, double d, const double (&m)[16], double cf, double ap, double lo, double hi,
                                                            double &g, double &v, double &pri, double &dua) {
         double a, s, t, sn;
-        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN_WOVEN D_MOV64 " %[v], %[sn]\n\t" D_WAIT
+        asm volatile(D_MOV64 " %[a], %[cf]\n\t" D_HAZ D_CHAIN_WOVEN D_MOV64 " %[v], %[sn]\n\t"
                      : [a] "=&v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [x] "v"(x), [d] "v"(d), [cf] "v"(cf), [ap] "v"(ap), [lo] "v"(lo), [hi] "v"(hi), D_MOPS);
+        lds_reads_landed();
         return a;
     }
     // ... and the row-local block alone, for the last step of a sweep
@@ -331,9 +335,10 @@ struct DStep<D_NX, D_NU> {
     static __device__ __forceinline__ double fwd_plain(double x, double d, const double (&m)[16], double c) {
         double a;
         asm volatile("v_mov_b64 %[a], %[c]\n\t"
-                     "s_nop 1\n\t" D_AL D_CHAIN D_WAIT
+                     "s_nop 1\n\t" D_AL D_CHAIN
                      : [a] "=&v"(a)
                      : [x] "v"(x), [d] "v"(d), [c] "v"(c), D_MOPS);
+        lds_reads_landed();
         return a;
     }
     // Backward step for slot s: a (in: accumulator start = q_s + cb on state lanes, cb on input lanes; out: p_s | d_s)
@@ -347,17 +352,19 @@ struct DStep<D_NX, D_NU> {
         asm volatile(D_HAZ D_CHAIN
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
-                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t"
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
+        lds_reads_landed();
     }
     // ... the same step with its tail woven into the chain (layout E)
     static __device__ __forceinline__ void bwd_woven(double &a, double x, double d, const double (&m)[16], double v2, double g2,
                                                      double rhom, double lrmc, double nrho, double lr, double &an, double &rn) {
         double t;
-        asm volatile(D_HAZ D_CHAIN_BWD_WOVEN D_WAIT
+        asm volatile(D_HAZ D_CHAIN_BWD_WOVEN
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), D_MOPS);
+        lds_reads_landed();
     }
     // ... the same with -rho as a vector operand (adaptive rho: rho is per instance)
     static __device__ __forceinline__ void bwd_v(double &a, double x, double d, const double (&m)[16], double v2, double g2,
@@ -366,21 +373,22 @@ struct DStep<D_NX, D_NU> {
         asm volatile(D_HAZ D_CHAIN
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
-                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" D_WAIT
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t"
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [x] "v"(x), [d] "v"(d), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "v"(nrho), [lr] "v"(lr), D_MOPS);
+        lds_reads_landed();
     }
     // a += T * d over the INPUT columns only (T_k in m[NX + k]; the other entries of m are not read): layout F accumulates a chunk's end
     // state from a zero incoming state, sum_s Phi^(S-1-s) (-B) d_s, while the backward sweep produces the d_s (tinympc_solve_f.hip).
     static __device__ __forceinline__ double acc_inputs(double a, double d, const double (&m)[16]) {
         // (its operand d is ALWAYS the result of the chain right in front of it: the two wait states of the DPP hazard are spelled out
         // here in every build, so that a compiled-in kernel's other chain blocks can stay bare)
-        asm volatile("s_nop 1\n\t" D_AL D_CHAIN_IN D_WAIT : [a] "+v"(a) : [d] "v"(d), D_MOPS);
+        asm volatile("s_nop 1\n\t" D_AL D_CHAIN_IN : [a] "+v"(a) : [d] "v"(d), D_MOPS); lds_reads_landed();
         return a;
     }
     // Last backward step (slot 0): nothing left to prepare.
     static __device__ __forceinline__ void bwd_last(double &a, double x, double d, const double (&m)[16]) {
-        asm volatile(D_HAZ D_CHAIN D_WAIT : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS);
+        asm volatile(D_HAZ D_CHAIN : [a] "+v"(a) : [x] "v"(x), [d] "v"(d), D_MOPS); lds_reads_landed();
     }
 };
 
@@ -440,6 +448,5 @@ struct DStep<D_NX, D_NU> {
 #undef D_T2
 #undef D_T3
 #undef D_CHAIN_BWD_WOVEN
-#undef D_WAIT
 #undef D_NX
 #undef D_NU

@@ -6,7 +6,7 @@
 // the upper row's), after which the mat-vec is the fused chain of tinympc_solve_d_chain.h with 16 columns per copy:
 //     a += m[k] * e(row_newbcast:k)   k < 16        a += m[16 + k] * o(row_newbcast:k)   16 + k < nx + nu
 // An asm statement takes at most 30 operands, so a step is two `asm volatile` blocks (columns 0-15 | columns 16.. + the
-// row-local instructions + the trailing s_waitcnt). Hazards: `e` and `o` are written by the swaps (VALU) right before
+// row-local instructions; the wait that retires the caller's LDS reads follows the block: lds_reads_landed). Hazards: `e` and `o` are written by the swaps (VALU) right before
 // the first block, which therefore opens with `s_nop 1`; tools/isa_lint.py checks the generated code.
 #if !defined(DW_NX) || !defined(DW_NU)
 #error "define DW_NX and DW_NU before including tinympc_solve_dw_chain.h"
@@ -124,7 +124,6 @@
     "v_max_f64 %[pri], %[pri], |%[t]|\n\t"         \
     "v_add_f64 %[t], %[v], -%[sn]\n\t"             \
     "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
-#define DW_WAIT "s_waitcnt lgkmcnt(0)"
 
 namespace tinympc {
 
@@ -143,17 +142,19 @@ struct DWStep<DW_NX, DW_NU> {
     static __device__ __forceinline__ void hi_fwd_reg(double &a, double o, const double (&m)[32], double lo, double hi, double &g, double &v,
                                                       double &pri, double &dua) {
         double s, t, sn;
-        asm volatile(DW_HAZ DW_HI DW_PROJECT "v_mov_b64 %[v], %[sn]\n\t" DW_WAIT
+        asm volatile(DW_HAZ DW_HI DW_PROJECT "v_mov_b64 %[v], %[sn]\n\t"
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [o] "v"(o), [lo] "v"(lo), [hi] "v"(hi), DW_MHI);
+        lds_reads_landed();
     }
     // ... slack in LDS: vold comes in, vnew goes out (the caller loads / stores them)
     static __device__ __forceinline__ void hi_fwd_lds(double &a, double o, const double (&m)[32], double lo, double hi, double &g, double v,
                                                       double &vnew, double &pri, double &dua) {
         double s, t;
-        asm volatile(DW_HAZ DW_HI DW_PROJECT DW_WAIT
+        asm volatile(DW_HAZ DW_HI DW_PROJECT
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [o] "v"(o), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), DW_MHI);
+        lds_reads_landed();
     }
     // columns 16.. going backward + the tail of tinympc_solve_d_chain.h (an: accumulator start of the next step, rn: its
     // input-row operand):  t = v2 - g2 ;  an = rhom * t + lrmc ;  rn = nrho * t + lr
@@ -163,12 +164,13 @@ struct DWStep<DW_NX, DW_NU> {
         asm volatile(DW_HAZ DW_HI
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
-                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" DW_WAIT
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t"
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [o] "v"(o), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), DW_MHI);
+        lds_reads_landed();
     }
     static __device__ __forceinline__ void hi_bwd_last(double &a, double o, const double (&m)[32]) {
-        asm volatile(DW_HAZ DW_HI DW_WAIT : [a] "+v"(a) : [o] "v"(o), DW_MHI);
+        asm volatile(DW_HAZ DW_HI : [a] "+v"(a) : [o] "v"(o), DW_MHI); lds_reads_landed();
     }
 };
 
@@ -182,7 +184,6 @@ struct DWStep<DW_NX, DW_NU> {
 #undef DW_MLO
 #undef DW_MHI
 #undef DW_PROJECT
-#undef DW_WAIT
 #undef DW_NXU
 #undef DW_H16
 #undef DW_H17

@@ -87,14 +87,10 @@ __host__ __device__ constexpr size_t wide_lds_bytes(int W, int nu, int N, bool c
 // buffer's own layout (tinympc_handle.hip: refresh_families) with the RECIPROCAL of the norm, so that a sweep step neither waits for L2 nor divides
 __host__ __device__ constexpr size_t wide_fam_lin_doubles(int W) { return (size_t)2 + (size_t)3 * MAX_LIN_ROWS * W; }
 
-typedef __attribute__((address_space(3))) double lds_double_w;
-__device__ __forceinline__ unsigned lds_addr_w(const double *p) { return (unsigned)(size_t)(const lds_double_w *)p; }
+__device__ __forceinline__ unsigned lds_addr_w(const double *p) { return lds_address(p); }
 template <int OFF>
-__device__ __forceinline__ double lds_read_async_w(unsigned addr) {  // the value is valid after the next s_waitcnt lgkmcnt(0)
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-    double v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
+__device__ __forceinline__ double lds_read_async_w(unsigned addr) {  // issued HERE, tracked by the compiler (tinympc_sweep.h); valid after the next lds_reads_landed()
+    return lds_read_issued_here<OFF>(addr);
 }
 template <int OFF>
 __device__ __forceinline__ void lds_write_async_w(unsigned addr, double v) {
@@ -112,7 +108,10 @@ __device__ __forceinline__ void lds_write_masked_w(unsigned addr, double v, unsi
                  : [m] "s"(mask), [a] "v"(addr), [v] "v"(v), [o] "n"(OFF)
                  : "memory", "scc");
 }
-__device__ __forceinline__ void lds_wait_w() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait_w() {
+    lds_reads_landed();
+    asm volatile("" ::: "memory");
+}
 
 // `bad` = ballot of lanes whose row already rules out convergence in this sweep, `live` = ballot of the lanes that
 // are still iterating. True if some live instance (W lanes) has no bad lane.
@@ -340,7 +339,7 @@ __device__ __forceinline__ void k_admm_solve_wide_body(const SolveParams &p, dou
         }
         // ---------------- forward sweep (F1) with S1 + D1 + R1 fused in
         // LDS operands of a step (its d, and vold of its slot if that lives in LDS) are requested right before the
-        // PREVIOUS step's block and retired by that block's trailing s_waitcnt.
+        // PREVIOUS step's block and retired by the wait behind that block (lds_reads_landed, inside the Step functions).
         double xcur = x0v;
         double dcur = lds_read_async_w<0>(aD), vcur = 0.0;
         if constexpr (VL > 0) vcur = lds_read_async_w<0>(aV);

@@ -228,7 +228,6 @@
     "v_max_f64 %[pri], %[pri], |%[t]|\n\t"         \
     "v_add_f64 %[t], %[v], -%[sn]\n\t"             \
     "v_max_f64 %[dua], %[dua], |%[t]|\n\t"
-#define DX_WAIT "s_waitcnt lgkmcnt(0)"
 
 namespace tinympc {
 
@@ -250,16 +249,18 @@ struct DXStep<DX_NX, DX_NU> {
     static __device__ __forceinline__ void q3_fwd_reg(double &a, double w, const double (&m)[64], double lo, double hi, double &g, double &v,
                                                       double &pri, double &dua) {
         double s, t, sn;
-        asm volatile("s_nop 1\n\t" DX_Q3 DX_PROJECT "v_mov_b64 %[v], %[sn]\n\t" DX_WAIT
+        asm volatile("s_nop 1\n\t" DX_Q3 DX_PROJECT "v_mov_b64 %[v], %[sn]\n\t"
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(sn), [g] "+v"(g), [v] "+v"(v), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [w] "v"(w), [lo] "v"(lo), [hi] "v"(hi), DX_M3);
+        lds_reads_landed();
     }
     static __device__ __forceinline__ void q3_fwd_lds(double &a, double w, const double (&m)[64], double lo, double hi, double &g, double v,
                                                       double &vnew, double &pri, double &dua) {
         double s, t;
-        asm volatile("s_nop 1\n\t" DX_Q3 DX_PROJECT DX_WAIT
+        asm volatile("s_nop 1\n\t" DX_Q3 DX_PROJECT
                      : [a] "+v"(a), [s] "=&v"(s), [t] "=&v"(t), [sn] "=&v"(vnew), [g] "+v"(g), [pri] "+v"(pri), [dua] "+v"(dua)
                      : [w] "v"(w), [lo] "v"(lo), [hi] "v"(hi), [v] "v"(v), DX_M3);
+        lds_reads_landed();
     }
     // block 3 going backward + the tail (see tinympc_solve_d_chain.h)
     static __device__ __forceinline__ void q3_bwd(double &a, double w, const double (&m)[64], double v2, double g2, double rhom, double lrmc,
@@ -268,12 +269,13 @@ struct DXStep<DX_NX, DX_NU> {
         asm volatile("s_nop 1\n\t" DX_Q3
                      "v_add_f64 %[t], %[v2], -%[g2]\n\t"
                      "v_fma_f64 %[an], %[rhom], %[t], %[lrmc]\n\t"
-                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t" DX_WAIT
+                     "v_fma_f64 %[rn], %[nrho], %[t], %[lr]\n\t"
                      : [a] "+v"(a), [an] "=&v"(an), [rn] "=&v"(rn), [t] "=&v"(t)
                      : [w] "v"(w), [v2] "v"(v2), [g2] "v"(g2), [rhom] "v"(rhom), [lrmc] "v"(lrmc), [nrho] "s"(nrho), [lr] "v"(lr), DX_M3);
+        lds_reads_landed();
     }
     static __device__ __forceinline__ void q3_bwd_last(double &a, double w, const double (&m)[64]) {
-        asm volatile("s_nop 1\n\t" DX_Q3 DX_WAIT : [a] "+v"(a) : [w] "v"(w), DX_M3);
+        asm volatile("s_nop 1\n\t" DX_Q3 : [a] "+v"(a) : [w] "v"(w), DX_M3); lds_reads_landed();
     }
 };
 
@@ -281,7 +283,6 @@ struct DXStep<DX_NX, DX_NU> {
 
 #undef DX_F_
 #undef DX_PROJECT
-#undef DX_WAIT
 #undef DX_NXU
 #undef DX_C0
 #undef DX_C1

@@ -25,14 +25,10 @@ __device__ __forceinline__ void e_static_for(F &&f) {
     }
 }
 
-typedef __attribute__((address_space(3))) double e_lds_double_t;
-__device__ __forceinline__ unsigned e_lds_addr(const double *p) { return (unsigned)(size_t)(const e_lds_double_t *)p; }
+__device__ __forceinline__ unsigned e_lds_addr(const double *p) { return lds_address(p); }
 template <int OFF>
-__device__ __forceinline__ double e_lds_read_async(unsigned addr) {  // valid after the next s_waitcnt lgkmcnt(0)
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-    double v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
+__device__ __forceinline__ double e_lds_read_async(unsigned addr) {  // issued HERE, tracked by the compiler (tinympc_sweep.h); valid after the next lds_reads_landed()
+    return lds_read_issued_here<OFF>(addr);
 }
 template <int OFF>
 __device__ __forceinline__ void e_lds_write_async(unsigned addr, double v) {
@@ -60,14 +56,15 @@ __device__ __forceinline__ void e_reg_write_masked(double &dst, double v, unsign
                  : [m] "s"(mask), [v] "v"(v)
                  : "scc");
 }
-__device__ __forceinline__ void e_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// ... the same wait, with the values of e_lds_read_async that ordinary C++ arithmetic consumes next passed THROUGH it: the compiler sees
-// no dependence between a `ds_read` in one asm statement and an s_waitcnt in another, and is free to schedule register arithmetic on the
-// read's result in front of the wait (round 4: a change that only removed four loads in front of layout E's families phase did exactly
-// that -- two thirds of a batch's iteration counts went wrong). Consumers that are asm statements themselves (the chain blocks) are
-// ordered behind the wait as volatile asm; everything else goes through here.
-// (a point in the order of the volatile asm statements that the named values cannot be copied or used in front of: behind a chain
-// block's own s_waitcnt, for the values its successor will take from e_lds_read_async)
+__device__ __forceinline__ void e_lds_wait() {
+    lds_reads_landed();
+    asm volatile("" ::: "memory");
+}
+// ... the same wait, with the values of e_lds_read_async that ordinary C++ arithmetic consumes next passed THROUGH it. (History: while
+// reads and waits were asm text the compiler saw no dependence between them and scheduled arithmetic on a read's result in front of the
+// wait -- round 4, two thirds of a batch's iteration counts went wrong; these pass-throughs were the fix. Round 5 found the same class once
+// more, as a register copy, and removed its cause: reads and waits are tracked by the compiler now, tinympc_sweep.h. The pass-throughs stay
+// as scheduling points: they keep consumers BEHIND the hand-placed wait instead of having the compiler add one of its own earlier.)
 __device__ __forceinline__ void e_lds_arrived() {}
 template <class... T>
 __device__ __forceinline__ void e_lds_arrived(double &v, T &...rest) {
@@ -76,15 +73,22 @@ __device__ __forceinline__ void e_lds_arrived(double &v, T &...rest) {
 }
 template <int NV>
 __device__ __forceinline__ void e_lds_wait_for(double (&v)[NV]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_reads_landed();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
 }
 // workgroup barrier that waits for this wavefront's LDS traffic only (not for its global stores, as __syncthreads() would)
 #if defined(TINY_E_EXP) && (TINY_E_EXP == 4 || TINY_E_EXP == 5)  // (timing experiment: no barrier)
-__device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void e_barrier() {
+    lds_reads_landed();
+    asm volatile("" ::: "memory");
+}
 #else
-__device__ __forceinline__ void e_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void e_barrier() {
+    lds_reads_landed();
+    asm volatile("s_barrier" ::: "memory");
+}
 #endif
 
 __device__ __forceinline__ bool e_wave_may_converge(unsigned long long bad, unsigned long long live) {

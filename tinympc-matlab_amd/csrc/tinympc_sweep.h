@@ -11,6 +11,30 @@
 namespace tinympc {
 
 // ------------------------------------------------------------------------------------------------
+// LDS reads whose ISSUE POINT the kernel chooses and whose arrival the COMPILER tracks (layouts D, E and the wide forms).
+//
+// The register-resident sweeps request a step's LDS operands one block ahead, in the shadow of the previous step's ~25 FP64
+// instructions, and retire them with one s_waitcnt behind that block. Through round 5 the requests were `asm volatile("ds_read_b64")`
+// and the wait a line of the block's own asm text: the compiler knew of neither, believed the destination register valid at once,
+// and under register pressure (the 512-register plans, whose overflow lives in AGPRs) it was free to COPY the register, or hand it
+// to other code, between the request and the wait -- tools/fuzz_wide_families.py found a shape (nx 48, nu 14, N 6, per-knot bounds)
+// where it parked the still-empty bound in an AGPR and reused the register for the operand vector (profiles/r05_inflight_bug.txt).
+// Now: the request is a VOLATILE load (volatile pins its place among the asm volatile blocks; for LDS the memory legalizer adds
+// no wait of its own) and the wait is __builtin_amdgcn_s_waitcnt -- both in the compiler's scoreboard. The instruction stream is the
+// one the hand schedule wants; should register allocation ever touch an in-flight value early, the compiler now inserts the wait
+// it needs instead of reading garbage. tools/inflight_lint.py checks the old form's assembly; the new form cannot violate it.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_double_as3;
+__device__ __forceinline__ unsigned lds_address(const double *p) { return (unsigned)(size_t)(const lds_double_as3 *)p; }
+template <int OFF>
+__device__ __forceinline__ double lds_read_issued_here(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds offset field is 16 bits");
+    return *((const volatile lds_double_as3 *)(size_t)addr + OFF / 8);
+}
+// s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched) that the compiler's wait-count pass sees: every LDS read issued so far has landed
+__device__ __forceinline__ void lds_reads_landed() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// ------------------------------------------------------------------------------------------------
 // References handed over in pinned host memory (single-instance handles; SolveParams::href_x). The ONE workgroup of
 // the launch recomputes what k_build_tables derives from them -- the linref rows -(Xref .* Q), -(Uref .* R)
 // (admm.cpp:77, 79) and pNref = -(Xref_{N-1}' Pinf)' (admm.cpp:81), same expressions, same order of operations, so the

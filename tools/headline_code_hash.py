@@ -53,8 +53,9 @@ if __name__ == "__main__":
         sys.exit("no build assembly: run __graft_entry__.build() first")
     print(json.dumps(h, indent=1))
     if "--record" in sys.argv:
-        h["measured"] = ("kernel 1.670-1.682 ms (8,192 x 200 iterations, bench.py on MI355X; profiles/r05_kernel_stats.csv); tools/headline_ab.py, one box, against round "
-                         "4's build (same instruction count, other kernel-argument offsets: SolveParams grew): 1.6753 vs 1.6736 ms, profiles/r05_headline_code_ab.txt")
+        h["measured"] = ("kernel 1.68-1.69 ms (8,192 x 200 iterations, bench.py on MI355X; profiles/r05_kernel_stats.csv); tools/headline_ab.py, one box, against the "
+                         "build before the sweeps' LDS reads and waits became compiler-tracked (4,349 instructions, asm-issued reads): 1.6872 vs 1.6820 ms "
+                         "(+0.3 %, three interleaved rounds each), profiles/r05_tracked_reads_headline_ab.txt")
         with open(RECORD, "w") as f:
             json.dump(h, f, indent=1)
             f.write("\n")
