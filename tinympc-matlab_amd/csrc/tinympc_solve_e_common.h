@@ -86,8 +86,10 @@ __device__ __forceinline__ void e_barrier() {
 }
 #else
 __device__ __forceinline__ void e_barrier() {
+    // (the wait once for the compiler's scoreboard and once FUSED with the barrier: between two statements the compiler may place code --
+    // it did put ds_bpermutes there --, and a store of this wavefront that other wavefronts read behind the barrier must have landed)
     lds_reads_landed();
-    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 #endif
 
