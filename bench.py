@@ -398,6 +398,12 @@ def main() -> int:
                                   stats_us)
     pkg = ge.load_package()
     P = pkg.problems
+    # The interpreter's cyclic collector: a full pass over torch's ~170,000 import-time objects takes 40-80 ms and lands wherever the
+    # allocation count says -- round 5 saw it as ONE 55 ms and one 78 ms tick among 400 Python-timed batched ticks (their means went from
+    # 125 to 1,501 us). gc.freeze() moves what exists now to the permanent generation: later passes look at the run's own objects only.
+    import gc
+    gc.collect()
+    gc.freeze()
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the HIP path has no CPU fallback", file=sys.stderr)
         return 2
