@@ -36,10 +36,12 @@ variants = [("box path (no families)", {"WIDE_BOX": "1"}), ("k_admm_solve_fam (r
             ("batch 2 + swap, no fences", {"TINYMPC_JIT_DEFS": "-DTINY_WIDE_FAM_BATCH=2 -DTINY_WIDE_FAM_SWAP=1 -DTINY_WIDE_FAM_FENCE=0"}),
             ("batch 6 + swap, ring 8", {"TINYMPC_JIT_DEFS": "-DTINY_WIDE_FAM_BATCH=6 -DTINY_WIDE_FAM_SWAP=1 -DTINY_WIDE_FAM_AHEAD=8"}),
             ("streamed, default (again)", {})]
+if len(sys.argv) > 1:  # custom variants: each argument one TINYMPC_JIT_DEFS string ("" = default)
+    variants = [("streamed, default", {})] + [(a, {"TINYMPC_JIT_DEFS": a}) for a in sys.argv[1:]] + [("streamed, default (again)", {})]
 for name, env in variants:
     o = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), capture_output=True, text=True)
     try:
         d = json.loads(o.stdout.strip().splitlines()[-1])
-        print(f"{name:32s} " + "   ".join(f"{m:7.3f} ms layout {l} u0 {h}" for m, l, j, h in d), flush=True)
+        print(f"{name:48s} " + "   ".join(f"{m:7.3f} ms layout {l} u0 {h} [{j[9:]}]" for m, l, j, h in d), flush=True)
     except Exception:
         print(name, "FAILED", o.stderr[-300:], flush=True)
