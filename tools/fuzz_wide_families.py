@@ -5,9 +5,10 @@ share rows (rounds), an input cone, up to 6 linear rows per side, fdyn, constant
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as g
 import pyoracle as O
+from wide_case import draw  # (tools/repro_wide_case.py replays a case of this generator)
 pkg = g.load_package(); P = pkg.problems
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -15,39 +16,21 @@ os.environ.pop("TINYMPC_LAYOUT", None)
 fails, worst, on_d = 0, 0.0, 0
 for case in range(count):
     t0 = time.time()
-    nxu = int(rng.integers(17, 65))
-    nu = int(rng.integers(2, max(3, nxu // 4)))
-    nx = nxu - nu
-    N = int(rng.integers(4, 41))
-    batch = int(rng.choice([16, 33, 70, 300]))
-    A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
-    Bm = 0.3 * rng.standard_normal((nx, nu))
-    prob = P.Problem("widefuzz", A, Bm, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, float(rng.uniform(0.5, 3.0)), rng.standard_normal(nx))
+    c = draw(rng)
+    nx, nu, N, batch = c["nx"], c["nu"], c["N"], c["batch"]
+    prob = P.Problem("widefuzz", c["A"], c["B"], c["Q"], c["R"], N, c["rho"], c["xref"])
     prob.x_min, prob.x_max = np.full(nx, -3.0), np.full(nx, 3.0)
     prob.u_min, prob.u_max = np.full(nu, -1.0), np.full(nu, 1.0)
-    if rng.integers(0, 2): prob.fdyn = 0.01 * rng.standard_normal(nx)
-    ncx = int(rng.integers(0, 4))
-    Acx, qcx, cx = [], [], []
-    for c in range(ncx):
-        q = int(rng.integers(2, 6)); a = int(rng.integers(0, nx - q + 1))
-        if c == 2 and Acx: a = min(Acx[0] + 1, nx - q)  # shares rows with the first cone: a second round
-        Acx.append(a); qcx.append(q); cx.append(float(rng.uniform(0.4, 1.5)))
-    has_cu = bool(rng.integers(0, 2)) and nu >= 2
-    qcu = [int(rng.integers(2, min(nu, 4) + 1))] if has_cu else []
-    prob.cones = dict(Acx=Acx, qcx=qcx, cx=cx, Acu=[0] if has_cu else [], qcu=qcu, cu=[0.7] if has_cu else [])
-    nlx, nlu = int(rng.integers(0, 7)), int(rng.integers(0, 4))
-    if not (ncx or has_cu or nlx or nlu): nlx = 1
-    prob.linear = dict(Alin_x=rng.standard_normal((nlx, nx)), blin_x=rng.uniform(0.5, 1.5, nlx), Alin_u=rng.standard_normal((nlu, nu)), blin_u=rng.uniform(0.3, 0.8, nlu))
-    settings = dict(max_iter=int(rng.integers(20, 80)), abs_pri_tol=1e-3, abs_dua_tol=1e-3, check_termination=int(rng.choice([1, 1, 3])))
+    prob.fdyn, prob.cones, prob.linear = c["fdyn"], c["cones"], c["linear"]
+    settings, varying, x0s = c["settings"], c["scale"] is not None, c["x0s"]
+    ncx, has_cu, nlx, nlu = len(prob.cones["Acx"]), bool(prob.cones["Acu"]), len(prob.linear["blin_x"]), len(prob.linear["blin_u"])
     s = pkg.TinyMPC()
     s.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=batch, rho=prob.rho, fdyn=prob.fdyn, **settings)
     xmin, xmax = prob.x_min, prob.x_max
-    varying = bool(rng.integers(0, 3) == 0)
     if varying:
-        xmin = np.repeat(prob.x_min[:, None], N, 1) * rng.uniform(0.8, 1.0, (1, N)); xmax = -xmin
+        xmin = np.repeat(prob.x_min[:, None], N, 1) * c["scale"]; xmax = -xmin
     s.set_bound_constraints(xmin, xmax, prob.u_min, prob.u_max)
     s.set_cone_constraints(**prob.cones); s.set_linear_constraints(**prob.linear)
-    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.1, 1.0, batch)[None, :]
     checked = sorted({0, batch // 2, batch - 1})
     orcs = {}
     for b in checked:

@@ -1,44 +1,15 @@
 """One case of tools/fuzz_wide_families.py again, by (seed, case number), with parts of it switched off -- to find what a failing
-case's error depends on. The generator below draws EXACTLY what the fuzzer draws, in its order, so the case is the fuzzer's.
+case's error depends on (the generator is the fuzzer's: tools/wide_case.py).
     python tools/repro_wide_case.py <seed> <case> [variant ...]
 variants: base layoutA nocones nolinear nocu nolu nolx const N=<n> batch=<n> iters=<n> noswap"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as g
 import pyoracle as O
+from wide_case import draw  # (the fuzzer's own generator)
 pkg = g.load_package(); P = pkg.problems
-
-
-def draw(rng):
-    nxu = int(rng.integers(17, 65))
-    nu = int(rng.integers(2, max(3, nxu // 4)))
-    nx = nxu - nu
-    N = int(rng.integers(4, 41))
-    batch = int(rng.choice([16, 33, 70, 300]))
-    A = 0.9 * np.eye(nx) + (0.15 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
-    Bm = 0.3 * rng.standard_normal((nx, nu))
-    Q, R = np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu))
-    rho, xref = float(rng.uniform(0.5, 3.0)), rng.standard_normal(nx)
-    fdyn = 0.01 * rng.standard_normal(nx) if rng.integers(0, 2) else None
-    ncx = int(rng.integers(0, 4))
-    Acx, qcx, cx = [], [], []
-    for c in range(ncx):
-        q = int(rng.integers(2, 6)); a = int(rng.integers(0, nx - q + 1))
-        if c == 2 and Acx: a = min(Acx[0] + 1, nx - q)
-        Acx.append(a); qcx.append(q); cx.append(float(rng.uniform(0.4, 1.5)))
-    has_cu = bool(rng.integers(0, 2)) and nu >= 2
-    qcu = [int(rng.integers(2, min(nu, 4) + 1))] if has_cu else []
-    cones = dict(Acx=Acx, qcx=qcx, cx=cx, Acu=[0] if has_cu else [], qcu=qcu, cu=[0.7] if has_cu else [])
-    nlx, nlu = int(rng.integers(0, 7)), int(rng.integers(0, 4))
-    if not (ncx or has_cu or nlx or nlu): nlx = 1
-    linear = dict(Alin_x=rng.standard_normal((nlx, nx)), blin_x=rng.uniform(0.5, 1.5, nlx), Alin_u=rng.standard_normal((nlu, nu)), blin_u=rng.uniform(0.3, 0.8, nlu))
-    settings = dict(max_iter=int(rng.integers(20, 80)), abs_pri_tol=1e-3, abs_dua_tol=1e-3, check_termination=int(rng.choice([1, 1, 3])))
-    varying = bool(rng.integers(0, 3) == 0)
-    scale = rng.uniform(0.8, 1.0, (1, N)) if varying else None
-    x0s = rng.standard_normal((nx, batch)) * np.linspace(0.1, 1.0, batch)[None, :]
-    return dict(nx=nx, nu=nu, N=N, batch=batch, A=A, B=Bm, Q=Q, R=R, rho=rho, xref=xref, fdyn=fdyn, cones=cones, linear=linear, settings=settings, scale=scale, x0s=x0s)
 
 
 def run(c, variant):
