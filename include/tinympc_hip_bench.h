@@ -5,6 +5,7 @@
  *   tinympc_bench_closed_loop      libtinympc_bench.so  (tinympc-matlab_amd/csrc/bench/tinympc_bench_loop.cpp: public verbs only)
  *   tinympc_debug_tick_timing      libtinympc_hip.so    (reads the handle's diagnostic counters)
  *   tinympc_debug_setup_timing     libtinympc_hip.so
+ *   tinympc_debug_mail_stamp       libtinympc_hip.so    (the session mailbox's line stamp, for the tests of its checksum)
  */
 #ifndef TINYMPC_HIP_BENCH_H
 #define TINYMPC_HIP_BENCH_H
@@ -34,6 +35,10 @@ int tinympc_debug_tick_timing(tinympc_solver *s, double *out4);
  * [7] shader clocks and [8] microseconds (100 MHz counter) of the Riccati loop inside k_precompute_rows (0 where another precompute
  * kernel ran), [9] the Riccati steps taken. */
 int tinympc_debug_setup_timing(tinympc_solver *s, double *out10);
+
+/* The stamp the session protocol puts behind a 64-byte line's seven payload words (tinympc_device.h: mail_stamp over mail_mix): sequence
+ * number + a 16-bit order-dependent checksum of the words and of the sequence number. No handle, no GPU. */
+double tinympc_debug_mail_stamp(double sequence_number, const double *words7);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,33 @@ def test_measurement_helpers_live_outside_the_boundary(pkg):
     assert bench.tinympc_bench_closed_loop(None, 2, 1, 5, p, p, None, p, 5, 1, 0, None, None, None) == L.ERR_INVALID_INPUT
 
 
+def test_session_line_stamp_tells_saturated_controls_from_an_empty_line(pkg):
+    """The session protocol accepts a 64-byte line when its stamp fits the seven words read with it. Through most of round 5 the checksum
+    was the folded XOR of the words: equal words cancelled, so four saturated controls (+0.4, +0.4, -0.4, -0.4) had the checksum of a
+    line of zeros, and a host that read a line's payload just before the resident kernel's answer landed and its stamp just after took
+    the zeros (one tick in ~3,000 of tools/fuzz_layout_f.py; profiles/r05_session_stamp_bug.txt). Now order-dependent and multiplicative."""
+    lib = pkg.load_library()
+
+    def stamp(seq, words):
+        w = np.zeros(7)
+        w[:len(words)] = words
+        return lib.tinympc_debug_mail_stamp(float(seq), w.ctypes.data_as(pkg._lib.c_double_p))
+
+    zero = stamp(1, [])
+    assert 1.0 <= zero < 2.0
+    sat = [[0.4, 0.4, -0.4, -0.4], [0.4, -0.4, 0.4, -0.4], [-0.4, -0.4, 0.4, 0.4], [0.4, 0.4], [0.25, 0.25, 0.25, 0.25], [1.0, 1.0, -1.0, -1.0, 0.3, 0.3]]
+    for u in sat:
+        assert stamp(1, u) != zero, u
+    assert stamp(1, [0.4, -0.4]) != stamp(1, [-0.4, 0.4])             # the order of the words counts
+    assert stamp(7, [0.1, 0.2]) - 7 != stamp(8, [0.1, 0.2]) - 8      # ... and the sequence number (a line of another tick with the same words)
+    assert len({stamp(3, [0.4 * a, 0.4 * b, 0.4 * c, 0.4 * d]) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1) for d in (-1, 1)}) >= 15
+    big = 2.0 ** 35 + 12345.0
+    assert int(stamp(big, [0.3])) == int(big) and 0.0 <= stamp(big, [0.3]) - big < 1.0  # exact below 2^36
+    rng = np.random.default_rng(0)
+    seen = {stamp(5, rng.standard_normal(7)) for _ in range(2000)}
+    assert len(seen) > 1900  # 16 bits: ~30 collisions expected among 2,000
+
+
 def test_seventeen_mex_verbs_have_entry_points(pkg):
     """One C entry point per verb of the reference dispatcher (bindings.cpp:641-692)."""
     verbs = ["setup", "set_x0", "set_x_ref", "set_u_ref", "solve", "get_solution", "get_stats", "codegen", "reset",

@@ -108,6 +108,7 @@ BENCH_SIGNATURES = {
 DEBUG_SIGNATURES = {  # (exported by the product library itself: they read the handle's diagnostic counters)
     "tinympc_debug_tick_timing": (C.c_int, [Handle, c_double_p]),
     "tinympc_debug_setup_timing": (C.c_int, [Handle, c_double_p]),
+    "tinympc_debug_mail_stamp": (C.c_double, [C.c_double, c_double_p]),
 }
 
 _lib = None

@@ -94,15 +94,25 @@ struct TableParams {
     double *tables;
 };
 
-// Stamp of a session-mailbox line: the command's sequence number plus a 12-bit checksum of the line's seven payload words
-// (xor of their bit patterns, folded), as a fraction -- exact in a double for every sequence number below 2^40. Host and
-// kernel compute it the same way; the kernel accepts a line only if the stamp fits the payload it read with it.
-__host__ __device__ inline double mail_stamp(double seq, unsigned long long payload_xor) {
-    unsigned long long x = payload_xor;
-    x ^= x >> 32;
-    x ^= x >> 16;
-    x ^= x >> 8;
-    return seq + (double)(unsigned)(x & 0xfffull) * (1.0 / 4096.0);
+// Stamp of a session-mailbox line: the command's sequence number plus a 16-bit checksum of the line's seven payload words and of the
+// sequence number itself, as a fraction -- exact in a double for every sequence number below 2^36. Host and kernel compute it the
+// same way; a reader accepts a line only if the stamp fits the payload it read with it. The checksum is ORDER-DEPENDENT and
+// multiplicative (mail_mix over the words, in order): through most of round 5 it was the folded XOR of the words, under which equal words
+// cancel -- four saturated controls (+-0.4, +-0.4) had the checksum of an all-zero line, and a host that read a line's payload just before
+// the kernel's answer landed and its stamp just after took zeros for the answer (tools/fuzz_layout_f.py, 1 tick in ~3,000;
+// profiles/r05_session_stamp_bug.txt). Readers also look at the stamp FIRST now (tinympc_session.hip).
+__host__ __device__ inline unsigned long long mail_mix(unsigned long long h, unsigned long long word_bits) {
+    unsigned a = (unsigned)h, b = (unsigned)(h >> 32);
+    a = (a ^ (unsigned)word_bits) * 0x9E3779B1u + 0x7F4A7C15u;
+    a ^= a >> 15;
+    b = (b + (unsigned)(word_bits >> 32) + a) * 0x85EBCA77u;
+    b ^= b >> 13;
+    return ((unsigned long long)b << 32) | (unsigned long long)a;
+}
+__host__ __device__ inline double mail_stamp(double seq, unsigned long long payload_hash) {
+    unsigned f = (unsigned)payload_hash ^ (unsigned)(payload_hash >> 32) ^ ((unsigned)(unsigned long long)seq * 0xC2B2AE3Du);
+    f ^= f >> 16;
+    return seq + (double)(f & 0xffffu) * (1.0 / 65536.0);
 }
 
 struct SolveParams {

@@ -48,7 +48,7 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
             m[8 * l + q % 7] = pay[q];
             unsigned long long bits;
             std::memcpy(&bits, &pay[q], sizeof bits);
-            x ^= bits;
+            x = tinympc::mail_mix(x, bits);
         }
         std::atomic_thread_fence(std::memory_order_release);
         m[8 * l + 7] = tinympc::mail_stamp(seq, x);  // (sequence number + checksum of the line's payload, see tinympc_device.h)
@@ -89,6 +89,11 @@ int launch_session_kernel(tinympc_solver *s) {
     p.families = fam ? 1 : 0;
     p.mail = s->mailbox();
     p.host_ans = s->h_ans;  // (both resident kernels answer early, see SolveParams::host_ans)
+    // (the pinned arena may have served another handle's session before -- arenas are pooled since round 5 --, whose last answer line is a
+    // VALID line for its sequence number: nothing of it may look like an answer of this session)
+    if (s->h_ans) for (int i = 0; i < 32; ++i) s->h_ans[i] = -1.0;
+    if (s->h_sol) s->h_sol[s->X() + s->U() + 6] = -1.0;  // (the completion stamp of solution + statistics, likewise)
+    std::atomic_thread_fence(std::memory_order_seq_cst);
     p.session_expect = (double)(s->session_seq + 1);
     p.session_idle = (unsigned long long)(kSessionIdleSeconds * 1e8);
     if (s->session_on_f) {
@@ -197,6 +202,12 @@ int tinympc_session_begin(tinympc_solver *s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     {
         std::lock_guard<std::mutex> tick(s->session_mu);
+        // (a pooled arena's mailbox still holds the last command of the session it served before -- a valid line for ITS sequence number,
+        // possibly the stop command: no stamp of it may survive into this session)
+        volatile double *m = s->mailbox();
+        for (int l = 0; l < 7; ++l) m[8 * l + 7] = -1.0;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        _mm_sfence();
         if ((rc = launch_session_kernel(s))) return rc;
         s->session_active = true;
         s->flag_pending = false;
@@ -235,19 +246,26 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
     const bool early = s->h_ans != nullptr;
     const int nlines = (s->nu + 6) / 7;
     double u0_lines[24];
+    // Reading order: the STAMP first. The kernel stores a line with one 64-byte store; once the stamp shows this tick's sequence number
+    // the payload read behind it is this tick's (x86 does not reorder loads). Payload first and stamp last -- the order of rounds 4-5 --
+    // left a window of a few nanoseconds in which the answer could land between the two: old payload, new stamp, and only the checksum to
+    // tell (which, as a folded XOR, four saturated controls shared with a line of zeros). The checksum and a second look at the stamp
+    // stay, for a line that should ever arrive in pieces.
     auto answered = [&]() -> bool {
         if (!early) return *done == want;
         const volatile double *a = s->h_ans;
         for (int l = 0; l < nlines; ++l) {
+            const double stamp = a[8 * l + 7];
+            if (!(stamp >= want && stamp < want + 1.0)) return false;
             unsigned long long x = 0ull;
             for (int q = 0; q < 7; ++q) {
                 const double v = a[8 * l + q];
                 u0_lines[7 * l + q] = v;
                 unsigned long long bits;
                 std::memcpy(&bits, &v, sizeof bits);
-                x ^= bits;
+                x = tinympc::mail_mix(x, bits);
             }
-            if (a[8 * l + 7] != tinympc::mail_stamp(want, x)) return false;
+            if (stamp != tinympc::mail_stamp(want, x) || a[8 * l + 7] != stamp) return false;
         }
         return true;
     };

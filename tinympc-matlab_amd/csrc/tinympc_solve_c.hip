@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             auto line_ok = [&](int l) -> bool {
                 unsigned long long x = 0ull;
 #pragma unroll
-                for (int q = 0; q < 7; ++q) x ^= (unsigned long long)__double_as_longlong(sMail[8 * l + q]);
+                for (int q = 0; q < 7; ++q) x = mail_mix(x, (unsigned long long)__double_as_longlong(sMail[8 * l + q]));
                 return sMail[8 * l + 7] == mail_stamp(expect, x);
             };
             go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 for (int q = 0; q < 7; ++q) {
                     const int idx = line * 7 + q;
                     const double val = idx < nu ? sMail[idx] : 0.0;
-                    x ^= (unsigned long long)__double_as_longlong(val);
+                    x = mail_mix(x, (unsigned long long)__double_as_longlong(val));
                     if (q == slot) mine = val;
                 }
                 host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, x) : mine);

@@ -407,7 +407,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             auto line_ok = [&](int l) -> bool {
                 unsigned long long x = 0ull;
 #pragma unroll
-                for (int q = 0; q < 7; ++q) x ^= (unsigned long long)__builtin_bit_cast(long long, sMail[8 * l + q]);
+                for (int q = 0; q < 7; ++q) x = mail_mix(x, (unsigned long long)__builtin_bit_cast(long long, sMail[8 * l + q]));
                 return sMail[8 * l + 7] == mail_stamp(expect, x);
             };
             go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
@@ -723,7 +723,7 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
             for (int q = 0; q < 7; ++q) {
                 const int idx = line * 7 + q;
                 const double v = idx < NU ? sMail[idx] : 0.0;
-                x ^= (unsigned long long)__builtin_bit_cast(long long, v);
+                x = mail_mix(x, (unsigned long long)__builtin_bit_cast(long long, v));
                 if (q == slot) mine = v;
             }
             host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, x) : mine);

@@ -2,7 +2,8 @@
 random cones / linear rows (both forms of the families), constant and per-knot tables, fdyn; launched solves (cold + warm), then -- for
 one instance -- a resident session of closed-loop ticks whose results must equal launched ticks of a twin handle bit for bit, with the
 references re-sent on some ticks. Against the oracle: iteration counts, statuses, trajectories.
-  python tools/fuzz_layout_f.py [count] [seed] > gpurun_out/r04_fuzz_layout_f.txt"""
+  python tools/fuzz_layout_f.py [count] [seed] > gpurun_out/r04_fuzz_layout_f.txt
+  FUZZ_ONLY_CASE=<n>: draw every case (the generator's stream stays the fuzzer's) but solve only case n, with a line per session tick"""
 import os
 import sys
 import time
@@ -20,6 +21,7 @@ P = pkg.problems
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 os.environ.pop("TINYMPC_LAYOUT", None)
+only = int(os.environ["FUZZ_ONLY_CASE"]) if "FUZZ_ONLY_CASE" in os.environ else None
 fails, worst, on_f, sessions = 0, 0.0, 0, 0
 for case in range(count):
     nxu = int(rng.integers(3, 17))
@@ -70,6 +72,9 @@ for case in range(count):
         return s
 
     t0 = time.time()
+    if only is not None and case != only:
+        rng.standard_normal((nx, batch))  # (x0s: keeps the stream in step)
+        continue
     s = handle()
     x0s = rng.standard_normal((nx, batch)) * np.linspace(0.3, 1.0, batch)[None, :]
     sample = sorted({0, batch // 2, batch - 1})
@@ -85,6 +90,8 @@ for case in range(count):
             ox, ou = orcs[b].solution()
             e = max(e, np.max(np.abs(sol["states"][:, :, b] - ox)) / max(np.max(np.abs(ox)), 1e-300), np.max(np.abs(sol["controls"][:, :, b] - ou)) / max(np.max(np.abs(ou)), 1e-300))
             ok = ok and st["iter"][b] == orcs[b].stats()["iter"] and st["status"][b] == orcs[b].stats()["status"]
+            if only is not None:
+                print(f"    launched solve {rnd} instance {b}: iter {st['iter'][b]} / oracle {orcs[b].stats()['iter']}, status {st['status'][b]} / {orcs[b].stats()['status']}", flush=True)
     layout = s.launch_info()["layout"]
     on_f += layout == "F"
     sess = ""
@@ -106,6 +113,8 @@ for case in range(count):
                 ua = s.session_step(x)
                 ub = twin.mpc_step(x)[:, 0]
                 same = same and np.array_equal(ua, ub) and s.get_stats()["iter"] == twin.get_stats()["iter"]
+                if only is not None:
+                    print(f"    tick {k:2d}: session iter {s.get_stats()['iter']} status {s.get_stats()['status']} | launched iter {twin.get_stats()['iter']} status {twin.get_stats()['status']} | max |u0 diff| {np.max(np.abs(ua - ub)):.3e}", flush=True)
                 x = prob.A @ x + prob.B @ ua + (prob.fdyn if prob.fdyn is not None else 0.0)
             s.session_end()
             sessions += 1
@@ -114,6 +123,26 @@ for case in range(count):
         except pkg.TinyMPCError as err:
             sess = " (no session: %s)" % str(err)[:60]
         twin.reset()
+    if only is not None and batch == 1 and "FUZZ_REPEAT" in os.environ:  # the session part again and again: fresh handle + twin, ticks compared one by one
+        nrep, nticks, nbad = int(os.environ["FUZZ_REPEAT"]), int(os.environ.get("FUZZ_TICKS", "12")), 0
+        for rep in range(nrep):
+            a, b = handle(), handle()
+            x = x0s[:, 0].copy()
+            a.session_begin()
+            for k in range(nticks):
+                ua = a.session_step(x)
+                sa = a.get_stats()
+                ub = b.mpc_step(x)[:, 0]
+                sb = b.get_stats()
+                if not (np.array_equal(ua, ub) and sa["iter"] == sb["iter"]):
+                    nbad += 1
+                    xa, xb = a.get_solution(), b.get_solution()
+                    print(f"    rep {rep} tick {k}: session iter {sa['iter']} status {sa['status']} | launched iter {sb['iter']} status {sb['status']} | max |u0 diff| {np.max(np.abs(ua - ub)):.3e} "
+                          f"| whole solution: states {np.max(np.abs(xa['states'] - xb['states'])):.3e} controls {np.max(np.abs(xa['controls'] - xb['controls'])):.3e} | u0 from get_solution vs step {np.max(np.abs(xa['controls'][:, 0] - ua)):.3e}", flush=True)
+                    break
+                x = prob.A @ x + prob.B @ ua + (prob.fdyn if prob.fdyn is not None else 0.0)
+            a.session_end(); a.reset(); b.reset()
+        print(f"    {nrep} repetitions of {nticks} ticks: {nbad} with a tick that differs", flush=True)
     worst = max(worst, e)
     bad = (not ok) or e > 1e-6
     fails += bad
