@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
             // nothing in PCIe promises they are one snapshot -- fails the test and is simply repeated.
             auto line_ok = [&](int l) -> bool {
                 unsigned long long x = 0ull;
-#pragma unroll
+#pragma unroll 1  // (a rolled loop: the families' resident variant has no register to spare for seven words in flight)
                 for (int q = 0; q < 7; ++q) x = mail_mix(x, (unsigned long long)__double_as_longlong(sMail[8 * l + q]));
                 return sMail[8 * l + 7] == mail_stamp(expect, x);
             };
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 const int line = tid >> 3, slot = tid & 7;
                 unsigned long long x = 0ull;
                 double mine = 0.0;
-#pragma unroll
+#pragma unroll 1
                 for (int q = 0; q < 7; ++q) {
                     const int idx = line * 7 + q;
                     const double val = idx < nu ? sMail[idx] : 0.0;
