@@ -565,15 +565,7 @@ int tinympc_debug_setup_timing(tinympc_solver *s, double *out10) {
     return TINYMPC_OK;
 }
 
-double tinympc_debug_mail_stamp(double sequence_number, const double *words7) {
-    unsigned long long h = 0ull;
-    for (int q = 0; q < 7; ++q) {
-        unsigned long long bits;
-        std::memcpy(&bits, &words7[q], sizeof bits);
-        h = tinympc::mail_mix(h, bits);
-    }
-    return tinympc::mail_stamp(sequence_number, h);
-}
+double tinympc_debug_mail_stamp(double sequence_number, const double *words7) { return tinympc::mail_stamp_of(sequence_number, words7); }
 
 int tinympc_debug_tick_timing(tinympc_solver *s, double *out4) {
     int rc = check_handle(s);

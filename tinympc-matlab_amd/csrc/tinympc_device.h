@@ -96,23 +96,55 @@ struct TableParams {
 
 // Stamp of a session-mailbox line: the command's sequence number plus a 16-bit checksum of the line's seven payload words and of the
 // sequence number itself, as a fraction -- exact in a double for every sequence number below 2^36. Host and kernel compute it the
-// same way; a reader accepts a line only if the stamp fits the payload it read with it. The checksum is ORDER-DEPENDENT and
-// multiplicative (mail_mix over the words, in order): through most of round 5 it was the folded XOR of the words, under which equal words
+// same way; a reader accepts a line only if the stamp fits the payload it read with it. The checksum is POSITION-DEPENDENT and
+// multiplicative (mail_term per word): through most of round 5 it was the folded XOR of the words, under which equal words
 // cancel -- four saturated controls (+-0.4, +-0.4) had the checksum of an all-zero line, and a host that read a line's payload just before
 // the kernel's answer landed and its stamp just after took zeros for the answer (tools/fuzz_layout_f.py, 1 tick in ~3,000;
 // profiles/r05_session_stamp_bug.txt). Readers also look at the stamp FIRST now (tinympc_session.hip).
-__host__ __device__ inline unsigned long long mail_mix(unsigned long long h, unsigned long long word_bits) {
-    unsigned a = (unsigned)h, b = (unsigned)(h >> 32);
-    a = (a ^ (unsigned)word_bits) * 0x9E3779B1u + 0x7F4A7C15u;
-    a ^= a >> 15;
-    b = (b + (unsigned)(word_bits >> 32) + a) * 0x85EBCA77u;
-    b ^= b >> 13;
-    return ((unsigned long long)b << 32) | (unsigned long long)a;
+// (the checksum: XOR over the seven words of one multiplicative term per word whose multipliers depend on the word's POSITION -- equal
+// words at different places do not cancel, swapped words change it -- so that the seven terms can be computed by seven lanes at once and
+// combined in three DPP steps: the sequential form of the first fix cost the resident kernels ~0.5 us per tick.)
+__host__ __device__ inline unsigned mail_term(unsigned long long word_bits, int position) {
+    // (three multiplies, the high half rotated before it enters: a double's sign bit is the TOP bit of its high half, and a multiplication
+    // only carries upwards -- with the high half entering as it is, swapping +0.4 and -0.4 between two positions left the checksum unchanged)
+    const unsigned c1 = 0x9E3779B1u + 0x3C6EF372u * (unsigned)position, c2 = 0x85EBCA77u + 0x27D4EB2Eu * (unsigned)position;  // (odd)
+    const unsigned lo = (unsigned)word_bits, hi = (unsigned)(word_bits >> 32);
+    unsigned t = (lo + 0x7F4A7C15u) * c1;
+    t ^= t >> 16;
+    unsigned u = (((hi << 11) | (hi >> 21)) + t) * c2;
+    u ^= u >> 15;
+    u *= c1;
+    return u ^ (u >> 13);
 }
-__host__ __device__ inline double mail_stamp(double seq, unsigned long long payload_hash) {
-    unsigned f = (unsigned)payload_hash ^ (unsigned)(payload_hash >> 32) ^ ((unsigned)(unsigned long long)seq * 0xC2B2AE3Du);
+__host__ __device__ inline double mail_stamp(double seq, unsigned payload_hash) {
+    unsigned f = payload_hash ^ ((unsigned)(unsigned long long)seq * 0xC2B2AE3Du);
     f ^= f >> 16;
     return seq + (double)(f & 0xffffu) * (1.0 / 65536.0);
+}
+// host side / tests: the stamp of seven words
+__host__ __device__ inline double mail_stamp_of(double seq, const double *words7) {
+    unsigned h = 0u;
+    for (int q = 0; q < 7; ++q) h ^= mail_term((unsigned long long)__builtin_bit_cast(long long, words7[q]), q);
+    return mail_stamp(seq, h);
+}
+// XOR over each aligned group of eight lanes (a 64-byte line held one word per lane), the same value in all eight: two quad steps and
+// the other quad of the half row, on the DPP crossbar. All lanes of the groups that take part must be active.
+__device__ __forceinline__ unsigned mail_xor8(unsigned t) {
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    t ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    return t;
+}
+// The mailbox as one wavefront holds it after ONE load instruction -- lane t: word t & 7 of line t >> 3, lanes 56.. hold nothing --: bit l of
+// the result says that line l's stamp is `expect` plus the checksum of the seven words that came with it. Wave-uniform; all 64 lanes active.
+__device__ __forceinline__ unsigned mail_lines_ok(double word, int lane, double expect) {
+    const int slot = lane & 7;
+    const unsigned h = mail_xor8((lane < 56 && slot < 7) ? mail_term((unsigned long long)__builtin_bit_cast(long long, word), slot) : 0u);
+    const unsigned long long fits = __ballot(lane < 56 && slot == 7 && word == mail_stamp(expect, h));
+    unsigned ok = 0u;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) ok |= (unsigned)((fits >> (8 * l + 7)) & 1ull) << l;
+    return ok;
 }
 
 struct SolveParams {

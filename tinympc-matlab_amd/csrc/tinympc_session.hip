@@ -43,15 +43,9 @@ void write_command(tinympc_solver *s, int flags, const double *x0) {
     const int nlines = (npay + 6) / 7;
     for (int q = npay; q < 7 * nlines; ++q) pay[q] = 0.0;  // (every word of a used line is written: the stamp covers all seven)
     for (int l = 0; l < nlines; ++l) {
-        unsigned long long x = 0ull;
-        for (int q = 7 * l; q < 7 * l + 7; ++q) {
-            m[8 * l + q % 7] = pay[q];
-            unsigned long long bits;
-            std::memcpy(&bits, &pay[q], sizeof bits);
-            x = tinympc::mail_mix(x, bits);
-        }
+        for (int q = 7 * l; q < 7 * l + 7; ++q) m[8 * l + q % 7] = pay[q];
         std::atomic_thread_fence(std::memory_order_release);
-        m[8 * l + 7] = tinympc::mail_stamp(seq, x);  // (sequence number + checksum of the line's payload, see tinympc_device.h)
+        m[8 * l + 7] = tinympc::mail_stamp_of(seq, pay + 7 * l);  // (sequence number + checksum of the line's payload, see tinympc_device.h)
     }
     std::atomic_thread_fence(std::memory_order_seq_cst);
     _mm_sfence();  // (a mailbox behind the BAR is write-combining memory: push the lines out now, not when the buffer is evicted)
@@ -257,15 +251,8 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
         for (int l = 0; l < nlines; ++l) {
             const double stamp = a[8 * l + 7];
             if (!(stamp >= want && stamp < want + 1.0)) return false;
-            unsigned long long x = 0ull;
-            for (int q = 0; q < 7; ++q) {
-                const double v = a[8 * l + q];
-                u0_lines[7 * l + q] = v;
-                unsigned long long bits;
-                std::memcpy(&bits, &v, sizeof bits);
-                x = tinympc::mail_mix(x, bits);
-            }
-            if (stamp != tinympc::mail_stamp(want, x) || a[8 * l + 7] != stamp) return false;
+            for (int q = 0; q < 7; ++q) u0_lines[7 * l + q] = a[8 * l + q];
+            if (stamp != tinympc::mail_stamp_of(want, u0_lines + 7 * l) || a[8 * l + 7] != stamp) return false;
         }
         return true;
     };

@@ -516,22 +516,28 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
         // payload: 0 flags | 1.. x0 (nx) | new last column of x_ref (nx, flag 4) | new last column of u_ref (nu, flag 8)
         bool go = false, quit = false;
         while (!go && !quit) {
-            if (tid < 56) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (tid == 0) sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+            // Wavefront 0 fetches the mailbox -- lanes 0..55: the seven lines in ONE load instruction -- and decides in registers: a line
+            // is accepted when its stamp is `expect` plus the checksum of the seven payload words READ WITH IT (mail_lines_ok,
+            // tinympc_device.h): a poll that caught a line half-written -- the 64 bytes come in one load, but nothing in PCIe
+            // promises they are one snapshot -- fails the test and is simply repeated. Line 0 carries the flags, which say how many
+            // lines the command uses. Words, the time-out's verdict and the decision reach the other wavefronts through sMail.
+            if (tid < 64) {
+                const double w = tid < 56 ? __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+                const unsigned ok = mail_lines_ok(w, tid, expect);
+                const unsigned long long w0 = (unsigned long long)__double_as_longlong(w);
+                const double flags_word = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
+                                                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)w0)));
+                const int f0 = (ok & 1u) ? (int)flags_word : 0;
+                const int npay = 1 + nx + ((f0 & 4) ? nx : 0) + ((f0 & 8) ? nu : 0), nlines = (npay + 6) / 7;
+                const unsigned need = (1u << nlines) - 1u;
+                if (tid < 56) sMail[tid] = w;
+                if (tid == 0) {
+                    sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+                    sMail[57] = ((ok & need) == need) ? 1.0 : 0.0;
+                }
+            }
             __syncthreads();
-            // A line is accepted when its stamp is `expect` plus the checksum of the seven payload words READ WITH IT
-            // (mail_stamp, tinympc_device.h): a poll that caught a line half-written -- the 64 bytes come in one load, but
-            // nothing in PCIe promises they are one snapshot -- fails the test and is simply repeated.
-            auto line_ok = [&](int l) -> bool {
-                unsigned long long x = 0ull;
-#pragma unroll 1  // (a rolled loop: the families' resident variant has no register to spare for seven words in flight)
-                for (int q = 0; q < 7; ++q) x = mail_mix(x, (unsigned long long)__double_as_longlong(sMail[8 * l + q]));
-                return sMail[8 * l + 7] == mail_stamp(expect, x);
-            };
-            go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
-            const int f0 = go ? (int)sMail[0] : 0;
-            const int npay = 1 + nx + ((f0 & 4) ? nx : 0) + ((f0 & 8) ? nu : 0), nlines = (npay + 6) / 7;
-            for (int l = 1; l < nlines; ++l) go = go && line_ok(l);
+            go = sMail[57] != 0.0;
             quit = !go && sMail[56] != 0.0;
             __syncthreads();  // (the next poll overwrites sMail)
         }
@@ -760,18 +766,11 @@ __global__ void __launch_bounds__(CTHREADS) k_admm_solve_c(const SolveParams p) 
                 if (ok[i] && !is_x && (c * S + i + koff) == 0) sMail[r - nx] = v[i];  // (the command in sMail has been consumed)
             __syncthreads();
             const int nla = (nu + 6) / 7;
-            if (tid < 8 * nla) {
-                const int line = tid >> 3, slot = tid & 7;
-                unsigned long long x = 0ull;
-                double mine = 0.0;
-#pragma unroll 1
-                for (int q = 0; q < 7; ++q) {
-                    const int idx = line * 7 + q;
-                    const double val = idx < nu ? sMail[idx] : 0.0;
-                    x = mail_mix(x, (unsigned long long)__double_as_longlong(val));
-                    if (q == slot) mine = val;
-                }
-                host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, x) : mine);
+            if (tid < 8 * nla) {  // (whole groups of eight lanes: mail_xor8)
+                const int line = tid >> 3, slot = tid & 7, idx = line * 7 + slot;
+                const double mine = (slot < 7 && idx < nu) ? sMail[idx] : 0.0;
+                const unsigned h = mail_xor8(slot < 7 ? mail_term((unsigned long long)__double_as_longlong(mine), slot) : 0u);
+                host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, h) : mine);
             }
         }
     }

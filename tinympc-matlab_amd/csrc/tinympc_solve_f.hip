@@ -401,19 +401,23 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         const unsigned long long t_idle0 = __builtin_amdgcn_s_memrealtime();
         bool go = false, quit = false;
         while (!go && !quit) {
-            if (tid < 56) sMail[tid] = __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (tid == 0) sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+            if (tid < 64) {  // wavefront 0 fetches the seven lines in one load and decides in registers (mail_lines_ok, tinympc_device.h)
+                const double w = tid < 56 ? __hip_atomic_load(p.mail + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+                const unsigned ok = mail_lines_ok(w, tid, expect);
+                const unsigned long long w0 = (unsigned long long)__builtin_bit_cast(long long, w);
+                const double flags_word = __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
+                                                                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)w0)));
+                const int f0 = (ok & 1u) ? (int)flags_word : 0;  // line 0 carries the flags, which say how many lines the command uses
+                const int npay = 1 + NX + ((f0 & 4) ? NX : 0) + ((f0 & 8) ? NU : 0), nlines = (npay + 6) / 7;
+                const unsigned need = (1u << nlines) - 1u;
+                if (tid < 56) sMail[tid] = w;
+                if (tid == 0) {
+                    sMail[56] = (__builtin_amdgcn_s_memrealtime() - t_idle0 > p.session_idle) ? 1.0 : 0.0;
+                    sMail[57] = ((ok & need) == need) ? 1.0 : 0.0;
+                }
+            }
             __syncthreads();
-            auto line_ok = [&](int l) -> bool {
-                unsigned long long x = 0ull;
-#pragma unroll
-                for (int q = 0; q < 7; ++q) x = mail_mix(x, (unsigned long long)__builtin_bit_cast(long long, sMail[8 * l + q]));
-                return sMail[8 * l + 7] == mail_stamp(expect, x);
-            };
-            go = line_ok(0);  // line 0 carries the flags, which say how many lines the command uses
-            const int f0 = go ? (int)sMail[0] : 0;
-            const int npay = 1 + NX + ((f0 & 4) ? NX : 0) + ((f0 & 8) ? NU : 0), nlines = (npay + 6) / 7;
-            for (int l = 1; l < nlines; ++l) go = go && line_ok(l);
+            go = sMail[57] != 0.0;
             quit = !go && sMail[56] != 0.0;
             __syncthreads();  // (the next poll overwrites sMail)
         }
@@ -716,17 +720,10 @@ __device__ __forceinline__ void k_admm_solve_f_body(const SolveParams &p, double
         // fenced or waited for here; the solution's write-out below happens while the host already steps its plant.
         constexpr int NLA = (NU + 6) / 7;
         if (p.host_ans && max_iter > 0 && tid < 8 * NLA) {
-            const int line = tid >> 3, slot = tid & 7;
-            unsigned long long x = 0ull;
-            double mine = 0.0;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int idx = line * 7 + q;
-                const double v = idx < NU ? sMail[idx] : 0.0;
-                x = mail_mix(x, (unsigned long long)__builtin_bit_cast(long long, v));
-                if (q == slot) mine = v;
-            }
-            host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, x) : mine);
+            const int line = tid >> 3, slot = tid & 7, idx = line * 7 + slot;  // (whole groups of eight lanes: mail_xor8)
+            const double mine = (slot < 7 && idx < NU) ? sMail[idx] : 0.0;
+            const unsigned h = mail_xor8(slot < 7 ? mail_term((unsigned long long)__builtin_bit_cast(long long, mine), slot) : 0u);
+            host_store(p.host_ans + tid, slot == 7 ? mail_stamp(expect, h) : mine);
         }
     }
 
