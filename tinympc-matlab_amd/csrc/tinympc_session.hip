@@ -83,8 +83,8 @@ int launch_session_kernel(tinympc_solver *s) {
     p.families = fam ? 1 : 0;
     p.mail = s->mailbox();
     p.host_ans = s->h_ans;  // (both resident kernels answer early, see SolveParams::host_ans)
-    // (the pinned arena may have served another handle's session before -- arenas are pooled since round 5 --, whose last answer line is a
-    // VALID line for its sequence number: nothing of it may look like an answer of this session)
+    // (no line of an earlier session of this handle may look like an answer of this one -- its sequence numbers go on, so none would;
+    // setup zeroes the pinned arena, pooled or new; this costs nothing and leaves nothing to those two arguments)
     if (s->h_ans) for (int i = 0; i < 32; ++i) s->h_ans[i] = -1.0;
     if (s->h_sol) s->h_sol[s->X() + s->U() + 6] = -1.0;  // (the completion stamp of solution + statistics, likewise)
     std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -196,8 +196,7 @@ int tinympc_session_begin(tinympc_solver *s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     {
         std::lock_guard<std::mutex> tick(s->session_mu);
-        // (a pooled arena's mailbox still holds the last command of the session it served before -- a valid line for ITS sequence number,
-        // possibly the stop command: no stamp of it may survive into this session)
+        // (likewise the mailbox: no stamp of an earlier session's last command survives into this one)
         volatile double *m = s->mailbox();
         for (int l = 0; l < 7; ++l) m[8 * l + 7] = -1.0;
         std::atomic_thread_fence(std::memory_order_seq_cst);
