@@ -103,7 +103,7 @@ for case in range(count):
         try:
             s.session_begin()
             resident = s.launch_info()["layout"]  # (the resident kernel's layout: C where layout F has none for the configuration)
-            same = True
+            same, close = True, True
             for k in range(12):
                 if prob.x_ref is not None and k % 3 == 1:  # references re-sent (shifted by one knot) on some ticks
                     xr = np.roll(prob.x_ref, -1, axis=1); ur = np.roll(prob.u_ref, -1, axis=1)
@@ -113,13 +113,16 @@ for case in range(count):
                 ua = s.session_step(x)
                 ub = twin.mpc_step(x)[:, 0]
                 same = same and np.array_equal(ua, ub) and s.get_stats()["iter"] == twin.get_stats()["iter"]
+                close = close and np.allclose(ua, ub, rtol=1e-7, atol=1e-9)  # (a session on layout C against launches on F: other rounding, same answer)
                 if only is not None:
                     print(f"    tick {k:2d}: session iter {s.get_stats()['iter']} status {s.get_stats()['status']} | launched iter {twin.get_stats()['iter']} status {twin.get_stats()['status']} | max |u0 diff| {np.max(np.abs(ua - ub)):.3e}", flush=True)
                 x = prob.A @ x + prob.B @ ua + (prob.fdyn if prob.fdyn is not None else 0.0)
             s.session_end()
             sessions += 1
             sess = (" session(%s)==launched" % resident) if same else (" session on layout %s, launches on F: last bits differ" % resident if resident != "F" else " SESSION DIFFERS")
-            ok = ok and (same or resident != "F")  # (a session on the generic latency kernel: documented, not bit-identical to layout F's launches)
+            ok = ok and (same or (resident != "F" and close))  # (a session on the generic latency kernel: documented, not bit-identical to layout F's launches)
+            if resident != "F" and not close:
+                sess += " AND NOT EVEN CLOSE"
         except pkg.TinyMPCError as err:
             sess = " (no session: %s)" % str(err)[:60]
         twin.reset()
