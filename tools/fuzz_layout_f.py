@@ -22,6 +22,8 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 os.environ.pop("TINYMPC_LAYOUT", None)
 only = int(os.environ["FUZZ_ONLY_CASE"]) if "FUZZ_ONLY_CASE" in os.environ else None
+if "FUZZ_LAYOUT" in os.environ:  # (replaying a case on another kernel: FUZZ_LAYOUT=A / C / E)
+    os.environ["TINYMPC_LAYOUT"] = os.environ["FUZZ_LAYOUT"]
 fails, worst, on_f, sessions = 0, 0.0, 0, 0
 for case in range(count):
     nxu = int(rng.integers(3, 17))
@@ -91,7 +93,10 @@ for case in range(count):
             e = max(e, np.max(np.abs(sol["states"][:, :, b] - ox)) / max(np.max(np.abs(ox)), 1e-300), np.max(np.abs(sol["controls"][:, :, b] - ou)) / max(np.max(np.abs(ou)), 1e-300))
             ok = ok and st["iter"][b] == orcs[b].stats()["iter"] and st["status"][b] == orcs[b].stats()["status"]
             if only is not None:
-                print(f"    launched solve {rnd} instance {b}: iter {st['iter'][b]} / oracle {orcs[b].stats()['iter']}, status {st['status'][b]} / {orcs[b].stats()['status']}", flush=True)
+                dxs, dus = np.abs(sol["states"][:, :, b] - ox), np.abs(sol["controls"][:, :, b] - ou)
+                print(f"    launched solve {rnd} instance {b}: iter {st['iter'][b]} / oracle {orcs[b].stats()['iter']}, status {st['status'][b]} / {orcs[b].stats()['status']}; "
+                      f"states {dxs.max() / np.abs(ox).max():.2e} at {np.unravel_index(dxs.argmax(), dxs.shape)} controls {dus.max() / max(np.abs(ou).max(), 1e-300):.2e} at {np.unravel_index(dus.argmax(), dus.shape)} "
+                      f"|u|max {np.abs(ou).max():.3e} residuals gpu {st['residuals'][:, b]} oracle {[orcs[b].stats()[k] for k in ('pri_x', 'dua_x', 'pri_u', 'dua_u')]}", flush=True)
     layout = s.launch_info()["layout"]
     on_f += layout == "F"
     sess = ""
