@@ -29,8 +29,13 @@ def _solver(pkg, prob, settings, families=False):
     return s
 
 
+@pytest.mark.parametrize("mailbox", ["device", "host"])
 @pytest.mark.parametrize("name", ["cartpole", "quadrotor"])
-def test_session_ticks_equal_launched_ticks(pkg, name):
+def test_session_ticks_equal_launched_ticks(pkg, monkeypatch, name, mailbox):
+    """(mailbox: in device memory behind the PCIe BAR where the device maps it -- round 5's default --, or in pinned host memory, the
+    fall-back for devices that do not and TINYMPC_MAILBOX=host: the same protocol over another path, the kernel polling across PCIe)"""
+    if mailbox == "host":
+        monkeypatch.setenv("TINYMPC_MAILBOX", "host")  # (read when a handle's arenas are acquired: tinympc_setup)
     P = pkg.problems
     prob = P.cartpole(10, True) if name == "cartpole" else P.quadrotor(50)
     settings = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=80)
@@ -358,3 +363,33 @@ def test_resident_solves_are_the_reference_loop_on_the_resident_kernel(pkg, name
     c.solve()
     assert c.get_stats_batch()["iter"].min() >= 1
     c.reset()
+
+
+def test_early_answer_is_the_solutions_first_column_when_the_controls_saturate(pkg):
+    """The tick's first controls travel ahead of the solution in a stamped 64-byte line (SolveParams::host_ans). Round 5's fuzzer caught one
+    tick in ~3,000 returning zeros there while the solution itself was right: saturated controls (+b, +b, -b, -b) had the XOR checksum of an
+    empty line, and the host read the line's words before its stamp (profiles/r05_session_stamp_bug.txt). A race cannot be pinned by a
+    deterministic test; this one is the self-consistency check that would have shown it within a few thousand ticks: session_step's
+    controls against the first column of get_solution, tick by tick, on a system whose inputs sit on their bounds with changing signs."""
+    rng = np.random.default_rng(3)
+    nx, nu, N = 10, 4, 12
+    A = 0.9 * np.eye(nx) + (0.1 / np.sqrt(nx)) * rng.standard_normal((nx, nx))
+    B = 0.3 * rng.standard_normal((nx, nu))
+    prob = pkg.problems.Problem("saturating", A, B, np.diag(rng.uniform(1, 10, nx)), np.diag(rng.uniform(0.5, 2, nu)), N, 1.5, rng.standard_normal(nx))
+    prob.x_min, prob.x_max = np.full(nx, -50.0), np.full(nx, 50.0)
+    prob.u_min, prob.u_max = np.full(nu, -0.4), np.full(nu, 0.4)
+    s = _solver(pkg, prob, dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=6))
+    s.prepare()
+    s.session_begin()
+    saturated, patterns = 0, set()
+    for k in range(4000):
+        x = 4.0 * rng.standard_normal(nx)
+        u = s.session_step(x)
+        full = s.get_solution()["controls"][:, 0]
+        assert np.array_equal(u, full), (k, u, full)
+        if np.all(np.abs(np.abs(u) - 0.4) < 1e-12):
+            saturated += 1
+            patterns.add(tuple(np.sign(u).astype(int)))
+    s.session_end()
+    assert saturated > 1000 and len(patterns) >= 6, (saturated, patterns)  # (the test must exercise what it is about)
+    s.reset()

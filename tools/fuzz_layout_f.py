@@ -100,7 +100,7 @@ for case in range(count):
     layout = s.launch_info()["layout"]
     on_f += layout == "F"
     sess = ""
-    if batch == 1 and layout == "F":  # resident session against launched ticks of a twin handle, bit for bit
+    if batch == 1 and (layout == "F" or (layout == "C" and "FUZZ_LAYOUT" in os.environ)):  # resident session against launched ticks of a twin handle, bit for bit
         twin = handle()
         x = x0s[:, 0].copy()
         for h in (s, twin):
@@ -124,9 +124,9 @@ for case in range(count):
                 x = prob.A @ x + prob.B @ ua + (prob.fdyn if prob.fdyn is not None else 0.0)
             s.session_end()
             sessions += 1
-            sess = (" session(%s)==launched" % resident) if same else (" session on layout %s, launches on F: last bits differ" % resident if resident != "F" else " SESSION DIFFERS")
-            ok = ok and (same or (resident != "F" and close))  # (a session on the generic latency kernel: documented, not bit-identical to layout F's launches)
-            if resident != "F" and not close:
+            sess = (" session(%s)==launched" % resident) if same else (" session on layout %s, launches on %s: last bits differ" % (resident, layout) if resident != layout else " SESSION DIFFERS")
+            ok = ok and (same or (resident != layout and close))  # (a session on the generic latency kernel: documented, not bit-identical to layout F's launches)
+            if resident != layout and not close:
                 sess += " AND NOT EVEN CLOSE"
         except pkg.TinyMPCError as err:
             sess = " (no session: %s)" % str(err)[:60]
