@@ -48,6 +48,18 @@ for case in range(count):
         x0s = np.asfortranarray(P.quadrotor_batch_x0(B) * rng.uniform(0.05, 3.0, B)[None, :])
     settings = dict(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=max_iter, check_termination=ct)
     t0 = time.time()
+    if "FUZZ_ONLY_CASE" in os.environ and case != int(os.environ["FUZZ_ONLY_CASE"]):
+        rng.choice(B, size=6, replace=False)  # (the sample: keeps the generator's stream in step)
+        continue
+    if "FUZZ_ONLY_CASE" in os.environ:  # how well conditioned is the case? the LQR cache against the oracle's, the plant's spectral radius
+        os.environ["TINYMPC_REFILL"] = "0"
+        h = pkg.TinyMPC(); h.setup(prob.A, prob.B, prob.Q, prob.R, prob.N, batch=1, rho=prob.rho, **settings)
+        o = O.OraclePort(prob).load_problem(prob, settings)
+        gc = h.get_cache()
+        print("    spectral radius of A %.4f, max|Pinf| %.3e; cache vs oracle:" % (np.abs(np.linalg.eigvals(prob.A)).max(), np.abs(np.asarray(o.get("Pinf"))).max()),
+              ", ".join("%s %.1e" % (k, np.max(np.abs(np.asarray(gc[k]) - np.asarray(o.get(k)))) / np.max(np.abs(np.asarray(o.get(k))))) for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt")), flush=True)
+        print("    Riccati steps: kernel %d, oracle %s" % (int(h.debug_setup_timing()["riccati_steps"]), o.stats().get("riccati_iters")), flush=True)
+        h.reset()
     got, info = {}, {}
     for mode in ("0", "1"):
         os.environ["TINYMPC_REFILL"] = mode
