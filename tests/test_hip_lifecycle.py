@@ -165,3 +165,18 @@ def test_single_instance_host_path_states(pkg):
     s.reset_workspace()                            # cold start: solution and statistics read as zero again
     assert not s.get_solution()["states"].any() and s.get_stats()["iter"] == 0
     s.reset()
+
+
+@pytest.mark.gpu
+def test_host_threads_share_the_device(pkg):
+    """tools/thread_stress.py in small: three host threads cycle through setup -> solve -> reset on handles of their own (pooled streams and
+    arenas change hands, specialisations are looked up concurrently) while a fourth keeps a resident session ticking, parked by every setup
+    of the others and restarted by its next step. Round 5 found a reader of the session's solution waiting for the sequence number of
+    another thread's park command (wait_session_solution); every result must equal the single-threaded one bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_stress.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "0 error(s)" in out.stdout

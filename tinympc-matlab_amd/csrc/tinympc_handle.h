@@ -171,6 +171,7 @@ struct tinympc_solver {
     // ONE counter stamps session commands and flag-raising launches alike (both complete by writing their stamp into the
     // same slot of h_sol: a launch after a session must not find its number already there)
     unsigned long long session_seq = 0;  // stamp of the last session command / flag-raising launch
+    unsigned long long answered_seq = 0;  // ... of the session tick whose early answer was taken last (its write-out is what host_sol_state 3 waits for)
     bool flag_pending = false;
     // ... and set_x_ref / set_u_ref only fill these pinned copies; the next launch's workgroup rebuilds the
     // reference-dependent table rows from them (refresh_reference_tables): a tick with per-tick references

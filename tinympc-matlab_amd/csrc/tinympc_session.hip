@@ -131,8 +131,13 @@ void tinympc::host::park_sessions_on_device(int device, const tinympc_solver *ex
 
 int tinympc::host::wait_session_solution(tinympc_solver *s) {
     if (s->host_sol_state != 3) return TINYMPC_OK;
+    // Under the handle's session mutex: another thread's setup may be parking this kernel right now (park_sessions_on_device) -- its stop
+    // command takes the next sequence number, and a reader that looked at session_seq instead of the answered tick's own number waited
+    // for a stamp nobody writes (tools/thread_stress.py, round 5: "not completed ... within 5 s"). The park completes the state itself.
+    std::lock_guard<std::mutex> tick(s->session_mu);
+    if (s->host_sol_state != 3) return TINYMPC_OK;
     const volatile double *done = s->h_sol + s->X() + s->U() + 6;
-    const double want = (double)s->session_seq;
+    const double want = (double)s->answered_seq;
     const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0; *done != want; ++spin) {
         __builtin_ia32_pause();
@@ -290,7 +295,8 @@ static int session_tick_locked(tinympc_solver *s, const double *x0, double *u0_o
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if (early) {
-        s->host_sol_state = 3;  // (solution + statistics: valid once the stamp behind them reads session_seq -- wait_session_solution)
+        s->answered_seq = s->session_seq;
+        s->host_sol_state = 3;  // (solution + statistics: valid once the stamp behind them reads answered_seq -- wait_session_solution)
         std::memcpy(u0_out, u0_lines, sizeof(double) * s->nu);
     } else {
         s->host_sol_state = 2;
