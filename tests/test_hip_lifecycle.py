@@ -180,3 +180,8 @@ def test_host_threads_share_the_device(pkg):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_stress.py"), "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "0 error(s)" in out.stdout
+    # ... and several sessions at once, each on its own host thread, parking one another with every setup. With ROCm's default of four
+    # hardware queues per process the launched twins queued behind resident kernels (2 s per tick); the library's default for
+    # GPU_MAX_HW_QUEUES (tinympc_handle.hip) is what this checks. The tool dumps every thread's stack and exits after 45 s of stall.
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_sessions.py"), "3", "3", "80"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "0 error(s)" in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]

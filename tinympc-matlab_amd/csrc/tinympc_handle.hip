@@ -2,6 +2,8 @@
 // operators / per-knot tables, the per-lane description of the cone / linear families. No solver arithmetic happens here.
 #include "tinympc_handle.h"
 
+#include <cstdlib>
+
 #include <atomic>
 #include <cstdarg>
 #include <cstring>
@@ -47,6 +49,14 @@ std::vector<ArenaKit> g_arenas[64];             // [device]; under g_kits_mu
 constexpr size_t kArenaKeepBytes = 4u << 20;    // device bytes of an arena worth keeping (a quadrotor N=50 instance: 0.1 MB)
 constexpr size_t kArenasKept = 8;
 }  // namespace
+
+// HIP streams are multiplexed onto a few hardware queues -- four per process unless GPU_MAX_HW_QUEUES says otherwise --, and a hardware queue
+// runs its packets in order: with more streams alive than queues, a launch can land BEHIND another handle's resident session kernel and
+// wait until that kernel's idle time-out (2 s), tick after tick (tools/thread_sessions.py, round 5: three host threads with a session and
+// a launched twin each stalled in five runs of six; none of twelve with 16 queues). The runtime reads the variable when it initialises:
+// set a default when this library is loaded (never over the user's own value). A process that initialised HIP before loading the library
+// has to set it itself -- INTEGRATION.md.
+__attribute__((constructor(101))) static void tinympc_default_environment() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 // Can the host store into device memory (the whole of it mapped through the PCIe BAR)? Asked once per device.
 static bool device_is_large_bar(int device) {
